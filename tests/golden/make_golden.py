@@ -1,0 +1,153 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under tests/golden/ by running the UNMODIFIED reference.
+
+The reference (/root/reference/Source.cpp) is compiled where it lies into
+oracle/_ref/libaai_ref.so by oracle/Makefile and driven through oracle/pyoracle.ref_run.
+Only inputs (as generator seeds / parameters) and outputs (raw float64) are stored -- no reference
+source text.  Run from the repo root in the build container (the reference is absent on the GPU box):
+
+    python tests/golden/make_golden.py small          # tests/golden/small_cases.npz      (seconds)
+    python tests/golden/make_golden.py errors         # tests/golden/error_paths.json
+    python tests/golden/make_golden.py full cfg2      # tests/golden/full_cfg2.npz         (minutes, 1 core)
+    python tests/golden/make_golden.py full all       # every BASELINE.json config that is CPU-feasible
+
+`full` stores, for the BASELINE-size runs, the long-double sum, the zero count, a strided sample
+grid of the output and a few complete rows (SURVEY.md Appendix C style known answers), not the
+whole image.
+"""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from oracle import pyoracle as po  # noqa: E402
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+# (name, W, H, srcRes, dstRes, iso or None (= image centre), angle)
+ANGLES = [0, 0.5, 1.5, 10, 17.5, 44.999, 45, 89.5, 90, 135, 180, 200, 270, 300, -17.5, 377.5]
+RATIOS = [(2, 1), (3, 1), (4, 1), (8192, 2731), (10, 9), (1, 1), (10, 17), (1, 4)]
+
+
+def small_case_list():
+    cases = []
+    n = 0
+    for ang in ANGLES:
+        for (sr, dr) in RATIOS:
+            W, H = (24, 17) if dr / sr <= 1 else (9, 7)
+            iso = [None, (0.0, 0.0), (10.25, 3.5), (W - 1.0, H - 1.0)][n % 4]
+            cases.append(dict(W=W, H=H, seed=n + 1, src_res=float(sr), dst_res=float(dr), iso=iso, angle=float(ang)))
+            n += 1
+    # square / larger / knife-edge quarantine cases: kept as golden vectors only
+    extra = [
+        dict(W=64, H=64, seed=101, src_res=2.0, dst_res=1.0, iso=None, angle=0.0),
+        dict(W=64, H=48, seed=102, src_res=4.0, dst_res=1.0, iso=None, angle=0.0),
+        dict(W=48, H=64, seed=103, src_res=3.0, dst_res=1.0, iso=None, angle=0.0),
+        dict(W=40, H=40, seed=104, src_res=2.0, dst_res=1.0, iso=None, angle=30.0),
+        dict(W=40, H=40, seed=105, src_res=2.0, dst_res=1.0, iso=None, angle=60.0),
+        dict(W=33, H=21, seed=106, src_res=150.0, dst_res=25.4, iso=(15.0, 9.0), angle=1.5),   # Source.cpp:1530-1533 style
+        dict(W=32, H=32, seed=107, src_res=1.0, dst_res=2.0, iso=None, angle=45.0),
+        dict(W=50, H=37, seed=108, src_res=5.0, dst_res=1.0, iso=(3.25, 30.5), angle=123.4),
+        dict(W=37, H=50, seed=109, src_res=2.5, dst_res=1.0, iso=None, angle=251.0),
+        dict(W=1, H=1, seed=110, src_res=1.0, dst_res=1.0, iso=(0.0, 0.0), angle=0.0),
+        dict(W=1, H=5, seed=111, src_res=1.0, dst_res=1.0, iso=(0.0, 2.0), angle=33.0),
+        dict(W=7, H=1, seed=112, src_res=2.0, dst_res=1.0, iso=(3.0, 0.0), angle=0.0),
+    ]
+    return cases + extra
+
+
+def gen_small():
+    cases = small_case_list()
+    store = {}
+    manifest = []
+    for i, c in enumerate(cases):
+        src = po.synth_image(c["W"], c["H"], c["seed"]).astype(np.float64)
+        iso = c["iso"] if c["iso"] is not None else ((c["W"] - 1) / 2.0, (c["H"] - 1) / 2.0)
+        entry = dict(c)
+        entry["iso"] = list(iso)
+        for mode, tag in ((po.MODE_EXACT, "exact"), (po.MODE_FAST, "fast")):
+            r = po.ref_run(mode, src, c["src_res"], c["dst_res"], iso, c["angle"])
+            assert r.ok, r.msg
+            store["c%03d_%s" % (i, tag)] = r.dst
+            entry["dst_iso"] = list(r.dst_iso)
+            entry["shape"] = list(r.dst.shape)
+        manifest.append(entry)
+    store["manifest"] = np.frombuffer(json.dumps(manifest).encode(), dtype=np.uint8)
+    path = os.path.join(HERE, "small_cases.npz")
+    np.savez_compressed(path, **store)
+    print("wrote", path, os.path.getsize(path), "bytes,", len(cases), "cases")
+
+
+def gen_errors():
+    out = []
+    src = np.ones((4, 4))
+    probes = [((1.0, 2.0), (1.0, 1.0)), ((1.0, 1.0), (2.0, 2.5)), ((0.0, 0.0), (1.0, 1.0)),
+              ((1.0, 1.0), (-1.0, -1.0)), ((1.0, 1.0), (0.0, 0.0))]
+    for mode in (po.MODE_EXACT, po.MODE_FAST):
+        for sr, dr in probes:
+            r = po.ref_run(mode, src, sr, dr, (0, 0), 0)
+            out.append(dict(mode=mode, kind="args", src_res=list(sr), dst_res=list(dr), ok=r.ok, msg=r.msg))
+        for rows in (0, 3):
+            ok, msg = po.ref_run_empty(mode, rows)
+            out.append(dict(mode=mode, kind="empty", rows=rows, ok=ok, msg=msg))
+    path = os.path.join(HERE, "error_paths.json")
+    with open(path, "w") as f:
+        json.dump(out, f, indent=1)
+    print("wrote", path)
+
+
+# BASELINE.json configs (resolutions, isocenter = image centre, seed 1)
+FULL = {
+    "cfg1": dict(W=512, H=512, src_res=2.0, dst_res=1.0, angle=0.0, modes=("exact", "fast")),
+    "cfg2": dict(W=8192, H=8192, src_res=4.0, dst_res=1.0, angle=0.0, modes=("exact",)),
+    "cfg3": dict(W=8192, H=8192, src_res=8192.0, dst_res=2731.0, angle=17.5, modes=("exact", "fast")),
+    "cfg4": dict(W=4096, H=4096, src_res=4.0, dst_res=1.0, angle=0.0, modes=("exact",)),
+    "cfg5s": dict(W=512, H=512, src_res=1.0, dst_res=4.0, angle=45.0, modes=("exact", "fast")),   # 1/8 linear scale of cfg5
+}
+
+
+def gen_full(name):
+    c = FULL[name]
+    W, H = c["W"], c["H"]
+    src = po.synth_image(W, H, 1).astype(np.float64)
+    iso = ((W - 1) / 2.0, (H - 1) / 2.0)
+    store = {}
+    meta = dict(name=name, W=W, H=H, seed=1, src_res=c["src_res"], dst_res=c["dst_res"], iso=list(iso), angle=c["angle"])
+    for tag in c["modes"]:
+        mode = po.MODE_EXACT if tag == "exact" else po.MODE_FAST
+        t0 = time.time()
+        r = po.ref_run(mode, src, c["src_res"], c["dst_res"], iso, c["angle"])
+        dt = time.time() - t0
+        assert r.ok, r.msg
+        d = r.dst
+        h, w = d.shape
+        step = max(1, min(h, w) // 48)
+        rows = sorted(set([0, 1, h // 3, h // 2, (2 * h) // 3, h - 2, h - 1]))
+        store[tag + "_grid"] = d[::step, ::step].copy()
+        store[tag + "_rows"] = d[rows, :].copy()
+        meta[tag] = dict(shape=[h, w], dst_iso=list(r.dst_iso), sum=repr(float(np.sum(d.astype(np.longdouble)))),
+                         zeros=int((d == 0).sum()), step=step, rows=rows, ref_seconds=dt,
+                         out_mpix_per_s=h * w / dt / 1e6)
+        print(name, tag, d.shape, "%.1fs" % dt, meta[tag]["sum"], meta[tag]["zeros"], flush=True)
+    store["meta"] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
+    path = os.path.join(HERE, "full_%s.npz" % name)
+    np.savez_compressed(path, **store)
+    print("wrote", path, os.path.getsize(path), "bytes")
+
+
+if __name__ == "__main__":
+    if not po.have_ref():
+        po.build()
+    what = sys.argv[1] if len(sys.argv) > 1 else "small"
+    if what == "small":
+        gen_small()
+    elif what == "errors":
+        gen_errors()
+    elif what == "full":
+        names = list(FULL) if sys.argv[2] == "all" else sys.argv[2:]
+        for n in names:
+            gen_full(n)
