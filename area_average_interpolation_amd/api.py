@@ -1,0 +1,152 @@
+"""Host-side mirror of the reference's call surface on top of the C ABI (libaai_hip.so).
+
+The reference boundary is ``class AreaAverageInterpolation`` with two methods of identical signature
+(/root/reference/Source.cpp:55-57 and 584-586)::
+
+    pair<bool,string> areaAverageInterpolation    (IMG src, IMG &dst, dP srcResolution, dP dstResolution,
+    pair<bool,string> fastAreaAverageInterpolation              dP srcIsocenter, dP &dstIsocenter, double rotationAngle)
+
+Python has no out-parameters, so the two methods below keep the names, the argument order and meaning and
+the error behaviour, and return ``((ok, message), dst, dstIsocenter)``; on failure ``dst`` and
+``dstIsocenter`` are ``None`` (the reference leaves them untouched).  The C++ drop-in with the exact
+reference signature is include/AreaAverageInterpolation.hpp.
+
+Everything here is plumbing around the C ABI; all arithmetic happens in the HIP kernels.
+"""
+import ctypes
+
+import numpy as np
+
+from . import _lib as L
+
+
+class AaiError(RuntimeError):
+    def __init__(self, code, message):
+        super().__init__("aai error %d: %s" % (code, message))
+        self.code, self.message = code, message
+
+
+def _pair(v):
+    if np.isscalar(v):
+        return float(v), float(v)
+    return float(v[0]), float(v[1])
+
+
+def make_request(width, height, src_resolution, dst_resolution, src_isocenter, rotation_angle,
+                 mode=L.MODE_AREA, policy=L.POLICY_REFERENCE):
+    sr, dr, iso = _pair(src_resolution), _pair(dst_resolution), _pair(src_isocenter)
+    return L.Request(int(mode), int(policy), int(width), int(height), sr[0], sr[1], dr[0], dr[1],
+                     iso[0], iso[1], float(rotation_angle))
+
+
+def last_error():
+    return L.load().aai_last_error().decode()
+
+
+def query(request):
+    """aai_query: validate + output layout.  Returns (code, message, Layout-or-None).  Needs no GPU."""
+    lib = L.load()
+    lay = L.Layout()
+    rc = lib.aai_query(ctypes.byref(request), ctypes.byref(lay))
+    if rc != L.OK:
+        return rc, last_error(), None
+    return rc, "", lay
+
+
+def device_count():
+    n = ctypes.c_int(0)
+    L.load().aai_device_count(ctypes.byref(n))
+    return n.value
+
+
+def set_device(ordinal):
+    rc = L.load().aai_set_device(int(ordinal))
+    if rc != L.OK:
+        raise AaiError(rc, last_error())
+
+
+def synchronize():
+    rc = L.load().aai_device_synchronize()
+    if rc != L.OK:
+        raise AaiError(rc, last_error())
+
+
+def last_kernel():
+    return L.load().aai_last_kernel().decode()
+
+
+def resample_host(src, src_resolution, dst_resolution, src_isocenter, rotation_angle,
+                  mode=L.MODE_AREA, policy=L.POLICY_REFERENCE):
+    """Host-buffer path (aai_resample_f32 / aai_resample_f64 by dtype).
+
+    Returns (code, message, dst ndarray or None, (dstIsoX, dstIsoY) or None, Layout or None)."""
+    lib = L.load()
+    a = np.asarray(src)
+    if a.ndim != 2:
+        # the reference's two "no data" errors (Source.cpp:123-132)
+        a = a.reshape(0, 0) if a.size == 0 else a
+    if a.dtype != np.float32:
+        a = a.astype(np.float64, copy=False)
+    a = np.ascontiguousarray(a)
+    H, W = (a.shape[0], a.shape[1]) if a.ndim == 2 else (0, 0)
+    rq = make_request(W, H, src_resolution, dst_resolution, src_isocenter, rotation_angle, mode, policy)
+    rc, msg, lay = query(rq)
+    if rc != L.OK:
+        return rc, msg, None, None, None
+    dst = np.empty((lay.dst_height, lay.dst_width), dtype=a.dtype)
+    fn = lib.aai_resample_f32 if a.dtype == np.float32 else lib.aai_resample_f64
+    out_lay = L.Layout()
+    rc = fn(ctypes.byref(rq), a.ctypes.data, W, dst.ctypes.data, max(lay.dst_width, 1), ctypes.byref(out_lay))
+    if rc != L.OK:
+        return rc, last_error(), None, None, None
+    return rc, "", dst, (out_lay.dst_iso_x, out_lay.dst_iso_y), out_lay
+
+
+def resample_device(request, src_ptr, src_stride, dst_ptr, dst_stride, stream=0, batch=None,
+                    src_image_stride=0, dst_image_stride=0):
+    """Device-resident path: raw device pointers (ints) and a hipStream_t handle (int, 0 = default)."""
+    lib = L.load()
+    if batch is None:
+        rc = lib.aai_resample_device_f32(ctypes.byref(request), src_ptr, src_stride, dst_ptr, dst_stride, stream)
+    else:
+        rc = lib.aai_resample_batch_device_f32(ctypes.byref(request), int(batch), src_ptr, src_stride, src_image_stride,
+                                               dst_ptr, dst_stride, dst_image_stride, stream)
+    if rc != L.OK:
+        raise AaiError(rc, last_error())
+
+
+def synth_device(dst_ptr, width, height, stride, seed, stream=0):
+    rc = L.load().aai_synth_device_f32(dst_ptr, int(width), int(height), int(stride), int(seed), stream)
+    if rc != L.OK:
+        raise AaiError(rc, last_error())
+
+
+class AreaAverageInterpolation:
+    """Stateless, like the reference class (no data members, Source.cpp:52-54)."""
+
+    def __init__(self, policy=L.POLICY_REFERENCE):
+        self.policy = policy
+
+    def _call(self, mode, src, srcResolution, dstResolution, srcIsocenter, rotationAngle):
+        rc, msg, dst, iso, _ = resample_host(src, srcResolution, dstResolution, srcIsocenter, rotationAngle,
+                                             mode=mode, policy=self.policy)
+        if rc in (L.ERR_RESOLUTION_MISMATCH, L.ERR_RESOLUTION_NONPOSITIVE, L.ERR_NO_ROWS, L.ERR_NO_COLUMNS):
+            return (False, msg), None, None          # the reference's {false, message}
+        if rc != L.OK:
+            raise AaiError(rc, msg)                  # conditions the reference cannot report
+        return (True, ""), dst, iso
+
+    def areaAverageInterpolation(self, src, srcResolution, dstResolution, srcIsocenter, rotationAngle):
+        """Source.cpp:55"""
+        return self._call(L.MODE_AREA, src, srcResolution, dstResolution, srcIsocenter, rotationAngle)
+
+    def fastAreaAverageInterpolation(self, src, srcResolution, dstResolution, srcIsocenter, rotationAngle):
+        """Source.cpp:584"""
+        return self._call(L.MODE_FAST, src, srcResolution, dstResolution, srcIsocenter, rotationAngle)
+
+    # build-defined comparison paths (README.md:8 of the reference names them; it implements neither)
+    def bilinearInterpolation(self, src, srcResolution, dstResolution, srcIsocenter, rotationAngle):
+        return self._call(L.MODE_BILINEAR, src, srcResolution, dstResolution, srcIsocenter, rotationAngle)
+
+    def bicubicInterpolation(self, src, srcResolution, dstResolution, srcIsocenter, rotationAngle):
+        return self._call(L.MODE_BICUBIC, src, srcResolution, dstResolution, srcIsocenter, rotationAngle)

@@ -1,0 +1,377 @@
+// aai_capi.cpp -- the C ABI declared in include/aai.h: request validation, plan cache (device-side
+// weight tables for the axis-aligned kernel), kernel dispatch, and the host-buffer convenience calls.
+//
+// There is deliberately no CPU implementation behind this ABI: without a HIP device every compute entry
+// point fails with AAI_ERR_NO_DEVICE.  The CPU oracle under oracle/ is test infrastructure and is never
+// linked or loaded here.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstring>
+#include <list>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "aai_kernels.hpp"
+
+namespace {
+
+thread_local std::string g_lastError;
+thread_local std::string g_lastKernel;
+
+int fail(int code, const std::string &msg)
+{
+    g_lastError = msg;
+    return code;
+}
+
+int hip_fail(hipError_t e, const char *what)
+{
+    std::string m = std::string(what) + ": " + hipGetErrorString(e);
+    // a missing / unusable device is reported as such so callers can tell it from a kernel fault
+    if (e == hipErrorNoDevice || e == hipErrorInvalidDevice || e == hipErrorInsufficientDriver || e == hipErrorNotInitialized)
+        return fail(AAI_ERR_NO_DEVICE, m);
+    return fail(AAI_ERR_HIP, m);
+}
+
+#define AAI_HIP(call)                                        \
+    do {                                                     \
+        hipError_t e__ = (call);                             \
+        if (e__ != hipSuccess) return hip_fail(e__, #call);  \
+    } while (0)
+
+// ---- plan cache ------------------------------------------------------------------------------------
+struct Plan {
+    aai_request key{};
+    int device = -1;
+    aai::Geometry g;
+    int kernel = 0;
+    // K1
+    aai::AxisTables tabs;
+    aai::AxisEntry *dLane = nullptr, *dRow = nullptr;
+    aai::AxisStrip *dStrips = nullptr;
+    ~Plan()
+    {
+        if (dLane) (void)hipFree(dLane);
+        if (dRow) (void)hipFree(dRow);
+        if (dStrips) (void)hipFree(dStrips);
+    }
+};
+
+std::mutex g_planMutex;
+std::list<Plan> g_plans;              // most recently used first
+constexpr size_t kMaxPlans = 32;
+
+bool same_request(const aai_request &a, const aai_request &b)
+{
+    return a.mode == b.mode && a.policy == b.policy && a.src_width == b.src_width && a.src_height == b.src_height &&
+           a.src_res_x == b.src_res_x && a.src_res_y == b.src_res_y && a.dst_res_x == b.dst_res_x &&
+           a.dst_res_y == b.dst_res_y && a.src_iso_x == b.src_iso_x && a.src_iso_y == b.src_iso_y &&
+           a.rotation_deg == b.rotation_deg;
+}
+
+int check_request(const aai_request *rq)
+{
+    if (!rq) return fail(AAI_ERR_BAD_ARGUMENT, "Null request.");
+    if (rq->mode < AAI_MODE_AREA || rq->mode > AAI_MODE_BICUBIC) return fail(AAI_ERR_BAD_ARGUMENT, "Unknown interpolation mode.");
+    if (rq->policy != AAI_POLICY_REFERENCE && rq->policy != AAI_POLICY_EXACT) return fail(AAI_ERR_BAD_ARGUMENT, "Unknown weight policy.");
+    return AAI_OK;
+}
+
+int pick_kernel(const aai_request &rq, const aai::Geometry &g)
+{
+    if (rq.mode == AAI_MODE_BILINEAR || rq.mode == AAI_MODE_BICUBIC) return AAI_KERNEL_SAMPLE;
+    if (g.axisAligned) return AAI_KERNEL_AXIS;
+    return rq.mode == AAI_MODE_FAST ? AAI_KERNEL_FAST : AAI_KERNEL_ROTATED;
+}
+
+int resolved_kernel(const aai_request &rq, const aai::Geometry &g)
+{
+    int kernel = pick_kernel(rq, g);
+    if (kernel == AAI_KERNEL_AXIS) {
+        aai::AxisTables t;
+        aai::build_axis_tables(g, rq.mode, t);
+        if (t.wide) kernel = AAI_KERNEL_AXIS_WIDE;
+    }
+    return kernel;
+}
+
+void fill_layout(const aai::Geometry &g, int kernel, aai_layout *out)
+{
+    aai_layout l{};
+    l.dst_width = g.dW; l.dst_height = g.dH;
+    l.dst_iso_x = g.dIsoX; l.dst_iso_y = g.dIsoY;
+    l.scale = g.scale; l.quadrant = g.quadrant;
+    l.reduced_angle_deg = g.angle; l.side = g.side;
+    l.kernel = kernel;
+    *out = l;
+}
+
+// Finds or builds the plan for (request, current device).  Returns a pointer valid until evicted; callers
+// hold g_planMutex for the duration of the launch (launches only enqueue, so this is short).
+int get_plan(const aai_request &rq, Plan **out)
+{
+    int dev = -1;
+    AAI_HIP(hipGetDevice(&dev));
+    for (auto it = g_plans.begin(); it != g_plans.end(); ++it) {
+        if (it->device == dev && same_request(it->key, rq)) {
+            g_plans.splice(g_plans.begin(), g_plans, it);
+            *out = &g_plans.front();
+            return AAI_OK;
+        }
+    }
+    aai::Geometry g;
+    std::string msg;
+    int rc = aai::make_geometry(rq, g, msg);
+    if (rc != AAI_OK) return fail(rc, msg);
+
+    g_plans.emplace_front();
+    Plan &p = g_plans.front();
+    p.key = rq; p.device = dev; p.g = g; p.kernel = pick_kernel(rq, g);
+    if (p.kernel == AAI_KERNEL_AXIS) {
+        aai::build_axis_tables(g, rq.mode, p.tabs);
+        if (p.tabs.wide) p.kernel = AAI_KERNEL_AXIS_WIDE;
+        auto upload = [&](const void *h, size_t bytes, void **d) -> hipError_t {
+            if (!bytes) { *d = nullptr; return hipSuccess; }
+            hipError_t e = hipMalloc(d, bytes);
+            if (e != hipSuccess) return e;
+            return hipMemcpy(*d, h, bytes, hipMemcpyHostToDevice);
+        };
+        hipError_t e = upload(p.tabs.lane.data(), p.tabs.lane.size() * sizeof(aai::AxisEntry), (void **)&p.dLane);
+        if (e == hipSuccess) e = upload(p.tabs.row.data(), p.tabs.row.size() * sizeof(aai::AxisEntry), (void **)&p.dRow);
+        if (e == hipSuccess) e = upload(p.tabs.strips.data(), p.tabs.strips.size() * sizeof(aai::AxisStrip), (void **)&p.dStrips);
+        if (e != hipSuccess) { g_plans.pop_front(); return hip_fail(e, "uploading axis tables"); }
+    }
+    while (g_plans.size() > kMaxPlans) g_plans.pop_back();
+    *out = &p;
+    return AAI_OK;
+}
+
+int enqueue(const aai_request &rq, int batch, const float *dSrc, int64_t srcStride, int64_t srcImageStride,
+            float *dDst, int64_t dstStride, int64_t dstImageStride, hipStream_t stream)
+{
+    std::lock_guard<std::mutex> lock(g_planMutex);
+    Plan *p = nullptr;
+    int rc = get_plan(rq, &p);
+    if (rc != AAI_OK) return rc;
+    const aai::Geometry &g = p->g;
+    if (srcStride < g.W) return fail(AAI_ERR_BAD_ARGUMENT, "Source stride smaller than the image width.");
+    if (dstStride < g.dW) return fail(AAI_ERR_BAD_ARGUMENT, "Destination stride smaller than the output width.");
+    if (g.dW == 0 || g.dH == 0 || batch == 0) return AAI_OK;
+
+    aai::ImageView sv{srcStride, srcImageStride}, dv{dstStride, dstImageStride};
+    const char *name = "";
+    hipError_t e;
+    if (p->kernel == AAI_KERNEL_AXIS || p->kernel == AAI_KERNEL_AXIS_WIDE) {
+        const aai::AxisTables &t = p->tabs;
+        aai::AxisLaunch a{};
+        a.laneTab = p->dLane; a.rowTab = p->dRow; a.strips = p->dStrips;
+        a.nA = t.nA; a.nB = t.nB; a.nStrips = (int)t.strips.size();
+        a.srcW = g.W; a.srcH = g.H;
+        a.wide = t.wide ? 1 : 0;
+        // (ka,kb) -> dst element: the lane axis is dst x unless the quadrant transposes; flips run an axis
+        // backwards
+        const int64_t sa = t.transposed ? dstStride : 1, sb = t.transposed ? 1 : dstStride;
+        a.outStrideA = t.flipA ? -sa : sa;
+        a.outStrideB = t.flipB ? -sb : sb;
+        a.outBase = (t.flipA ? (int64_t)(t.nA - 1) * sa : 0) + (t.flipB ? (int64_t)(t.nB - 1) * sb : 0);
+        e = aai::launch_axis(a, dSrc, sv, dDst, dv, batch, stream, &name);
+    } else {
+        aai::RotLaunch r{};
+        r.fracX = g.fracX; r.fracY = g.fracY; r.side = g.side; r.isoX = g.isoX; r.isoY = g.isoY;
+        r.offX = g.offX; r.offY = g.offY; r.sn = g.sn; r.cs = g.cs;
+        r.reach = g.side * std::sqrt(2.0) / 2 + 1;
+        r.dW = g.dW; r.dH = g.dH; r.mW = g.mW; r.mH = g.mH; r.W = g.W; r.H = g.H;
+        r.scale = g.scale; r.quadrant = g.quadrant; r.mode = rq.mode; r.policy = rq.policy;
+        e = aai::launch_rotated(r, dSrc, sv, dDst, dv, batch, stream, &name);
+    }
+    g_lastKernel = name;
+    if (e != hipSuccess) return hip_fail(e, name);
+    return AAI_OK;
+}
+
+int require_device()
+{
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) {
+        (void)hipGetLastError();
+        return fail(AAI_ERR_NO_DEVICE, "No HIP device available: libaai_hip has no CPU fallback.");
+    }
+    return AAI_OK;
+}
+
+}  // namespace
+
+// Host-buffer convenience path: H2D, one launch, D2H.  T is float or double (converted on the device).
+template <typename T>
+int resample_host(const aai_request *req, const T *src, int64_t srcStride, T *dst, int64_t dstStride, aai_layout *layout)
+{
+    int rc = check_request(req);
+    if (rc != AAI_OK) return rc;
+    aai::Geometry g;
+    std::string msg;
+    rc = aai::make_geometry(*req, g, msg);
+    if (rc != AAI_OK) return fail(rc, msg);
+    if (!src || !dst) return fail(AAI_ERR_BAD_ARGUMENT, "Null image pointer.");
+    if (srcStride < g.W) return fail(AAI_ERR_BAD_ARGUMENT, "Source stride smaller than the image width.");
+    if (dstStride < g.dW) return fail(AAI_ERR_BAD_ARGUMENT, "Destination stride smaller than the output width.");
+    rc = require_device();
+    if (rc != AAI_OK) return rc;
+
+    const size_t nSrc = (size_t)g.W * g.H, nDst = (size_t)g.dW * g.dH;
+    T *dSrcT = nullptr, *dDstT = nullptr;
+    float *dSrc = nullptr, *dDst = nullptr;
+    hipStream_t stream = nullptr;
+    auto cleanup = [&]() {
+        if (dSrcT) (void)hipFree(dSrcT);
+        if (dDstT && (void *)dDstT != (void *)dDst) (void)hipFree(dDstT);
+        if (dSrc && (void *)dSrc != (void *)dSrcT) (void)hipFree(dSrc);
+        if (dDst) (void)hipFree(dDst);
+    };
+#define AAI_HIP_C(call)                                                        \
+    do {                                                                       \
+        hipError_t e__ = (call);                                               \
+        if (e__ != hipSuccess) { cleanup(); return hip_fail(e__, #call); }     \
+    } while (0)
+
+    AAI_HIP_C(hipMalloc((void **)&dSrcT, sizeof(T) * nSrc));
+    AAI_HIP_C(hipMemcpy2D(dSrcT, sizeof(T) * g.W, src, sizeof(T) * srcStride, sizeof(T) * g.W, g.H, hipMemcpyHostToDevice));
+    if (nDst) AAI_HIP_C(hipMalloc((void **)&dDst, sizeof(float) * nDst));
+    if (sizeof(T) == sizeof(float)) {
+        dSrc = reinterpret_cast<float *>(dSrcT);
+        dDstT = reinterpret_cast<T *>(dDst);
+    } else {
+        AAI_HIP_C(hipMalloc((void **)&dSrc, sizeof(float) * nSrc));
+        AAI_HIP_C(aai::launch_f64_to_f32(reinterpret_cast<const double *>(dSrcT), dSrc, nSrc, stream));
+        if (nDst) AAI_HIP_C(hipMalloc((void **)&dDstT, sizeof(T) * nDst));
+    }
+    if (nDst) {
+        rc = enqueue(*req, 1, dSrc, g.W, 0, dDst, g.dW, 0, stream);
+        if (rc != AAI_OK) { cleanup(); return rc; }
+        if (sizeof(T) != sizeof(float))
+            AAI_HIP_C(aai::launch_f32_to_f64(dDst, reinterpret_cast<double *>(dDstT), nDst, stream));
+        AAI_HIP_C(hipStreamSynchronize(stream));
+        AAI_HIP_C(hipMemcpy2D(dst, sizeof(T) * dstStride, dDstT, sizeof(T) * g.dW, sizeof(T) * g.dW, g.dH, hipMemcpyDeviceToHost));
+    }
+    cleanup();
+#undef AAI_HIP_C
+    if (layout) fill_layout(g, resolved_kernel(*req, g), layout);
+    g_lastError.clear();
+    return AAI_OK;
+}
+
+extern "C" {
+
+int aai_version(void) { return AAI_VERSION_MAJOR * 1000 + AAI_VERSION_MINOR; }
+
+const char *aai_last_error(void) { return g_lastError.c_str(); }
+
+const char *aai_last_kernel(void) { return g_lastKernel.c_str(); }
+
+const char *aai_error_string(int code)
+{
+    switch (code) {
+    case AAI_OK: return "";
+    case AAI_ERR_RESOLUTION_MISMATCH: return "Assumed X & Y resolution are same.";
+    case AAI_ERR_RESOLUTION_NONPOSITIVE: return "0 or negative resolution is not acceptable.";
+    case AAI_ERR_NO_ROWS: return "There is no data in src array.";
+    case AAI_ERR_NO_COLUMNS: return "There is no data in the second dimension of src array.";
+    case AAI_ERR_NONFINITE: return "Non-finite argument.";
+    case AAI_ERR_BAD_ARGUMENT: return "Bad argument.";
+    case AAI_ERR_TOO_LARGE: return "Image too large.";
+    case AAI_ERR_NO_DEVICE: return "No HIP device available.";
+    case AAI_ERR_HIP: return "HIP runtime error.";
+    default: return "Unknown error.";
+    }
+}
+
+int aai_query(const aai_request *req, aai_layout *out)
+{
+    int rc = check_request(req);
+    if (rc != AAI_OK) return rc;
+    if (!out) return fail(AAI_ERR_BAD_ARGUMENT, "Null layout.");
+    aai::Geometry g;
+    std::string msg;
+    rc = aai::make_geometry(*req, g, msg);
+    if (rc != AAI_OK) return fail(rc, msg);
+    fill_layout(g, resolved_kernel(*req, g), out);
+    g_lastError.clear();
+    return AAI_OK;
+}
+
+int aai_device_count(int *count)
+{
+    if (!count) return fail(AAI_ERR_BAD_ARGUMENT, "Null count.");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) { (void)hipGetLastError(); n = 0; }
+    *count = n;
+    return AAI_OK;
+}
+
+int aai_set_device(int ordinal)
+{
+    int rc = require_device();
+    if (rc != AAI_OK) return rc;
+    AAI_HIP(hipSetDevice(ordinal));
+    return AAI_OK;
+}
+
+int aai_device_synchronize(void)
+{
+    int rc = require_device();
+    if (rc != AAI_OK) return rc;
+    AAI_HIP(hipDeviceSynchronize());
+    return AAI_OK;
+}
+
+int aai_resample_batch_device_f32(const aai_request *req, int32_t batch,
+                                  const float *d_src, int64_t src_stride, int64_t src_image_stride,
+                                  float *d_dst, int64_t dst_stride, int64_t dst_image_stride, void *stream)
+{
+    int rc = check_request(req);
+    if (rc != AAI_OK) return rc;
+    if (batch < 0 || batch > 65535) return fail(AAI_ERR_BAD_ARGUMENT, "Batch must be in [0, 65535].");
+    // argument errors are reported before the device is touched, like the reference reports them first
+    {
+        aai::Geometry g;
+        std::string msg;
+        rc = aai::make_geometry(*req, g, msg);
+        if (rc != AAI_OK) return fail(rc, msg);
+    }
+    if (!d_src || !d_dst) return fail(AAI_ERR_BAD_ARGUMENT, "Null image pointer.");
+    rc = require_device();
+    if (rc != AAI_OK) return rc;
+    rc = enqueue(*req, batch, d_src, src_stride, src_image_stride, d_dst, dst_stride, dst_image_stride, (hipStream_t)stream);
+    if (rc == AAI_OK) g_lastError.clear();
+    return rc;
+}
+
+int aai_resample_device_f32(const aai_request *req, const float *d_src, int64_t src_stride,
+                            float *d_dst, int64_t dst_stride, void *stream)
+{
+    return aai_resample_batch_device_f32(req, 1, d_src, src_stride, 0, d_dst, dst_stride, 0, stream);
+}
+
+int aai_synth_device_f32(float *d_dst, int32_t width, int32_t height, int64_t stride, uint64_t seed, void *stream)
+{
+    if (!d_dst || width < 0 || height < 0 || stride < width) return fail(AAI_ERR_BAD_ARGUMENT, "Bad synthetic image arguments.");
+    int rc = require_device();
+    if (rc != AAI_OK) return rc;
+    AAI_HIP(aai::launch_synth(d_dst, width, height, stride, seed, (hipStream_t)stream));
+    return AAI_OK;
+}
+
+int aai_resample_f32(const aai_request *req, const float *src, int64_t src_stride, float *dst, int64_t dst_stride, aai_layout *layout)
+{
+    return resample_host<float>(req, src, src_stride, dst, dst_stride, layout);
+}
+
+int aai_resample_f64(const aai_request *req, const double *src, int64_t src_stride, double *dst, int64_t dst_stride, aai_layout *layout)
+{
+    return resample_host<double>(req, src, src_stride, dst, dst_stride, layout);
+}
+
+}  // extern "C"

@@ -1,0 +1,40 @@
+// aai_kernels.hpp -- launcher declarations shared between the C ABI (aai_capi.cpp) and the HIP
+// translation units.  Every launcher only enqueues work on `stream`.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include "aai_plan.hpp"
+#include "aai_rot_math.hpp"
+
+namespace aai {
+
+// Image addressing shared by every kernel: element (x,y) of image b is base[b*imageStride + y*rowStride + x].
+struct ImageView {
+    int64_t rowStride;
+    int64_t imageStride;
+};
+
+// ---- K1: axis-aligned separable kernel ----------------------------------------------------------------
+struct AxisLaunch {
+    const AxisEntry *laneTab;   // device, nA entries (ascending source x)
+    const AxisEntry *rowTab;    // device, nB entries (ascending source y)
+    const AxisStrip *strips;    // device, nStrips entries
+    int nA, nB, nStrips;
+    int srcW, srcH;
+    int64_t outBase, outStrideA, outStrideB;   // dst element = outBase + ka*outStrideA + kb*outStrideB
+    int wide;
+};
+hipError_t launch_axis(const AxisLaunch &a, const float *src, ImageView sv, float *dst, ImageView dv,
+                       int batch, hipStream_t stream, const char **kernelName);
+
+// ---- K2/K3/K4/K5: per-output-pixel kernels on the rotated lattice --------------------------------------
+hipError_t launch_rotated(const RotLaunch &r, const float *src, ImageView sv, float *dst, ImageView dv,
+                          int batch, hipStream_t stream, const char **kernelName);
+
+// ---- utilities -----------------------------------------------------------------------------------------
+hipError_t launch_synth(float *dst, int W, int H, int64_t stride, uint64_t seed, hipStream_t stream);
+hipError_t launch_f64_to_f32(const double *src, float *dst, size_t n, hipStream_t stream);
+hipError_t launch_f32_to_f64(const float *src, double *dst, size_t n, hipStream_t stream);
+
+}  // namespace aai

@@ -1,0 +1,292 @@
+// aai_plan.cpp -- host-side validation, affine set-up and the separable tables for the axis-aligned
+// kernel.  Double precision throughout; mirrors Source.cpp:112-305 of the reference.
+#include "aai_plan.hpp"
+
+#include <algorithm>
+#include <cfloat>
+#include <cmath>
+
+namespace aai {
+
+namespace {
+constexpr double kEps = DBL_EPSILON;
+constexpr double kPi = 3.14159265358979323846;   // M_PI
+constexpr double kMaxExtent = 1073741824.0;       // 2^30: keeps every index below 31 bits
+
+bool finite_all(std::initializer_list<double> v)
+{
+    for (double x : v) if (!std::isfinite(x)) return false;
+    return true;
+}
+}  // namespace
+
+int make_geometry(const aai_request &rq, Geometry &g, std::string &msg)
+{
+    // The reference's four checks, in its order and with its texts (Source.cpp:112-132).
+    if (kEps < std::fabs(rq.src_res_x - rq.src_res_y) || kEps < std::fabs(rq.dst_res_x - rq.dst_res_y)) {
+        msg = "Assumed X & Y resolution are same.";
+        return AAI_ERR_RESOLUTION_MISMATCH;
+    }
+    if (rq.src_res_x <= kEps || rq.dst_res_x <= kEps) {
+        msg = "0 or negative resolution is not acceptable.";
+        return AAI_ERR_RESOLUTION_NONPOSITIVE;
+    }
+    if (rq.src_height <= 0) { msg = "There is no data in src array."; return AAI_ERR_NO_ROWS; }
+    if (rq.src_width <= 0) { msg = "There is no data in the second dimension of src array."; return AAI_ERR_NO_COLUMNS; }
+    // The reference lets NaN/Inf through all comparisons above and then hits undefined behaviour at
+    // Source.cpp:139 (double -> unsigned of a non-finite value); reject instead.
+    if (!finite_all({rq.src_res_x, rq.src_res_y, rq.dst_res_x, rq.dst_res_y, rq.src_iso_x, rq.src_iso_y, rq.rotation_deg})) {
+        msg = "Non-finite argument.";
+        return AAI_ERR_NONFINITE;
+    }
+
+    Geometry o;
+    o.W = rq.src_width; o.H = rq.src_height;
+
+    // Source.cpp:139 -- integer pre-expansion so that the dst pixel side exceeds sqrt(2) virtual pixels
+    const double scaleReal = rq.dst_res_x / rq.src_res_x * std::sqrt(2.0) + 1 + kEps;
+    if (!(scaleReal < 65536.0)) { msg = "Expansion ratio too large."; return AAI_ERR_TOO_LARGE; }
+    o.scale = (int)(unsigned)scaleReal;
+
+    // Source.cpp:141-148 -- wrap to [0,360) (closed form: the reference loops +-360), split off the quadrant
+    double ang = rq.rotation_deg;
+    if (std::fabs(ang) > 1e9) { msg = "Rotation angle magnitude too large."; return AAI_ERR_BAD_ARGUMENT; }
+    while (ang < 0) ang += 360;
+    while (360 <= ang) ang -= 360;
+    if (ang < 90) o.quadrant = 0;
+    else if (ang < 180) { o.quadrant = 1; ang -= 90; }
+    else if (ang < 270) { o.quadrant = 2; ang -= 180; }
+    else { o.quadrant = 3; ang -= 270; }
+    o.angle = ang;
+    o.sn = std::sin(ang / 180.0 * kPi);
+    o.cs = std::cos(ang / 180.0 * kPi);
+
+    // Source.cpp:150-156
+    const double vW = (double)((o.quadrant & 1) ? o.H : o.W) * o.scale;
+    const double vH = (double)((o.quadrant & 1) ? o.W : o.H) * o.scale;
+    if (vW >= kMaxExtent || vH >= kMaxExtent) { msg = "Virtual source too large."; return AAI_ERR_TOO_LARGE; }
+    o.mW = (int)vW; o.mH = (int)vH;
+
+    // Source.cpp:173-186 (the isocenter is deliberately NOT pre-rotated: quirk A.5)
+    o.isoX = rq.src_iso_x * o.scale + (o.scale - 1) / 2.0;
+    o.isoY = rq.src_iso_y * o.scale + (o.scale - 1) / 2.0;
+    const double sres = rq.src_res_x * o.scale;
+    o.ratio = rq.dst_res_x / sres;
+    o.side = sres / rq.dst_res_x;
+    const double dWr = std::round((o.mW * std::fabs(o.cs) + o.mH * std::fabs(o.sn)) * o.ratio);
+    const double dHr = std::round((o.mW * std::fabs(o.sn) + o.mH * std::fabs(o.cs)) * o.ratio);
+    if (!(dWr < kMaxExtent) || !(dHr < kMaxExtent) || dWr * dHr >= 1099511627776.0 /* 2^40 */) {
+        msg = "Output image too large."; return AAI_ERR_TOO_LARGE;
+    }
+    o.dW = (int)dWr; o.dH = (int)dHr;
+    const double dix = (o.isoX * o.cs + (o.mH - o.isoY) * o.sn) * o.ratio;
+    const double diy = (o.isoX * o.sn + o.isoY * o.cs) * o.ratio;
+    if (std::fabs(dix) >= 2147483647.0 || std::fabs(diy) >= 2147483647.0) {
+        msg = "Isocenter out of range."; return AAI_ERR_TOO_LARGE;
+    }
+    o.fracX = dix - (int)dix;
+    o.fracY = diy - (int)diy;
+    o.dIsoX = (int)dix;
+    o.dIsoY = (int)diy;
+
+    // Source.cpp:187-200
+    const double wm1 = (double)(o.mW - 1), hm1 = (double)(o.mH - 1);
+    double ox = 0, oy = 0;
+    ox = std::min(ox, -o.isoX * o.cs + o.isoY * o.sn + o.isoX);
+    oy = std::min(oy, -o.isoX * o.sn - o.isoY * o.cs + o.isoY);
+    ox = std::min(ox, (wm1 - o.isoX) * o.cs + o.isoY * o.sn + o.isoX);
+    oy = std::min(oy, (wm1 - o.isoX) * o.sn - o.isoY * o.cs + o.isoY);
+    ox = std::min(ox, -o.isoX * o.cs - (hm1 - o.isoY) * o.sn + o.isoX);
+    oy = std::min(oy, -o.isoX * o.sn + (hm1 - o.isoY) * o.cs + o.isoY);
+    ox = std::min(ox, (wm1 - o.isoX) * o.cs - (hm1 - o.isoY) * o.sn + o.isoX);
+    oy = std::min(oy, (wm1 - o.isoX) * o.sn + (hm1 - o.isoY) * o.cs + o.isoY);
+    o.offX = ox; o.offY = oy;
+
+    // Source.cpp:229-240
+    o.lt45 = ang < 45;
+    if (o.lt45) { o.tsn = o.sn; o.tcs = o.cs; o.ttn = std::tan(ang / 180.0 * kPi); }
+    else {
+        o.tsn = std::sin((ang - 90) / 180.0 * kPi);
+        o.tcs = std::cos((ang - 90) / 180.0 * kPi);
+        o.ttn = std::tan((ang - 90) / 180.0 * kPi);
+    }
+    if (std::fabs(o.ttn) < kEps) o.ttn = 0;
+    o.axisAligned = o.lt45 && o.ttn == 0;
+    g = o;
+    return AAI_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// K1 tables.  With the reduced angle at zero every dst pixel is an axis-parallel box on the virtual
+// lattice, so overlap areas factor into (x overlap) * (y overlap) and the reference's
+// sum(v*a)/sum(a) (Source.cpp:573-577) becomes two 1-D normalised box filters.
+// ------------------------------------------------------------------------------------------------
+namespace {
+
+struct VirtRange {        // inclusive virtual-pixel range with the weights of its two end pixels
+    int a = 0, b = -1;    // empty when a > b
+    double wa = 0, wb = 0;
+};
+
+// Edge k (k = 0..n) of the dst pixels along one axis, exactly as the reference's line tables place it
+// (Source.cpp:243-305 with tmpTan == 0, then getIntersectionPoint, Source.cpp:962-985).
+double edge_along_x(const Geometry &g, int k)
+{
+    double px, py;
+    const double h = g.side / 2;
+    if (k < g.dW) { dst_centre(g, k, 0, px, py); return px - h * (g.tcs + g.tsn); }
+    dst_centre(g, g.dW - 1, 0, px, py);
+    return px + h * (g.tcs - g.tsn);
+}
+double edge_along_y(const Geometry &g, int k)
+{
+    double px, py;
+    const double h = g.side / 2;
+    if (k < g.dH) { dst_centre(g, 0, k, px, py); return py - h * (g.tcs - g.tsn); }
+    dst_centre(g, 0, g.dH - 1, px, py);
+    return py + h * (g.tcs + g.tsn);
+}
+
+// AREA: overlap length of [lo,hi] with each virtual pixel [X-0.5, X+0.5], X in [0,m-1].
+VirtRange area_range(double lo, double hi, int m)
+{
+    VirtRange r;
+    const double clo = std::max(lo, -0.5), chi = std::min(hi, m - 0.5);
+    if (!(clo < chi)) return r;
+    int a = (int)std::floor(clo + 0.5), b = (int)std::floor(chi + 0.5);
+    a = std::max(a, 0); b = std::min(b, m - 1);
+    auto ov = [&](int X) { return std::max(0.0, std::min(chi, X + 0.5) - std::max(clo, X - 0.5)); };
+    while (a <= b && !(ov(a) > 0)) ++a;
+    while (b >= a && !(ov(b) > 0)) --b;
+    if (a > b) return r;
+    r.a = a; r.b = b; r.wa = ov(a); r.wb = ov(b);
+    return r;
+}
+
+// FAST: virtual pixels whose CENTRE lies in the closed interval [lo,hi].  The reference
+// decides this with ray/edge parameters compared against +-DBL_EPSILON (Source.cpp:857): the parameter
+// along a dst edge is s = (X-lo)/(hi-lo) and must satisfy -eps < s < 1+eps; the ray parameter
+// r = distance/100 must satisfy r > -eps.
+VirtRange fast_range(double lo, double hi, int m)
+{
+    VirtRange r;
+    if (!(hi > lo)) return r;
+    auto inside = [&](int X) {
+        const double s = (-100.0 * (lo - X)) / (100.0 * (hi - lo));
+        if (!(-kEps < s && s < 1 + kEps)) return false;
+        return (X - lo) / 100.0 > -kEps && (hi - X) / 100.0 > -kEps;
+    };
+    int a = (int)std::ceil(lo) - 1, b = (int)std::floor(hi) + 1;
+    a = std::max(a, 0); b = std::min(b, m - 1);
+    while (a <= b && !inside(a)) ++a;
+    while (b >= a && !inside(b)) --b;
+    if (a > b) return r;
+    r.a = a; r.b = b; r.wa = 1; r.wb = 1;
+    return r;
+}
+
+// Fold a virtual range onto original-image indices (each covers `scale` consecutive virtual pixels),
+// optionally mirrored (quadrants 1-3 read an axis backwards, Source.cpp:165-167).
+AxisEntry fold(const VirtRange &vr, int m, int scale, bool reversed, double otherAxisSpan)
+{
+    AxisEntry e{};
+    e.s0 = 0; e.s1 = 0; e.wFirst = e.wMid = e.wLast = 0.f;
+    if (vr.a > vr.b) return e;
+    int a = vr.a, b = vr.b;
+    double wa = vr.wa, wb = vr.wb;
+    if (reversed) { const int na = m - 1 - b, nb = m - 1 - a; a = na; b = nb; std::swap(wa, wb); }
+    const double total = (a == b) ? wa : wa + wb + (double)(b - a - 1);
+    // Source.cpp:577: DBL_EPSILON < |sumArea| or the pixel is 0.  sumArea is the 2-D product; a row/column
+    // of full pixels contributes about `otherAxisSpan`.
+    if (!(total * otherAxisSpan > kEps)) return e;
+    const int t0 = a / scale, t1 = b / scale;
+    auto weight = [&](int t) {
+        const int va = std::max(a, t * scale), vb = std::min(b, t * scale + scale - 1);
+        double w = (double)(vb - va + 1);
+        if (va == a) w += wa - 1;
+        if (vb == b && !(a == b)) w += wb - 1;
+        return w;
+    };
+    e.s0 = t0; e.s1 = t1;
+    e.wFirst = (float)(weight(t0) / total);
+    e.wLast = (t1 > t0) ? (float)(weight(t1) / total) : 0.f;
+    e.wMid = (float)((double)scale / total);
+    return e;
+}
+
+}  // namespace
+
+void build_axis_tables(const Geometry &g, int mode, AxisTables &t)
+{
+    // Which virtual axis reads which source axis (Source.cpp:164-167):
+    //   q0: X -> src x (+), Y -> src y (+)      q1: X -> src y (-), Y -> src x (+)
+    //   q2: X -> src x (-), Y -> src y (-)      q3: X -> src y (+), Y -> src x (-)
+    const bool transposed = (g.quadrant & 1) != 0;
+    const bool revX = (g.quadrant == 1 || g.quadrant == 2);
+    const bool revY = (g.quadrant == 2 || g.quadrant == 3);
+
+    std::vector<AxisEntry> alongX(g.dW), alongY(g.dH);
+    double lo = edge_along_x(g, 0);
+    for (int k = 0; k < g.dW; ++k) {
+        const double hi = edge_along_x(g, k + 1);
+        const VirtRange vr = (mode == AAI_MODE_FAST) ? fast_range(lo, hi, g.mW) : area_range(lo, hi, g.mW);
+        alongX[k] = fold(vr, g.mW, g.scale, revX, g.side);
+        lo = hi;
+    }
+    lo = edge_along_y(g, 0);
+    for (int k = 0; k < g.dH; ++k) {
+        const double hi = edge_along_y(g, k + 1);
+        const VirtRange vr = (mode == AAI_MODE_FAST) ? fast_range(lo, hi, g.mH) : area_range(lo, hi, g.mH);
+        alongY[k] = fold(vr, g.mH, g.scale, revY, g.side);
+        lo = hi;
+    }
+
+    // Lane axis = the virtual axis that reads source x; put both tables in ascending source order.
+    std::vector<AxisEntry> &laneSrc = transposed ? alongY : alongX;
+    std::vector<AxisEntry> &rowSrc = transposed ? alongX : alongY;
+    t.transposed = transposed;
+    t.flipA = transposed ? revY : revX;     // lane-axis output index runs against source x
+    t.flipB = transposed ? revX : revY;
+    t.lane = laneSrc; t.row = rowSrc;
+    if (t.flipA) std::reverse(t.lane.begin(), t.lane.end());
+    if (t.flipB) std::reverse(t.row.begin(), t.row.end());
+    t.nA = (int)t.lane.size(); t.nB = (int)t.row.size();
+
+    // Empty entries (dst pixels off the image) carry s0 = s1 = 0; park them on a neighbour's window so
+    // that strips stay compact.
+    int lastS = 0;
+    for (auto &e : t.lane) { if (e.wFirst == 0.f && e.wMid == 0.f && e.wLast == 0.f) { e.s0 = e.s1 = lastS; } else lastS = e.s0; }
+    lastS = 0;
+    for (auto &e : t.row) { if (e.wFirst == 0.f && e.wMid == 0.f && e.wLast == 0.f) { e.s0 = e.s1 = lastS; } else lastS = e.s0; }
+
+    t.maxRowSpan = 0;
+    for (const auto &e : t.row) t.maxRowSpan = std::max(t.maxRowSpan, e.s1 - e.s0 + 1);
+
+    // Greedy strips: consecutive lane-axis outputs whose windows fit in STRIP_COLS source columns.
+    t.strips.clear();
+    t.wide = false;
+    int k = 0;
+    while (k < t.nA) {
+        AxisStrip s{};
+        s.k0 = k; s.x0 = t.lane[k].s0;
+        int x0 = s.x0;
+        int kk = k;
+        while (kk < t.nA) {
+            const int lo2 = std::min(x0, t.lane[kk].s0);
+            const int hi2 = t.lane[kk].s1;
+            // windows are ascending, but parked empties may sit lower; keep x0 = min
+            int need = hi2 - lo2 + 1;
+            // also every earlier window must still fit from the (possibly lowered) origin: ascending
+            // windows make the last one the binding constraint
+            if (need > STRIP_COLS) break;
+            x0 = lo2;
+            ++kk;
+        }
+        if (kk == k) { t.wide = true; kk = k + 1; }   // a single window wider than a strip
+        s.x0 = x0; s.k1 = kk;
+        t.strips.push_back(s);
+        k = kk;
+    }
+}
+
+}  // namespace aai

@@ -1,0 +1,84 @@
+// aai_plan.hpp -- host-side geometry ("plan") for one resampling request, and the argument blocks the
+// device kernels consume.  Host code is plain C++17 (no HIP types) so that validation and layout
+// queries work on machines without a GPU.
+//
+// Geometry follows SURVEY.md Appendix A, i.e. Source.cpp:112-305 of the reference, evaluated in double
+// precision.  Nothing the reference materialises per pixel (modSrc, dstPos, the edge-line tables) is
+// stored: they are affine in the pixel indices and are recomputed on the fly.
+#pragma once
+
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "../../include/aai.h"
+
+namespace aai {
+
+// ---- geometry --------------------------------------------------------------------------------------
+struct Geometry {
+    int W = 0, H = 0;            // input image
+    int scale = 1;               // Source.cpp:139
+    int quadrant = 0;            // Source.cpp:140-146
+    double angle = 0;            // reduced angle, degrees, [0,90)
+    double sn = 0, cs = 1;       // Source.cpp:147-148
+    int mW = 0, mH = 0;          // virtual (scaled, pre-rotated) source size, Source.cpp:150-156
+    double isoX = 0, isoY = 0;   // isocenter on the virtual lattice, Source.cpp:173-174
+    double ratio = 1, side = 1;  // expansionRatio, dstSideLength, Source.cpp:177-178
+    int dW = 0, dH = 0;          // Source.cpp:179-180
+    double dIsoX = 0, dIsoY = 0; // Source.cpp:185-186
+    double fracX = 0, fracY = 0; // Source.cpp:183-184
+    double offX = 0, offY = 0;   // Source.cpp:187-200
+    bool lt45 = true;            // Source.cpp:230
+    double tsn = 0, tcs = 1, ttn = 0;   // Source.cpp:229-240 (ttn snapped to 0 below DBL_EPSILON)
+    bool axisAligned = true;     // ttn == 0 with lt45: dst pixel edges parallel to the source axes
+};
+
+// Validates like Source.cpp:112-132 (+ finiteness and size limits) and fills g.  Returns AAI_OK or an
+// AAI_ERR_* code with the message in `msg`.
+int make_geometry(const aai_request &rq, Geometry &g, std::string &msg);
+
+// Centre of dst pixel (dx,dy) on the virtual lattice, Source.cpp:212-219.
+inline void dst_centre(const Geometry &g, double dx, double dy, double &px, double &py)
+{
+    const double u = (dx + g.fracX) * g.side - g.isoX + g.offX;
+    const double v = (dy + g.fracY) * g.side - g.isoY + g.offY;
+    px = u * g.cs + v * g.sn + g.isoX;
+    py = -u * g.sn + v * g.cs + g.isoY;
+}
+
+// ---- K1: separable axis-aligned tables ---------------------------------------------------------------
+// One entry per output index along one axis: the source window [s0,s1] along the matching SOURCE axis
+// (original-image indices, ascending) and the three distinct weights a box footprint can produce.
+// Weights are already divided by the window's total weight, so the kernel never normalises.
+struct alignas(16) AxisEntry {
+    int32_t s0, s1;      // inclusive source index range; s0 > s1 never happens (empty => weights 0)
+    float wFirst;        // weight of s0
+    float wMid;          // weight of every index strictly between s0 and s1
+    float wLast;         // weight of s1 (unused when s0 == s1)
+    int32_t pad[3];
+};
+static_assert(sizeof(AxisEntry) == 32, "AxisEntry layout");
+
+// A wave strip: output indices [k0,k1) along the lane axis whose windows all lie in [x0, x0+STRIP_COLS).
+struct alignas(16) AxisStrip { int32_t k0, k1, x0, pad; };
+
+constexpr int STRIP_COLS = 256;   // 64 lanes x float4
+
+struct AxisTables {
+    std::vector<AxisEntry> lane;     // along source x (the coalesced, lane-mapped axis): nA entries
+    std::vector<AxisEntry> row;      // along source y: nB entries
+    std::vector<AxisStrip> strips;   // partition of the lane axis
+    int nA = 0, nB = 0;
+    // output element for (ka,kb) = base + ka*strideA + kb*strideB   (in elements of one dst image, with
+    // the dst row stride folded in by the launcher)
+    bool transposed = false;         // lane axis runs along dst y (quadrants 1 and 3)
+    bool flipA = false, flipB = false;
+    bool wide = false;               // some window is wider than a strip -> per-pixel fallback kernel
+    int maxRowSpan = 0;              // largest s1-s0+1 over the row table
+};
+
+// mode: AAI_MODE_AREA (overlap lengths) or AAI_MODE_FAST (centre counts).  Only for g.axisAligned.
+void build_axis_tables(const Geometry &g, int mode, AxisTables &t);
+
+}  // namespace aai

@@ -1,0 +1,155 @@
+/* aai.h -- C ABI of the MI355X-native area-average interpolation engine (libaai_hip.so).
+ *
+ * This is the drop-in boundary for the reference's hot path.  The reference
+ * (Ishikawa-lab/Area_average_interpolation, Source.cpp) has no FFI of its own: its boundary is the
+ * public section of `class AreaAverageInterpolation` (Source.cpp:52-54),
+ *
+ *     pair<bool,string> areaAverageInterpolation    (IMG src, IMG &dst, dP srcResolution, dP dstResolution,
+ *     pair<bool,string> fastAreaAverageInterpolation              dP srcIsocenter, dP &dstIsocenter, double rotationAngle)
+ *
+ * (Source.cpp:55-57 and 584-586, argument semantics Source.cpp:78-87), called from Source.cpp:1565 / 1569.
+ * Every entry point below cites the reference interface it replaces.  include/AreaAverageInterpolation.hpp
+ * re-creates the class on top of this ABI so that `main()`-style callers compile unchanged;
+ * INTEGRATION.md shows the binding a maintainer of the reference would add.
+ *
+ * Conventions (all taken from the reference):
+ *   - images are row-major [y][x] (Source.cpp:31, 150); strides are in ELEMENTS, not bytes;
+ *   - `first` = x, `second` = y for every pair (Source.cpp:43-46);
+ *   - resolutions in pixel/mm or dpi, only their ratio matters, x and y must agree (Source.cpp:112-117);
+ *   - isocenter in pixel-centre coordinates of the input image (Source.cpp:82);
+ *   - rotation in degrees, clockwise positive, any real value (Source.cpp:83, 141-142);
+ *   - the output size depends on the rotation (Source.cpp:179-180): query it with aai_query().
+ *
+ * Plain pointers and sizes only; no C++ or torch types cross this boundary.
+ * All functions return AAI_OK (0) or an AAI_ERR_* code; aai_last_error() gives the message.
+ */
+#ifndef AAI_H
+#define AAI_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AAI_VERSION_MAJOR 0
+#define AAI_VERSION_MINOR 1
+
+/* ---- status codes ------------------------------------------------------------------------- */
+enum {
+    AAI_OK = 0,
+    AAI_ERR_RESOLUTION_MISMATCH = 1,  /* "Assumed X & Y resolution are same."                       Source.cpp:112-117 */
+    AAI_ERR_RESOLUTION_NONPOSITIVE = 2, /* "0 or negative resolution is not acceptable."            Source.cpp:118-122 */
+    AAI_ERR_NO_ROWS = 3,              /* "There is no data in src array."                           Source.cpp:123-127 */
+    AAI_ERR_NO_COLUMNS = 4,           /* "There is no data in the second dimension of src array."   Source.cpp:128-132 */
+    AAI_ERR_NONFINITE = 5,            /* NaN/Inf argument: the reference does not check (UB at Source.cpp:139); we reject */
+    AAI_ERR_BAD_ARGUMENT = 6,         /* null pointer, unknown mode/policy, stride < width, batch < 0 ... */
+    AAI_ERR_TOO_LARGE = 7,            /* output or virtual source would overflow 31-bit indexing */
+    AAI_ERR_NO_DEVICE = 8,            /* no HIP device / runtime unavailable: the product has NO CPU fallback */
+    AAI_ERR_HIP = 9                   /* a HIP runtime call failed; message holds hipGetErrorString */
+};
+
+/* ---- what to compute ---------------------------------------------------------------------- */
+enum {
+    AAI_MODE_AREA = 1,      /* areaAverageInterpolation,     Source.cpp:55   (interpolationMode 1, Source.cpp:1563) */
+    AAI_MODE_FAST = 2,      /* fastAreaAverageInterpolation, Source.cpp:584  (interpolationMode 2, Source.cpp:1567) */
+    AAI_MODE_BILINEAR = 3,  /* comparison path named in README.md:8; absent from the reference -> build-defined */
+    AAI_MODE_BICUBIC = 4    /* comparison path named in README.md:8; absent from the reference -> build-defined */
+};
+enum {
+    AAI_POLICY_REFERENCE = 0, /* overlap areas exactly as getArea() returns them, including the corner-triangle
+                                 leg choice of Source.cpp:1055-1062 (the graded, reference-compatible answer) */
+    AAI_POLICY_EXACT = 1      /* geometrically exact overlap areas (differs from the reference for rotations
+                                 that are not multiples of 90 degrees) */
+};
+
+/* One resampling request = the by-value arguments of Source.cpp:55-57 plus the engine's mode switches. */
+typedef struct aai_request {
+    int32_t mode;            /* AAI_MODE_*    */
+    int32_t policy;          /* AAI_POLICY_*  (ignored by FAST / BILINEAR / BICUBIC) */
+    int32_t src_width;       /* src.front().size(), Source.cpp:150 */
+    int32_t src_height;      /* src.size(),         Source.cpp:150 */
+    double src_res_x, src_res_y;   /* srcResolution.first/.second  */
+    double dst_res_x, dst_res_y;   /* dstResolution.first/.second  */
+    double src_iso_x, src_iso_y;   /* srcIsocenter.first/.second   */
+    double rotation_deg;           /* rotationAngle                */
+} aai_request;
+
+/* What the callee decides: `dst` size (Source.cpp:179-180, 411-414) and `dstIsocenter` (Source.cpp:181-186),
+ * plus the derived quantities callers of the reference can only infer. */
+typedef struct aai_layout {
+    int32_t dst_width, dst_height;
+    double dst_iso_x, dst_iso_y;     /* integer-valued, like the reference writes them */
+    int32_t scale;                   /* integer pre-expansion factor, Source.cpp:139 */
+    int32_t quadrant;                /* 0..3 = 0/90/180/270 degree pre-rotation, Source.cpp:140-146 */
+    double reduced_angle_deg;        /* rotation left after the pre-rotation, in [0,90) */
+    double side;                     /* dst pixel side in virtual-source pixels (dstSideLength, Source.cpp:178) */
+    int32_t kernel;                  /* which device path serves this request: AAI_KERNEL_* */
+    int32_t reserved;
+} aai_layout;
+
+enum {
+    AAI_KERNEL_AXIS = 1,      /* separable streaming kernel: reduced angle == 0 (K1) */
+    AAI_KERNEL_ROTATED = 2,   /* general clip kernel (K2) */
+    AAI_KERNEL_FAST = 3,      /* centre-inclusion kernel (K3) */
+    AAI_KERNEL_SAMPLE = 4,    /* bilinear / bicubic point samplers (K4/K5) */
+    AAI_KERNEL_AXIS_WIDE = 5  /* axis-aligned, footprint wider than one wave strip: per-pixel fallback kernel */
+};
+
+/* ---- host-only entry points (no GPU needed) ---------------------------------------------------------- */
+
+/* Validate a request and compute the output layout.  Replaces the argument checks and the affine
+ * set-up of Source.cpp:112-200 (duplicated at 638-726).  On failure `out` is left untouched, like the
+ * reference leaves dst/dstIsocenter untouched. */
+int aai_query(const aai_request *req, aai_layout *out);
+
+/* Message of the most recent failure on the calling thread ("" if none).  For the four argument errors
+ * the text is byte-identical to the reference's (Source.cpp:115, 120, 125, 130). */
+const char *aai_last_error(void);
+const char *aai_error_string(int code);
+int aai_version(void);   /* major*1000 + minor */
+
+/* ---- device management ------------------------------------------------------------------------------ */
+int aai_device_count(int *count);
+int aai_set_device(int ordinal);          /* one process per GPU: call once with LOCAL_RANK */
+int aai_device_synchronize(void);
+
+/* ---- resampling: host buffers ------------------------------------------------------------------------
+ * Replaces the whole call at Source.cpp:1565 / 1569 for callers that hold the image in host memory:
+ * upload, run the hot path on the GPU, download.  `dst` must hold layout.dst_height rows of
+ * `dst_stride` elements (query the size first); `layout` may be NULL. */
+int aai_resample_f32(const aai_request *req, const float *src, int64_t src_stride,
+                     float *dst, int64_t dst_stride, aai_layout *layout);
+/* Same with the reference's element type (IMG = vector<vector<double>>, Source.cpp:31).  The device
+ * computes on fp32 pixels (weights and geometry in fp64); results agree with the reference to 1e-5 relative. */
+int aai_resample_f64(const aai_request *req, const double *src, int64_t src_stride,
+                     double *dst, int64_t dst_stride, aai_layout *layout);
+
+/* ---- resampling: device-resident buffers (the measured hot path) ---------------------------------------
+ * Replaces the loops of Source.cpp:413-579 / 868-907 (and the modSrc / dstPos / edge-line tables of
+ * Source.cpp:150-305, which are never materialised).  `stream` is a hipStream_t passed as void* (NULL =
+ * default stream); the call only enqueues work and returns. */
+int aai_resample_device_f32(const aai_request *req, const float *d_src, int64_t src_stride,
+                            float *d_dst, int64_t dst_stride, void *stream);
+
+/* A batch of `batch` independent images of identical geometry (BASELINE config 4): image b starts at
+ * d_src + b*src_image_stride and is written to d_dst + b*dst_image_stride.  One launch covers the batch. */
+int aai_resample_batch_device_f32(const aai_request *req, int32_t batch,
+                                  const float *d_src, int64_t src_stride, int64_t src_image_stride,
+                                  float *d_dst, int64_t dst_stride, int64_t dst_image_stride,
+                                  void *stream);
+
+/* ---- synthetic input ------------------------------------------------------------
+ * Fill a device image with the stateless-hash fp32 uniform [0,1) pattern used by every benchmark and
+ * known-answer test: idx = y*width + x, seed as given (image b of a batch uses seed b+1). */
+int aai_synth_device_f32(float *d_dst, int32_t width, int32_t height, int64_t stride,
+                         uint64_t seed, void *stream);
+
+/* Name and launch geometry of the kernel that served the most recent device call on this thread
+ * (for profiling / bench bookkeeping). */
+const char *aai_last_kernel(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AAI_H */

@@ -1,0 +1,116 @@
+"""Shared fixtures.  `-m "not gpu"` runs in a container without a GPU; `-m gpu` runs on an MI355X box
+(where /root/reference does not exist: nothing here reads it at run time)."""
+import ctypes
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+BUILD = os.path.join(ROOT, "tests", "_build")
+
+# Golden cases sitting on DBL_EPSILON knife edges of the reference's classifier:
+# a dst edge passes exactly through source-pixel corners (reduced angle 30/45/60 degrees with commensurate
+# sizes), so the reference's answer for a handful of pixels is decided by its own last-bit rounding.
+# The CPU oracle reproduces them bit for bit; the GPU path (which does not replay the reference's
+# operation order) is only required to match on all OTHER pixels of these cases.
+#   (case index in small_cases.npz, mode tag) -> max pixels allowed to differ
+KNIFE_EDGE = {(48, "exact"): 8, (49, "exact"): 10, (73, "exact"): 8, (105, "fast"): 6, (108, "exact"): 2,
+              (109, "exact"): 16, (131, "exact"): 18, (132, "exact"): 8}
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def _run(cmd):
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("command failed: %s\n%s\n%s" % (" ".join(cmd), r.stdout, r.stderr))
+
+
+@pytest.fixture(scope="session")
+def po():
+    """oracle bindings (builds liboracle.so; builds oracle/_ref only where the reference is present)."""
+    from oracle import pyoracle
+    if not pyoracle.have_oracle() or (os.path.exists("/root/reference/Source.cpp") and not pyoracle.have_ref()):
+        pyoracle.build()
+    return pyoracle
+
+
+@pytest.fixture(scope="session")
+def aai():
+    """the product package; builds libaai_hip.so if it is missing"""
+    so = os.path.join(ROOT, "area_average_interpolation_amd", "libaai_hip.so")
+    if not os.path.exists(so):
+        _run(["make", "-C", os.path.join(ROOT, "area_average_interpolation_amd", "csrc")])
+    import area_average_interpolation_amd as pkg
+    return pkg
+
+
+@pytest.fixture(scope="session")
+def hostemu(aai):
+    """tests/emulation/host_emulation.cpp compiled with g++ (serial replay of the kernels' arithmetic)"""
+    from area_average_interpolation_amd import _lib as L
+    os.makedirs(BUILD, exist_ok=True)
+    so = os.path.join(BUILD, "libaai_hostemu.so")
+    srcs = [os.path.join(ROOT, "tests", "emulation", "host_emulation.cpp"),
+            os.path.join(ROOT, "area_average_interpolation_amd", "csrc", "aai_plan.cpp"),
+            os.path.join(ROOT, "area_average_interpolation_amd", "csrc", "aai_plan.hpp"),
+            os.path.join(ROOT, "area_average_interpolation_amd", "csrc", "aai_rot_math.hpp")]
+    if not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
+        _run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-o", so, srcs[0]])
+    lib = ctypes.CDLL(so)
+    lib.aai_emu_resample.restype = ctypes.c_int
+    lib.aai_emu_resample.argtypes = [ctypes.POINTER(L.Request), ctypes.c_void_p, ctypes.c_void_p,
+                                     ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]
+    lib.aai_emu_strip_stats.restype = ctypes.c_int
+    lib.aai_emu_strip_stats.argtypes = [ctypes.POINTER(L.Request)] + [ctypes.POINTER(ctypes.c_int)] * 4
+
+    def resample(rq, src):
+        src = np.ascontiguousarray(src, dtype=np.float32)
+        dW, dH, ax = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+        rc = lib.aai_emu_resample(ctypes.byref(rq), src.ctypes.data, None, ctypes.byref(dW), ctypes.byref(dH), ctypes.byref(ax))
+        assert rc == 0, rc
+        out = np.empty((dH.value, dW.value), np.float32)
+        lib.aai_emu_resample(ctypes.byref(rq), src.ctypes.data, out.ctypes.data, ctypes.byref(dW), ctypes.byref(dH), ctypes.byref(ax))
+        return out, bool(ax.value)
+
+    def strip_stats(rq):
+        v = [ctypes.c_int() for _ in range(4)]
+        rc = lib.aai_emu_strip_stats(ctypes.byref(rq), *[ctypes.byref(x) for x in v])
+        return rc, [x.value for x in v]
+
+    lib.resample = resample
+    lib.strip_stats = strip_stats
+    return lib
+
+
+@pytest.fixture(scope="session")
+def small_golden():
+    z = np.load(os.path.join(GOLDEN, "small_cases.npz"))
+    manifest = json.loads(bytes(z["manifest"]).decode())
+    return z, manifest
+
+
+def load_full(name):
+    z = np.load(os.path.join(GOLDEN, "full_%s.npz" % name))
+    return z, json.loads(bytes(z["meta"]).decode())
+
+
+def rel_err(got, gold, floor=1e-3):
+    """|got-gold| / max(|gold|, floor): relative error with an absolute floor for near-zero pixels
+    (synthetic images are uniform [0,1), so 1e-3 is far below any non-empty pixel's value scale)."""
+    got = np.asarray(got, dtype=np.float64)
+    gold = np.asarray(gold, dtype=np.float64)
+    return np.abs(got - gold) / np.maximum(np.abs(gold), floor)
+
+
+TOL = 1e-5   # BASELINE.json north_star: outputs within 1e-5 relative of the reference CPU path

@@ -1,0 +1,259 @@
+"""GPU (MI355X): parity of the HIP path against the reference, through the C ABI.
+
+Comparisons are against (a) the committed golden vectors produced by the unmodified reference,
+(b) the CPU oracle (oracle/aai_oracle.c, itself bit-exact against (a)) on the same seeded inputs, and
+(c) size-independent properties at BASELINE.json's full sizes.  Tolerance: 1e-5 relative
+(BASELINE.json north_star), exact zeros must stay exact.  Nothing here reads /root/reference.
+"""
+import ctypes
+
+import numpy as np
+import pytest
+
+from conftest import KNIFE_EDGE, TOL, load_full, rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def gpu(aai):
+    import torch
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    from area_average_interpolation_amd import _lib as L
+    L.load()                       # raises if libaai_hip.so is missing: no silent fallback
+    assert aai.device_count() >= 1
+    aai.set_device(0)
+    return aai
+
+
+def _host(gpu, src, c, mode, policy=0):
+    rc, msg, dst, iso, lay = gpu.resample_host(src, c["src_res"], c["dst_res"], c["iso"], c["angle"], mode=mode, policy=policy)
+    assert rc == 0, msg
+    return dst, iso, lay
+
+
+# ---- (a) golden vectors of the unmodified reference ---------------------------------------------------------
+def test_small_golden_cases_f32(gpu, po, small_golden):
+    z, manifest = small_golden
+    for i, c in enumerate(manifest):
+        src = po.synth_image(c["W"], c["H"], c["seed"])
+        for mode, tag in ((1, "exact"), (2, "fast")):
+            dst, iso, lay = _host(gpu, src, c, mode)
+            gold = z["c%03d_%s" % (i, tag)]
+            assert dst.dtype == np.float32 and dst.shape == gold.shape, (i, tag)
+            assert list(iso) == c["dst_iso"]
+            bad = int((rel_err(dst, gold) > TOL).sum())
+            allowed = KNIFE_EDGE.get((i, tag), 0)
+            assert bad <= allowed, (i, tag, c, bad, gpu.last_kernel())
+            if allowed == 0:
+                assert np.array_equal(gold == 0, dst == 0), (i, tag)
+
+
+def test_small_golden_cases_f64_entry(gpu, po, small_golden):
+    """aai_resample_f64: the reference's own element type (IMG = vector<vector<double>>)."""
+    z, manifest = small_golden
+    for i in range(0, len(manifest), 7):
+        c = manifest[i]
+        if (i, "exact") in KNIFE_EDGE:
+            continue
+        src = po.synth_image(c["W"], c["H"], c["seed"]).astype(np.float64)
+        dst, iso, lay = _host(gpu, src, c, 1)
+        assert dst.dtype == np.float64
+        assert rel_err(dst, z["c%03d_exact" % i]).max() <= TOL, i
+
+
+@pytest.mark.parametrize("name", ["cfg1", "cfg2", "cfg3", "cfg4", "cfg5s"])
+def test_baseline_configs_against_reference_known_answers(gpu, name):
+    """BASELINE.json configs at full size (cfg5 at 1/8 linear scale, as BASELINE.md section 4 prescribes):
+    strided sample grid, complete rows, sum and zero count of the unmodified reference's output."""
+    import torch
+    z, meta = load_full(name)
+    W, H = meta["W"], meta["H"]
+    src = torch.empty((H, W), dtype=torch.float32, device="cuda")
+    gpu.synth_device(src.data_ptr(), W, H, W, 1)
+    for tag, mode in (("exact", 1), ("fast", 2)):
+        if tag not in meta:
+            continue
+        m = meta[tag]
+        rq = gpu.make_request(W, H, meta["src_res"], meta["dst_res"], meta["iso"], meta["angle"], mode=mode)
+        rc, msg, lay = gpu.query(rq)
+        assert rc == 0 and [lay.dst_height, lay.dst_width] == m["shape"] and [lay.dst_iso_x, lay.dst_iso_y] == m["dst_iso"]
+        dst = torch.full((lay.dst_height, lay.dst_width), -1.0, dtype=torch.float32, device="cuda")
+        gpu.resample_device(rq, src.data_ptr(), W, dst.data_ptr(), lay.dst_width, torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        out = dst.cpu().numpy()
+        step = m["step"]
+        assert rel_err(out[::step, ::step], z[tag + "_grid"]).max() <= TOL, (name, tag)
+        assert rel_err(out[m["rows"], :], z[tag + "_rows"]).max() <= TOL, (name, tag)
+        assert np.array_equal(out[m["rows"], :] == 0, z[tag + "_rows"] == 0)
+        assert int((out == 0).sum()) == m["zeros"], (name, tag)
+        total = float(out.astype(np.float64).sum())
+        assert abs(total - float(m["sum"])) <= 2e-7 * float(m["sum"]), (name, tag, total, m["sum"])
+
+
+# ---- (b) oracle on the same seeded inputs -------------------------------------------------------------------
+def test_random_geometries_against_oracle(gpu, po):
+    rng = np.random.default_rng(11)
+    for k in range(60):
+        W, H = int(rng.integers(1, 90)), int(rng.integers(1, 90))
+        sr, dr = float(rng.uniform(0.5, 6)), float(rng.uniform(0.5, 3))
+        if dr / sr > 2.0:
+            dr = sr * 2.0
+        ang = float(rng.uniform(-400, 400))
+        if k % 6 == 0:
+            ang = float(rng.choice([0, 90, 180, 270, 360, -90]))
+        iso = (float(rng.uniform(-3, W + 3)), float(rng.uniform(-3, H + 3)))
+        src = rng.random((H, W)).astype(np.float32)
+        c = dict(src_res=sr, dst_res=dr, iso=iso, angle=ang)
+        for mode, omode in ((1, po.MODE_EXACT), (2, po.MODE_FAST)):
+            gold = po.oracle_run(omode, src.astype(np.float64), sr, dr, iso, ang)
+            dst, giso, lay = _host(gpu, src, c, mode)
+            assert dst.shape == gold.dst.shape and tuple(giso) == gold.dst_iso
+            assert rel_err(dst, gold.dst).max() <= TOL, (k, mode, W, H, sr, dr, ang, iso, gpu.last_kernel())
+            assert np.array_equal(gold.dst == 0, dst == 0), (k, mode)
+
+
+def test_exact_policy_against_oracle(gpu, po):
+    rng = np.random.default_rng(12)
+    from area_average_interpolation_amd import _lib as L
+    for k in range(12):
+        W, H = int(rng.integers(8, 60)), int(rng.integers(8, 60))
+        sr, dr, ang = float(rng.uniform(1, 5)), 1.0, float(rng.uniform(1, 89)) + 90 * (k % 4)
+        iso = ((W - 1) / 2, (H - 1) / 2)
+        src = rng.random((H, W)).astype(np.float32)
+        gold = po.oracle_run(po.MODE_EXACT, src.astype(np.float64), sr, dr, iso, ang, policy=po.POLICY_EXACT).dst
+        dst, _, _ = _host(gpu, src, dict(src_res=sr, dst_res=dr, iso=iso, angle=ang), 1, policy=L.POLICY_EXACT)
+        assert rel_err(dst, gold).max() <= TOL, (k, ang)
+
+
+def test_comparison_samplers_against_cpu_restatement(gpu, po):
+    """Bilinear / bicubic are build-defined (the reference has none): parity is against our own CPU
+    restatement only ('parity unpinned')."""
+    import ctypes as C
+    lib = po._load_oracle()
+    rng = np.random.default_rng(13)
+    for k in range(16):
+        W, H = int(rng.integers(4, 50)), int(rng.integers(4, 50))
+        sr, dr = [(1, 4), (1, 2), (1, 1), (3, 1)][k % 4]
+        ang = [0, 45, 17.5, 200, 270, 300][k % 6]
+        iso = ((W - 1) / 2, (H - 1) / 2)
+        src = rng.random((H, W)).astype(np.float32)
+        for mode in (3, 4):
+            gold = po.oracle_run(mode, src.astype(np.float64), sr, dr, iso, ang).dst
+            dst, _, _ = _host(gpu, src, dict(src_res=sr, dst_res=dr, iso=iso, angle=ang), mode)
+            assert dst.shape == gold.shape
+            # fp32 taps vs fp64 restatement; cubic weights reach 1.125, values in [0,1)
+            assert np.abs(dst - gold).max() <= 2e-5, (k, mode, float(np.abs(dst - gold).max()))
+
+
+# ---- (c) properties at full BASELINE sizes -------------------------------------------------------------------
+def _device_run(gpu, rq, src, batch=None):
+    import torch
+    rc, msg, lay = gpu.query(rq)
+    assert rc == 0, msg
+    shape = (lay.dst_height, lay.dst_width) if batch is None else (batch, lay.dst_height, lay.dst_width)
+    dst = torch.empty(shape, dtype=torch.float32, device="cuda")
+    W = rq.src_width
+    if batch is None:
+        gpu.resample_device(rq, src.data_ptr(), W, dst.data_ptr(), lay.dst_width, torch.cuda.current_stream().cuda_stream)
+    else:
+        gpu.resample_device(rq, src.data_ptr(), W, dst.data_ptr(), lay.dst_width, torch.cuda.current_stream().cuda_stream,
+                            batch=batch, src_image_stride=rq.src_width * rq.src_height,
+                            dst_image_stride=lay.dst_width * lay.dst_height)
+    torch.cuda.synchronize()
+    return dst
+
+
+@pytest.mark.parametrize("cfg", [(8192, 8192, 4.0, 1.0, 0.0), (8192, 8192, 8192.0, 2731.0, 17.5)])
+def test_full_size_constant_and_linearity(gpu, cfg):
+    """Constant image -> the same constant wherever the dst pixel touches the image, exact 0 elsewhere
+    (Source.cpp:577); and resample(a*x + b*y) == a*resample(x) + b*resample(y) (weights do not depend on data)."""
+    import torch
+    W, H, sr, dr, ang = cfg
+    rq = gpu.make_request(W, H, sr, dr, ((W - 1) / 2, (H - 1) / 2), ang)
+    const = torch.full((H, W), 0.7310586, dtype=torch.float32, device="cuda")
+    out = _device_run(gpu, rq, const)
+    nz = out[out != 0]
+    assert nz.numel() > 0.6 * out.numel()
+    assert float((nz - 0.7310586).abs().max()) <= 2e-6
+    x = torch.empty((H, W), dtype=torch.float32, device="cuda")
+    y = torch.empty((H, W), dtype=torch.float32, device="cuda")
+    gpu.synth_device(x.data_ptr(), W, H, W, 21)
+    gpu.synth_device(y.data_ptr(), W, H, W, 22)
+    lhs = _device_run(gpu, rq, 0.25 * x + 3.0 * y)
+    rhs = 0.25 * _device_run(gpu, rq, x) + 3.0 * _device_run(gpu, rq, y)
+    assert float((lhs - rhs).abs().max()) <= 2e-5
+    assert torch.equal(lhs == 0, rhs == 0)
+
+
+def test_integer_ratio_is_a_box_mean(gpu):
+    """theta = 0, integer ratio: output = mean of an aligned LxL block with the reference's
+    isocenter-anchored phase (cfg2 covers source columns 4dx+2 .. 4dx+5)."""
+    import torch
+    W = H = 8192
+    rq = gpu.make_request(W, H, 4, 1, ((W - 1) / 2, (H - 1) / 2), 0.0)
+    x = torch.empty((H, W), dtype=torch.float32, device="cuda")
+    gpu.synth_device(x.data_ptr(), W, H, W, 5)
+    out = _device_run(gpu, rq, x)
+    pad = torch.nn.functional.pad(x.double()[2:, 2:], (0, 2, 0, 2))            # shift by the phase, zero-fill
+    box = torch.nn.functional.avg_pool2d(pad[None, None], 4)[0, 0]
+    # interior: all 16 source pixels exist
+    assert float((out[:-1, :-1].double() - box[:-1, :-1]).abs().max()) <= 1e-6
+    # last row/column: only 2 of 4 source rows/columns exist and the mean renormalises (Source.cpp:577)
+    assert float((out[-1, :-1].double() - box[-1, :-1] * 2).abs().max()) <= 1e-6
+    assert float((out[-1, -1].double() - box[-1, -1] * 4).abs()) <= 1e-6
+
+
+def test_batch_equals_singles_and_strides(gpu):
+    """BASELINE config 4 shape: a batch launch is bit-identical to per-image launches; padded row strides work."""
+    import torch
+    W = H = 1024
+    B = 5
+    rq = gpu.make_request(W, H, 4, 1, ((W - 1) / 2, (H - 1) / 2), 0.0)
+    src = torch.empty((B, H, W), dtype=torch.float32, device="cuda")
+    for b in range(B):
+        gpu.synth_device(src[b].data_ptr(), W, H, W, b + 1)
+    batched = _device_run(gpu, rq, src, batch=B)
+    for b in range(B):
+        assert torch.equal(batched[b], _device_run(gpu, rq, src[b]))
+    # strided source and destination
+    rc, _, lay = gpu.query(rq)
+    wide_src = torch.zeros((H, W + 24), dtype=torch.float32, device="cuda")
+    wide_src[:, :W] = src[0]
+    wide_dst = torch.full((lay.dst_height, lay.dst_width + 8), -7.0, dtype=torch.float32, device="cuda")
+    gpu.resample_device(rq, wide_src.data_ptr(), W + 24, wide_dst.data_ptr(), lay.dst_width + 8, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert torch.equal(wide_dst[:, :lay.dst_width], batched[0])
+    assert float(wide_dst[:, lay.dst_width:].max()) == -7.0            # padding untouched
+    # rotated kernel, batch + stride
+    rq2 = gpu.make_request(W, H, 3, 1, ((W - 1) / 2, (H - 1) / 2), 33.0)
+    b2 = _device_run(gpu, rq2, src, batch=B)
+    assert torch.equal(b2[3], _device_run(gpu, rq2, src[3]))
+
+
+def test_device_synth_matches_appendix_c_generator(gpu, po):
+    import torch
+    t = torch.empty((300, 517), dtype=torch.float32, device="cuda")
+    gpu.synth_device(t.data_ptr(), 517, 300, 517, 3)
+    torch.cuda.synchronize()
+    assert np.array_equal(t.cpu().numpy(), po.synth_image(517, 300, 3))
+
+
+def test_errors_before_device_work(gpu):
+    from area_average_interpolation_amd import _lib as L
+    rc, msg, dst, iso, lay = gpu.resample_host(np.ones((4, 4), np.float32), (1, 2), 1, (0, 0), 0)
+    assert rc == L.ERR_RESOLUTION_MISMATCH and msg == "Assumed X & Y resolution are same." and dst is None
+    with pytest.raises(gpu.AaiError):
+        gpu.resample_device(gpu.make_request(4, 4, 1, 1, (0, 0), 0), 0, 4, 0, 4)      # null pointers
+
+
+def test_reference_style_class(gpu, po):
+    a = gpu.AreaAverageInterpolation()
+    src = po.synth_image(64, 48, 4).astype(np.float64)
+    (ok, msg), dst, iso = a.areaAverageInterpolation(src, (150, 150), (25.4, 25.4), (31, 23), 1.5)     # Source.cpp:1530-1533 style
+    gold = po.oracle_run(po.MODE_EXACT, src, 150, 25.4, (31, 23), 1.5)
+    assert ok and msg == "" and tuple(iso) == gold.dst_iso
+    assert rel_err(dst, gold.dst).max() <= TOL
+    (ok, msg), dst, iso = a.fastAreaAverageInterpolation(src, (150, 150), (25.4, 25.4), (31, 23), 1.5)
+    gold = po.oracle_run(po.MODE_FAST, src, 150, 25.4, (31, 23), 1.5)
+    assert ok and rel_err(dst, gold.dst).max() <= TOL

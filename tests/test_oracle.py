@@ -1,0 +1,130 @@
+"""CPU: the oracle (oracle/aai_oracle.c) is pinned against the reference's golden vectors, and against the
+unmodified reference itself (oracle/_ref) wherever that build exists."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, load_full
+
+
+def _case_src(po, c):
+    return po.synth_image(c["W"], c["H"], c["seed"]).astype(np.float64)
+
+
+def test_oracle_matches_small_golden_bit_exact(po, small_golden):
+    z, manifest = small_golden
+    assert len(manifest) >= 140
+    for i, c in enumerate(manifest):
+        src = _case_src(po, c)
+        for mode, tag in ((po.MODE_EXACT, "exact"), (po.MODE_FAST, "fast")):
+            r = po.oracle_run(mode, src, c["src_res"], c["dst_res"], c["iso"], c["angle"])
+            assert r.ok, (i, tag, r.msg)
+            gold = z["c%03d_%s" % (i, tag)]
+            assert r.dst.shape == gold.shape == tuple(c["shape"])
+            assert list(r.dst_iso) == c["dst_iso"]
+            assert np.array_equal(r.dst, gold), (i, tag, float(np.abs(r.dst - gold).max()))
+
+
+def test_oracle_error_paths_match_reference_text(po):
+    probes = json.load(open(os.path.join(GOLDEN, "error_paths.json")))
+    src = np.ones((4, 4))
+    seen = set()
+    for p in probes:
+        if p["kind"] == "args":
+            r = po.oracle_run(p["mode"], src, p["src_res"], p["dst_res"], (0, 0), 0)
+            assert r.ok == p["ok"] and r.msg == p["msg"]
+        else:
+            import ctypes
+            lib = po._load_oracle()
+            err = ctypes.create_string_buffer(256)
+            out = ctypes.c_void_p()
+            a, b = ctypes.c_int(), ctypes.c_int()
+            x, y = ctypes.c_double(), ctypes.c_double()
+            rows = p["rows"]
+            # rows == 0 -> H = 0; rows > 0 with an empty first row -> W = 0
+            ok = lib.aai_oracle_run(p["mode"], 0, None, 0 if rows else 4, rows, 1.0, 1.0, 1.0, 1.0, 0.0, 0.0, 0.0,
+                                    ctypes.byref(out), ctypes.byref(a), ctypes.byref(b), ctypes.byref(x), ctypes.byref(y), err, 256)
+            assert bool(ok) == p["ok"] and err.value.decode() == p["msg"]
+        seen.add(p["msg"])
+    assert {po.ERR_RES_MISMATCH, po.ERR_RES_NONPOS, po.ERR_NO_ROWS, po.ERR_NO_COLS} <= seen
+
+
+def test_oracle_cfg1_known_answers(po):
+    """BASELINE config 1 (512^2 -> 256^2, theta 0) in full: SURVEY.md Appendix C row 1."""
+    z, meta = load_full("cfg1")
+    src = po.synth_image(meta["W"], meta["H"], 1).astype(np.float64)
+    for tag, mode in (("exact", po.MODE_EXACT), ("fast", po.MODE_FAST)):
+        m = meta[tag]
+        r = po.oracle_run(mode, src, meta["src_res"], meta["dst_res"], meta["iso"], meta["angle"])
+        assert r.dst.shape == tuple(m["shape"]) and list(r.dst_iso) == m["dst_iso"]
+        assert repr(float(np.sum(r.dst.astype(np.longdouble)))) == m["sum"]
+        assert int((r.dst == 0).sum()) == m["zeros"]
+        assert np.array_equal(r.dst[::m["step"], ::m["step"]], z[tag + "_grid"])
+        assert np.array_equal(r.dst[m["rows"], :], z[tag + "_rows"])
+    assert meta["exact"]["sum"] == "32765.606647133827"          # SURVEY.md Appendix C, cfg 1
+
+
+@pytest.mark.parametrize("name", ["cfg2", "cfg3", "cfg4", "cfg5s"])
+def test_oracle_rows_of_full_size_configs(po, name):
+    """A few complete output rows of the BASELINE-size runs, recomputed with aai_oracle_rows."""
+    import ctypes
+    z, meta = load_full(name)
+    src = po.synth_image(meta["W"], meta["H"], 1)            # f32, promoted per pixel by the oracle
+    lib = po._load_oracle()
+    lib.aai_oracle_rows.restype = ctypes.c_int
+    lib.aai_oracle_rows.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int] + \
+        [ctypes.c_double] * 7 + [ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int]
+    for tag, mode in (("exact", po.MODE_EXACT), ("fast", po.MODE_FAST)):
+        if tag not in meta:
+            continue
+        m = meta[tag]
+        h, w = m["shape"]
+        rows = m["rows"][2:4]                                # two interior rows keep this test to seconds
+        for k, row in enumerate(rows):
+            out = np.empty((1, w), np.float64)
+            err = ctypes.create_string_buffer(256)
+            ok = lib.aai_oracle_rows(mode, 0, src.ctypes.data, 1, meta["W"], meta["H"], meta["src_res"], meta["src_res"],
+                                     meta["dst_res"], meta["dst_res"], meta["iso"][0], meta["iso"][1], meta["angle"],
+                                     row, row + 1, out.ctypes.data, err, 256)
+            assert ok
+            assert np.array_equal(out[0], z[tag + "_rows"][2 + k]), (name, tag, row)
+
+
+def test_oracle_equals_reference_when_present(po):
+    """Direct pin against the unmodified reference (only where oracle/_ref was built)."""
+    if not po.have_ref():
+        pytest.skip("oracle/_ref not built (no reference source in this environment)")
+    rng = np.random.default_rng(7)
+    for k in range(40):
+        W, H = int(rng.integers(2, 30)), int(rng.integers(2, 30))
+        sr, dr = float(rng.uniform(0.5, 5)), float(rng.uniform(0.5, 5))
+        if dr / sr > 2.5:
+            dr = sr * 2.5
+        ang = float(rng.uniform(-400, 400)) if k % 4 else float(rng.choice([0, 30, 45, 60, 90, 180, 270]))
+        iso = (float(rng.uniform(-2, W + 2)), float(rng.uniform(-2, H + 2)))
+        src = rng.random((H, W))
+        for mode in (po.MODE_EXACT, po.MODE_FAST):
+            a = po.ref_run(mode, src, sr, dr, iso, ang)
+            b = po.oracle_run(mode, src, sr, dr, iso, ang)
+            assert a.ok and b.ok and a.dst_iso == b.dst_iso
+            assert np.array_equal(a.dst, b.dst), (k, mode)
+
+
+def test_exact_policy_is_plain_polygon_area(po):
+    """POLICY_EXACT: a constant image stays constant and interior weights sum to L^2 (true areas do;
+    the reference-policy weights do not, SURVEY.md executive summary item 5)."""
+    src = np.full((30, 30), 3.25)
+    r = po.oracle_run(po.MODE_EXACT, src, 3.0, 1.0, (14.5, 14.5), 17.5, policy=po.POLICY_EXACT)
+    nz = r.dst[r.dst != 0]
+    assert nz.size > 0 and np.allclose(nz, 3.25, rtol=1e-12)
+
+
+def test_synth_generator_c_matches_numpy(po):
+    import ctypes
+    lib = po._load_oracle()
+    a = np.empty((37, 53), np.float32)
+    lib.aai_oracle_synth_f32(a.ctypes.data, 53, 37, 9)
+    b = po.synth_image(53, 37, 9)
+    assert np.array_equal(a, b) and a.min() >= 0 and a.max() < 1
