@@ -20,6 +20,9 @@
 //   with each other, so there is no s_barrier anywhere.
 #include "aai_kernels.hpp"
 
+#include <cstdlib>
+#include <cstring>
+
 namespace aai {
 
 namespace {
@@ -30,15 +33,30 @@ constexpr int kLdsLine = STRIP_COLS + 8;   // floats per wave; +8 keeps lines 16
 typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));   // dword-aligned 16-byte access
 typedef float f4 __attribute__((ext_vector_type(4)));
 
-// One 16-byte load of source columns [col, col+4) of a row, zero-filled past the image edge.
-__device__ __forceinline__ f4 load_cols(const float *__restrict__ row, int col, int W)
+// One 16-byte load of four consecutive source columns of a row.  Branch-free: near the right image edge
+// the lane loads the last in-range vector instead (colc = min(col, W-4)) and fix_edge() shifts the
+// REDUCED vector afterwards (the shift is linear, so it is applied once per output row, not per load).
+// Keeping loads unconditional lets the compiler count them (s_waitcnt vmcnt(N)) and overlap the next
+// output row's loads with the current row's reduction.
+// NT = nontemporal (streaming) load: the source is read exactly once, so it should not displace the
+// tables and the output lines in L2 / Infinity Cache.  Measured on MI355X (tools/membw.hip): plain
+// 16-byte reads stream at ~6.3 TB/s, nontemporal ones at ~7.1 TB/s.
+template <bool NT>
+__device__ __forceinline__ f4 load_cols(const float *__restrict__ row, int colc)
 {
-    if (col + 3 < W) return *reinterpret_cast<const f4u *>(row + col);
-    f4 v = {0.f, 0.f, 0.f, 0.f};
-    if (col < W) v.x = row[col];
-    if (col + 1 < W) v.y = row[col + 1];
-    if (col + 2 < W) v.z = row[col + 2];
-    return v;
+    const f4u *p = reinterpret_cast<const f4u *>(row + colc);
+    return NT ? __builtin_nontemporal_load(p) : *p;
+}
+
+// v holds columns [colc, colc+4); return columns [colc+shift, colc+shift+4) with zeros past the edge.
+__device__ __forceinline__ f4 fix_edge(f4 v, int shift)
+{
+    f4 r;
+    r.x = shift == 0 ? v.x : shift == 1 ? v.y : shift == 2 ? v.z : shift == 3 ? v.w : 0.f;
+    r.y = shift == 0 ? v.y : shift == 1 ? v.z : shift == 2 ? v.w : 0.f;
+    r.z = shift == 0 ? v.z : shift == 1 ? v.w : 0.f;
+    r.w = shift == 0 ? v.w : 0.f;
+    return r;
 }
 
 // A table entry unpacked into plain scalars (keeps it in registers: a struct copy of AxisEntry would be
@@ -60,25 +78,41 @@ __device__ __forceinline__ float row_weight(const Win e, int y)
     return y == e.s0 ? e.wF : (y == e.s1 ? e.wL : e.wM);
 }
 
-// Vertical pass for one output row: sum_y w(y) * src[y][col..col+3], rows issued four at a time.
-__device__ __forceinline__ f4 vertical_pass(const float *__restrict__ img, int64_t rowStride, int col, int W,
-                                            const Win e)
+// Four source rows of one output row, issued together and unconditionally: rows past the window re-read
+// row s1 with weight 0 (an L1/L2 hit, never extra HBM traffic).
+struct Quad { f4 r0, r1, r2, r3; float w0, w1, w2, w3; };
+
+template <bool NT>
+__device__ __forceinline__ Quad issue_quad(const float *__restrict__ img, int64_t rowStride, int colc, const Win e, int y)
+{
+    Quad q;
+    const int y1 = min(y + 1, e.s1), y2 = min(y + 2, e.s1), y3 = min(y + 3, e.s1);
+    q.r0 = load_cols<NT>(img + (int64_t)y * rowStride, colc);
+    q.r1 = load_cols<NT>(img + (int64_t)y1 * rowStride, colc);
+    q.r2 = load_cols<NT>(img + (int64_t)y2 * rowStride, colc);
+    q.r3 = load_cols<NT>(img + (int64_t)y3 * rowStride, colc);
+    q.w0 = row_weight(e, y);
+    q.w1 = y + 1 <= e.s1 ? row_weight(e, y + 1) : 0.f;
+    q.w2 = y + 2 <= e.s1 ? row_weight(e, y + 2) : 0.f;
+    q.w3 = y + 3 <= e.s1 ? row_weight(e, y + 3) : 0.f;
+    return q;
+}
+
+__device__ __forceinline__ f4 reduce_quad(const Quad &q, f4 acc)
+{
+    acc += q.w0 * q.r0;
+    acc += q.w1 * q.r1;
+    acc += q.w2 * q.r2;
+    acc += q.w3 * q.r3;
+    return acc;
+}
+
+// Vertical pass for one output row: sum_y w(y) * src[y][colc..colc+3], rows issued four at a time.
+template <bool NT>
+__device__ __forceinline__ f4 vertical_pass(const float *__restrict__ img, int64_t rowStride, int colc, const Win e)
 {
     f4 acc = {0.f, 0.f, 0.f, 0.f};
-    for (int y = e.s0; y <= e.s1; y += 4) {
-        f4 r0, r1 = {0.f, 0.f, 0.f, 0.f}, r2 = r1, r3 = r1;
-        const float *p = img + (int64_t)y * rowStride;
-        // e is wave-uniform, so these branches are scalar; the taken loads issue back to back.
-        r0 = load_cols(p, col, W);
-        if (y + 1 <= e.s1) r1 = load_cols(p + rowStride, col, W);
-        if (y + 2 <= e.s1) r2 = load_cols(p + 2 * rowStride, col, W);
-        if (y + 3 <= e.s1) r3 = load_cols(p + 3 * rowStride, col, W);
-        const float w0 = row_weight(e, y), w1 = row_weight(e, y + 1), w2 = row_weight(e, y + 2), w3 = row_weight(e, y + 3);
-        acc += w0 * r0;
-        acc += w1 * r1;
-        acc += w2 * r2;
-        acc += w3 * r3;
-    }
+    for (int y = e.s0; y <= e.s1; y += 4) acc = reduce_quad(issue_quad<NT>(img, rowStride, colc, e, y), acc);
     return acc;
 }
 
@@ -94,38 +128,54 @@ __device__ __forceinline__ float horizontal_pass(const float *line, int off, int
     return s;
 }
 
-__global__ __launch_bounds__(kWaves * 64) void aai_axis_kernel(AxisLaunch a, const float *__restrict__ src, ImageView sv,
-                                                                float *__restrict__ dst, ImageView dv, int rowsPerBlock)
+// NT: nontemporal source loads.
+// A workgroup owns `rowsPerBlock` consecutive output rows of its 4 strips (or, with `interleave`, the rows
+// blockIdx.y, blockIdx.y + gridDim.y, ...).  Measured on MI355X (tools/tune_axis.py, profiles/): ONE output
+// row per workgroup is fastest by a wide margin (8192^2 -> 2048^2: 6.8 TB/s at 1 row, 6.3 at 2, 5.3 at 8,
+// 4.8 at 32): workgroups are dispatched in grid order, so small workgroups make the whole chip sweep the
+// image top to bottom together and the HBM pages of a source row are read by all CUs at about the same
+// time, whereas tall workgroups open 2048 independent streams 32 KiB apart.  A software-pipelined variant
+// (two output rows in flight per wave) bought 2 % at 2+ rows per workgroup and nothing at 1, so the kernel
+// keeps the simple form: 4 source rows (4 KiB per wave) in flight, latency covered by 8 waves per SIMD.
+template <bool NT>
+__global__ __launch_bounds__(kWaves * 64) void aai_axis_kernel(AxisLaunch a, const AxisEntry *__restrict__ laneTab,
+                                                                const AxisEntry *__restrict__ rowTab, const AxisStrip *__restrict__ strips,
+                                                                const float *__restrict__ src, ImageView sv,
+                                                                float *__restrict__ dst, ImageView dv,
+                                                                int rowsPerBlock, int interleave)
 {
     __shared__ __attribute__((aligned(16))) float lds[kWaves][kLdsLine];
 
     const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform: strip/row tables load through the scalar cache
     const int strip = blockIdx.x * kWaves + wave;
     if (strip >= a.nStrips) return;   // waves are independent: no barrier is skipped by leaving early
 
     typedef int i4s __attribute__((ext_vector_type(4)));
-    const i4s stq = reinterpret_cast<const i4s *>(a.strips)[strip];
+    const i4s stq = reinterpret_cast<const i4s *>(strips)[strip];
     struct { int k0, k1, x0; } st = {stq.x, stq.y, stq.z};
     const float *img = src + (int64_t)blockIdx.z * sv.imageStride;
     float *out = dst + (int64_t)blockIdx.z * dv.imageStride + a.outBase;
     float *line = lds[wave];
     const int col = st.x0 + 4 * lane;
+    const int colc = min(col, a.srcW - 4);          // srcW >= 4 here (narrower images use the wide kernel)
+    const int shift = col - colc;                    // 0 away from the right edge
 
-    const int kb0 = blockIdx.y * rowsPerBlock;
-    const int kb1 = min(kb0 + rowsPerBlock, a.nB);
+    const int rowStart = interleave ? (int)blockIdx.y : (int)blockIdx.y * rowsPerBlock;
+    const int rowStep = interleave ? (int)gridDim.y : 1;
+    const int rowEnd = interleave ? a.nB : min(rowStart + rowsPerBlock, a.nB);
     const int nOut = st.k1 - st.k0;
 
     if (nOut <= 64) {
         // Common case (any down-sampling ratio >= 4 source columns per output): one output per lane,
         // its window description stays in registers for all rows.
         const bool live = lane < nOut;
-        const Win c = load_win(a.laneTab, live ? st.k0 + lane : st.k0);
+        const Win c = load_win(laneTab, live ? st.k0 + lane : st.k0);
         const int off = c.s0 - st.x0, span = c.s1 - c.s0;
         const int64_t outCol = (int64_t)(st.k0 + lane) * a.outStrideA;
-        for (int kb = kb0; kb < kb1; ++kb) {
-            const Win e = load_win(a.rowTab, kb);
-            const f4 v = vertical_pass(img, sv.rowStride, col, a.srcW, e);
+        for (int kb = rowStart; kb < rowEnd; kb += rowStep) {
+            const Win e = load_win(rowTab, kb);
+            const f4 v = fix_edge(vertical_pass<NT>(img, sv.rowStride, colc, e), shift);
             __builtin_amdgcn_wave_barrier();
             *reinterpret_cast<f4 *>(line + 4 * lane) = v;
             __builtin_amdgcn_wave_barrier();
@@ -133,14 +183,14 @@ __global__ __launch_bounds__(kWaves * 64) void aai_axis_kernel(AxisLaunch a, con
         }
     } else {
         // Many outputs per strip (up-sampling, or ratios below 4): lanes walk the strip's outputs.
-        for (int kb = kb0; kb < kb1; ++kb) {
-            const Win e = load_win(a.rowTab, kb);
-            const f4 v = vertical_pass(img, sv.rowStride, col, a.srcW, e);
+        for (int kb = rowStart; kb < rowEnd; kb += rowStep) {
+            const Win e = load_win(rowTab, kb);
+            const f4 v = fix_edge(vertical_pass<NT>(img, sv.rowStride, colc, e), shift);
             __builtin_amdgcn_wave_barrier();
             *reinterpret_cast<f4 *>(line + 4 * lane) = v;
             __builtin_amdgcn_wave_barrier();
             for (int k = st.k0 + lane; k < st.k1; k += 64) {
-                const Win c = load_win(a.laneTab, k);
+                const Win c = load_win(laneTab, k);
                 out[(int64_t)k * a.outStrideA + (int64_t)kb * a.outStrideB] =
                     horizontal_pass(line, c.s0 - st.x0, c.s1 - c.s0, c.wF, c.wM, c.wL);
             }
@@ -181,14 +231,27 @@ hipError_t launch_axis(const AxisLaunch &a, const float *src, ImageView sv, floa
         hipLaunchKernelGGL(aai_axis_wide_kernel, grid, dim3(256), 0, stream, a, src, sv, dst, dv);
         return hipGetLastError();
     }
-    // Rows per workgroup: enough waves to fill 256 CUs several times over, few enough rows that the
-    // tail wave-round stays short.
+    // Launch shape (see the kernel comment for the measurements behind the defaults).  Each knob can be
+    // overridden for experiments: AAI_AXIS_TUNE="nt=1,rows=1,interleave=0,gy=0".
+    int nt = 1, interleave = 0, gy = 0;
+    // one output row per workgroup when it needs >= 4 source rows; more when rows are cheap
+    int rows = a.maxRowSpan >= 4 ? 1 : (a.maxRowSpan >= 2 ? 2 : 4);
+    if (const char *env = getenv("AAI_AXIS_TUNE")) {
+        auto get = [&](const char *key, int &v) {
+            const char *p = strstr(env, key);
+            if (p) v = atoi(p + strlen(key));
+        };
+        get("nt=", nt); get("rows=", rows); get("interleave=", interleave); get("gy=", gy);
+        if (rows < 1) rows = 1;
+    }
     const int blocksX = (a.nStrips + kWaves - 1) / kWaves;
-    int rowsPerBlock = 8;
-    while (rowsPerBlock > 1 && (int64_t)blocksX * ((a.nB + rowsPerBlock - 1) / rowsPerBlock) * batch < 4096) rowsPerBlock >>= 1;
-    dim3 grid(blocksX, (a.nB + rowsPerBlock - 1) / rowsPerBlock, batch);
+    int blocksY = (a.nB + rows - 1) / rows;
+    if (interleave && gy > 0) blocksY = gy < a.nB ? gy : a.nB;
+    while (blocksY > 65535) { rows *= 2; blocksY = (a.nB + rows - 1) / rows; }
+    dim3 grid(blocksX, blocksY, batch), block(kWaves * 64);
     if (kernelName) *kernelName = "aai_axis_kernel";
-    hipLaunchKernelGGL(aai_axis_kernel, grid, dim3(kWaves * 64), 0, stream, a, src, sv, dst, dv, rowsPerBlock);
+    if (nt) hipLaunchKernelGGL((aai_axis_kernel<true>), grid, block, 0, stream, a, a.laneTab, a.rowTab, a.strips, src, sv, dst, dv, rows, interleave);
+    else hipLaunchKernelGGL((aai_axis_kernel<false>), grid, block, 0, stream, a, a.laneTab, a.rowTab, a.strips, src, sv, dst, dv, rows, interleave);
     return hipGetLastError();
 }
 

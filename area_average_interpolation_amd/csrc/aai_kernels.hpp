@@ -24,6 +24,7 @@ struct AxisLaunch {
     int srcW, srcH;
     int64_t outBase, outStrideA, outStrideB;   // dst element = outBase + ka*outStrideA + kb*outStrideB
     int wide;
+    int maxRowSpan;             // largest number of source rows any output row needs
 };
 hipError_t launch_axis(const AxisLaunch &a, const float *src, ImageView sv, float *dst, ImageView dv,
                        int batch, hipStream_t stream, const char **kernelName);

@@ -264,7 +264,7 @@ void build_axis_tables(const Geometry &g, int mode, AxisTables &t)
 
     // Greedy strips: consecutive lane-axis outputs whose windows fit in STRIP_COLS source columns.
     t.strips.clear();
-    t.wide = false;
+    t.wide = g.W < 4;      // the strip kernel loads whole 4-column vectors
     int k = 0;
     while (k < t.nA) {
         AxisStrip s{};

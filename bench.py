@@ -47,14 +47,51 @@ WORKLOADS = {
 
 
 def cpu_baseline(name, budget_s=15.0):
-    """The CPU oracle (reference-faithful restatement, 1 thread) timed on a bounded sample of the SAME
-    workload: a band of complete output rows, sized from a short probe to take about `budget_s`."""
+    """CPU baseline on this box's host cores (1 thread: the reference is single-threaded), on a BOUNDED
+    sample of the same workload sized from a short probe to take about `budget_s` seconds.
+
+    kind "reference": the unmodified reference (oracle/_ref/libaai_ref.so, built from Source.cpp by
+    oracle/Makefile) when that build travelled with the repo; the sample is a full-width band of the
+    image for rotation 0 (same ratio, same per-pixel work: the reference's cost per output pixel does not
+    depend on the image height) or a square crop for rotated workloads.
+    kind "port": otherwise, the CPU oracle (oracle/aai_oracle.c) on a band of output rows of the full image.
+    """
     from oracle import pyoracle as po          # checker / baseline only; never on the product path
     import numpy as np
-    if not po.have_oracle():
-        po.build()
     W, H, sr, dr, ang, mode, _ = WORKLOADS[name]
     omode = {aai.MODE_AREA: po.MODE_EXACT, aai.MODE_FAST: po.MODE_FAST}.get(mode, mode)
+    cpu_model = ""
+    try:
+        cpu_model = [l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name")][0]
+    except Exception:
+        pass
+
+    if po.have_ref():
+        def run_crop(w, h):
+            src = po.synth_image(w, h, 1).astype(np.float64)
+            t0 = time.perf_counter()
+            r = po.ref_run(omode, src, sr, dr, ((w - 1) / 2, (h - 1) / 2), ang)
+            dt = time.perf_counter() - t0
+            assert r.ok, r.msg
+            return r.dst.size, dt
+
+        L = sr / dr
+        if ang == 0.0:
+            unit = max(1, int(round(8 * L)))                 # source rows for 8 output rows
+            n, t = run_crop(W, unit)
+            rows_src = int(min(H, max(unit, unit * (budget_s / max(t, 1e-6)))))
+            n, t = run_crop(W, rows_src)
+            sample = "unmodified reference (Source.cpp via oracle/_ref) on a full-width band: %dx%d source rows -> %d output pixels, %.1f s" % (W, rows_src, n, t)
+        else:
+            n, t = run_crop(256, 256)
+            side = int(min(W, max(256, 256 * (budget_s / max(t, 1e-6)) ** 0.5)))
+            n, t = run_crop(side, side)
+            sample = "unmodified reference (Source.cpp via oracle/_ref) on a %dx%d crop with the same ratio/rotation: %d output pixels, %.1f s" % (side, side, n, t)
+        return {"value": n / t / 1e6, "unit": "Mpixels/s (output)", "cores": 1, "kind": "reference",
+                "sample": sample, "host_cpus": os.cpu_count(), "cpu_model": cpu_model}
+
+    if not po.have_oracle():
+        po.build()
     lib = po._load_oracle()
     lib.aai_oracle_rows.restype = ctypes.c_int
     lib.aai_oracle_rows.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int] + \
@@ -80,7 +117,7 @@ def cpu_baseline(name, budget_s=15.0):
     return {"value": rows * dW / t / 1e6, "unit": "Mpixels/s (output)", "cores": 1, "kind": "port",
             "sample": "oracle/aai_oracle.c (double precision, 1 thread) on %d of %d output rows of the same "
                       "workload (rows %d..%d), %.1f s" % (rows, dH, mid, mid + rows - 1, t),
-            "host_cpus": os.cpu_count()}
+            "host_cpus": os.cpu_count(), "cpu_model": cpu_model}
 
 
 def main():

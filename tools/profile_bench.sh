@@ -1,0 +1,15 @@
+#!/bin/bash
+# Profile bench.py on the GPU box with rocprofv3: per-kernel time first, then HBM counters in passes of
+# their own (FETCH_SIZE needs 3 TCC slots, WRITE_SIZE 2: MI355X_MICROARCH.md "rocprofv3 PMC slots").
+# usage: tools/profile_bench.sh <tag> [bench args...]      outputs under gpurun_out/prof_<tag>/
+set -e
+TAG=${1:-r01}; shift || true
+OUT=gpurun_out/prof_$TAG
+mkdir -p $OUT
+export TMPDIR=/tmp
+ARGS="--no-cpu-baseline --steps 10 --warmup 2 $@"
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 bench.py $ARGS > $OUT/bench_trace.json 2> $OUT/trace.err
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -- python3 bench.py $ARGS > $OUT/bench_fetch.json 2> $OUT/fetch.err
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -- python3 bench.py $ARGS > $OUT/bench_write.json 2> $OUT/write.err
+python3 tools/summarize_prof.py $OUT > $OUT/summary.txt
+cat $OUT/summary.txt
