@@ -129,6 +129,8 @@ def main():
     ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
     ap.add_argument("--policy", default="reference", choices=["reference", "exact"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="torch.distributed backend; nccl (= RCCL) is the real one, gloo lets two ranks rehearse on one GPU")
     ap.add_argument("--gather", action="store_true", help="also time an RCCL gather of the outputs to rank 0 (reported separately)")
     args = ap.parse_args()
 
@@ -138,17 +140,23 @@ def main():
     if args.gpus > 1 or world > 1:
         assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        local = local % torch.cuda.device_count()
         torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))      # nccl == RCCL on ROCm
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))  # nccl == RCCL on ROCm
+        else:
+            dist.init_process_group("gloo")
     else:
+        local = 0
         torch.cuda.set_device(0)
     dev = torch.device("cuda", local)
+    cdev = dev if (world == 1 or args.backend == "nccl") else torch.device("cpu")     # where collective payloads live
     aai.set_device(local)
 
     W, H, sr, dr, ang, mode, desc = WORKLOADS[args.workload]
     policy = aai.POLICY_REFERENCE if args.policy == "reference" else aai.POLICY_EXACT
     rq = aai.make_request(W, H, sr, dr, ((W - 1) / 2, (H - 1) / 2), ang, mode=mode, policy=policy)
-    rq = D.broadcast_request(rq, src=0, device=dev)           # the only collective the path needs
+    rq = D.broadcast_request(rq, src=0, device=cdev)           # the only collective the path needs
     rc, msg, lay = aai.query(rq)
     assert rc == 0, msg
     dW, dH = lay.dst_width, lay.dst_height
@@ -187,7 +195,7 @@ def main():
     kernel_ms = sum(a.elapsed_time(b) for a, b in evs) / args.steps          # HIP events on the launch stream
     kernel_name = aai.last_kernel()
 
-    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    t = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
@@ -196,8 +204,9 @@ def main():
     if args.gather and world > 1:
         fence()
         g0 = time.perf_counter()
-        parts = [torch.empty_like(dst) for _ in range(world)] if rank == 0 else None
-        dist.gather(dst, gather_list=parts, dst=0)
+        payload = dst if cdev == dev else dst.cpu()
+        parts = [torch.empty_like(payload) for _ in range(world)] if rank == 0 else None
+        dist.gather(payload, gather_list=parts, dst=0)
         fence()
         gather_ms = (time.perf_counter() - g0) * 1e3
 
@@ -205,6 +214,13 @@ def main():
         out_pix = total_images * dW * dH * args.steps
         alg_bytes = B * (4 * W * H + 4 * dW * dH)                             # per launch, per GPU
         achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
+        traffic = None                                                        # measured HBM bytes per launch (rocprofv3 PMC)
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json"))).get(args.workload)
+            if pmc and pmc["batch"] == B:
+                traffic = pmc["bytes_per_launch"]
+        except Exception:
+            pass
         line = {
             "metric": "Mpixels/s (output) and achieved HBM GB/s, 8192^2->2048^2 fp32, 1/2/4/8 GPU",
             "value": out_pix / elapsed / 1e6,
@@ -217,7 +233,7 @@ def main():
                        if mode == aai.MODE_AREA else "%s: %s" % (args.workload, desc),
                        "images_per_gpu_per_step": B, "src_bytes_per_gpu": 4 * W * H * B, "parallelism": "batch-sharded x%d" % world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                          "kernel": kernel_name, "kernel_ms_per_launch": kernel_ms, "algorithmic_bytes_per_launch": alg_bytes},
             "src_gbps_input_rate": 4 * W * H * B / (kernel_ms * 1e-3) / 1e9,
         }
