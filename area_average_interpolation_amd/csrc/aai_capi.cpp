@@ -51,8 +51,12 @@ struct Plan {
     aai::AxisTables tabs;
     aai::AxisEntry *dLane = nullptr, *dRow = nullptr;
     aai::AxisStrip *dStrips = nullptr;
+    // K2/K3: per-wave knife-edge flags from the one-off scan; NULL when the geometry has none (the usual case)
+    unsigned *dFlags = nullptr;
+    unsigned knifeWaves = 0;
     ~Plan()
     {
+        if (dFlags) (void)hipFree(dFlags);
         if (dLane) (void)hipFree(dLane);
         if (dRow) (void)hipFree(dRow);
         if (dStrips) (void)hipFree(dStrips);
@@ -143,6 +147,25 @@ int get_plan(const aai_request &rq, Plan **out)
         if (e == hipSuccess) e = upload(p.tabs.strips.data(), p.tabs.strips.size() * sizeof(aai::AxisStrip), (void **)&p.dStrips);
         if (e != hipSuccess) { g_plans.pop_front(); return hip_fail(e, "uploading axis tables"); }
     }
+    if (p.kernel == AAI_KERNEL_ROTATED || p.kernel == AAI_KERNEL_FAST) {
+        // one-off knife-edge scan of this geometry (see aai_knife_scan_kernel); keeps the flags only if any
+        const aai::RotLaunch r = aai::make_rot_launch(g, rq.mode, rq.policy);
+        const size_t words = aai::rotated_flag_words(r);
+        unsigned *dCount = nullptr;
+        unsigned count = 0;
+        hipError_t e = hipSuccess;
+        if (words) {
+            e = hipMalloc((void **)&p.dFlags, words * sizeof(unsigned));
+            if (e == hipSuccess) e = hipMalloc((void **)&dCount, sizeof(unsigned));
+            if (e == hipSuccess) e = hipMemset(dCount, 0, sizeof(unsigned));
+            if (e == hipSuccess) e = aai::launch_knife_scan(r, p.dFlags, dCount, nullptr);
+            if (e == hipSuccess) e = hipMemcpy(&count, dCount, sizeof(unsigned), hipMemcpyDeviceToHost);
+            if (dCount) (void)hipFree(dCount);
+        }
+        if (e != hipSuccess) { g_plans.pop_front(); return hip_fail(e, "knife-edge scan"); }
+        p.knifeWaves = count;
+        if (count == 0 && p.dFlags) { (void)hipFree(p.dFlags); p.dFlags = nullptr; }
+    }
     while (g_plans.size() > kMaxPlans) g_plans.pop_back();
     *out = &p;
     return AAI_OK;
@@ -179,13 +202,8 @@ int enqueue(const aai_request &rq, int batch, const float *dSrc, int64_t srcStri
         a.outBase = (t.flipA ? (int64_t)(t.nA - 1) * sa : 0) + (t.flipB ? (int64_t)(t.nB - 1) * sb : 0);
         e = aai::launch_axis(a, dSrc, sv, dDst, dv, batch, stream, &name);
     } else {
-        aai::RotLaunch r{};
-        r.fracX = g.fracX; r.fracY = g.fracY; r.side = g.side; r.isoX = g.isoX; r.isoY = g.isoY;
-        r.offX = g.offX; r.offY = g.offY; r.sn = g.sn; r.cs = g.cs;
-        r.reach = g.side * std::sqrt(2.0) / 2 + 1;
-        r.dW = g.dW; r.dH = g.dH; r.mW = g.mW; r.mH = g.mH; r.W = g.W; r.H = g.H;
-        r.scale = g.scale; r.quadrant = g.quadrant; r.mode = rq.mode; r.policy = rq.policy;
-        e = aai::launch_rotated(r, dSrc, sv, dDst, dv, batch, stream, &name);
+        const aai::RotLaunch r = aai::make_rot_launch(g, rq.mode, rq.policy);
+        e = aai::launch_rotated(r, dSrc, sv, dDst, dv, batch, p->dFlags, stream, &name);
     }
     g_lastKernel = name;
     if (e != hipSuccess) return hip_fail(e, name);

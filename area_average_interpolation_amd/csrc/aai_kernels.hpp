@@ -30,8 +30,12 @@ hipError_t launch_axis(const AxisLaunch &a, const float *src, ImageView sv, floa
                        int batch, hipStream_t stream, const char **kernelName);
 
 // ---- K2/K3/K4/K5: per-output-pixel kernels on the rotated lattice --------------------------------------
+// Knife-edge flags (one 32-bit word per wave of the 16x16-pixel tiling, geometry only): launch_knife_scan fills
+// them and counts the flagged waves in counter[0]; launch_rotated runs the fix-up pass iff waveFlags != NULL.
+size_t rotated_flag_words(const RotLaunch &r);
+hipError_t launch_knife_scan(const RotLaunch &r, unsigned *waveFlags, unsigned *counter, hipStream_t stream);
 hipError_t launch_rotated(const RotLaunch &r, const float *src, ImageView sv, float *dst, ImageView dv,
-                          int batch, hipStream_t stream, const char **kernelName);
+                          int batch, const unsigned *waveFlags, hipStream_t stream, const char **kernelName);
 
 // ---- utilities -----------------------------------------------------------------------------------------
 hipError_t launch_synth(float *dst, int W, int H, int64_t stride, uint64_t seed, hipStream_t stream);

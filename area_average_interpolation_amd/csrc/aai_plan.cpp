@@ -116,6 +116,32 @@ int make_geometry(const aai_request &rq, Geometry &g, std::string &msg)
     return AAI_OK;
 }
 
+RotLaunch make_rot_launch(const Geometry &g, int mode, int policy)
+{
+    RotLaunch r{};
+    r.fracX = g.fracX; r.fracY = g.fracY; r.side = g.side; r.isoX = g.isoX; r.isoY = g.isoY;
+    r.offX = g.offX; r.offY = g.offY; r.sn = g.sn; r.cs = g.cs;
+    r.reach = g.side * std::sqrt(2.0) / 2 + 1;
+    r.dW = g.dW; r.dH = g.dH; r.mW = g.mW; r.mH = g.mH; r.W = g.W; r.H = g.H;
+    r.scale = g.scale; r.quadrant = g.quadrant; r.mode = mode; r.policy = policy;
+    r.invScale = 1.0 / g.scale;
+    const double c = g.cs, s = g.sn, h = 0.5 * g.side;
+    r.c = c; r.s = s; r.h = h;
+    r.o0x = -h * (c + s); r.o0y = h * (s - c);
+    r.o1x = h * (c - s);  r.o1y = -h * (s + c);
+    // the area kernels only run with s > 0 and c > 0 (reduced angle 0 goes to the axis-aligned kernel);
+    // the samplers ignore these fields
+    r.m1 = s / c;  r.im1 = c / s;
+    r.m2 = -c / s; r.im2 = -s / c;
+    r.Lc = g.side * c; r.Ls = g.side * s;
+    r.rLc = 1.0 / r.Lc; r.rLs = 1.0 / r.Ls;
+    r.k = 0.5 * (c + s);
+    r.lo = std::min(c, s); r.hi = std::max(c, s);
+    r.rc = 1.0 / c; r.rs = 1.0 / s; r.rhi = 1.0 / r.hi; r.r2cs = 1.0 / (2.0 * c * s);
+    r.lt45 = g.lt45 ? 1 : 0; r.tsn = g.tsn; r.tcs = g.tcs; r.ttn = g.ttn;
+    return r;
+}
+
 // ------------------------------------------------------------------------------------------------
 // K1 tables.  With the reduced angle at zero every dst pixel is an axis-parallel box on the virtual
 // lattice, so overlap areas factor into (x overlap) * (y overlap) and the reference's

@@ -12,6 +12,7 @@
 #include <vector>
 
 #include "../../include/aai.h"
+#include "aai_rot_math.hpp"
 
 namespace aai {
 
@@ -46,6 +47,9 @@ inline void dst_centre(const Geometry &g, double dx, double dy, double &px, doub
     px = u * g.cs + v * g.sn + g.isoX;
     py = -u * g.sn + v * g.cs + g.isoY;
 }
+
+// Fills the uniform block of the per-output-pixel kernels (K2-K5) from the geometry.
+RotLaunch make_rot_launch(const Geometry &g, int mode, int policy);
 
 // ---- K1: separable axis-aligned tables ---------------------------------------------------------------
 // One entry per output index along one axis: the source window [s0,s1] along the matching SOURCE axis

@@ -14,6 +14,7 @@
 #include "../../include/aai.h"
 
 #if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
 #define AAI_HD __host__ __device__ __forceinline__
 #else
 #define AAI_HD inline
@@ -21,23 +22,34 @@
 
 namespace aai {
 
-// Geometry block handed to the per-output-pixel kernels, all double.
+// Geometry block handed to the per-output-pixel kernels.  Everything here is
+// uniform over the launch and computed once on the host in double precision (make_rot_launch in
+// aai_plan.cpp), so the divisions below never run on the device and the values live in scalar registers.
 struct RotLaunch {
+    // affine map dst pixel -> virtual source (Source.cpp:173-219)
     double fracX, fracY, side, isoX, isoY, offX, offY, sn, cs;
     double reach;        // side*sqrt(2)/2 + 1, the reference's search-window half width (Source.cpp:426-429)
     int dW, dH, mW, mH, W, H, scale, quadrant;
     int mode, policy;
-};
-
-struct Frame {                      // per-dst-pixel constants, all in virtual-source units
-    double px, py;                  // centre
-    double c, s, h;                 // cos, sin of the reduced angle; half side
+    double invScale;     // 1/scale: virtual index -> original index is (int)((X + 0.5) * invScale), exact
+    // the dst square in the reduced frame: c = cos, s = sin of the reduced angle (both > 0), h = L/2
+    double c, s, h;
     double o0x, o0y, o1x, o1y;      // v0 = P + o0, v1 = P + o1, v2 = P - o1, v3 = P - o0
     double m1, im1;                 // dx/dy of the left/right edges (s/c) and its reciprocal
     double m2, im2;                 // dx/dy of the top/bottom edges (-c/s) and its reciprocal
-    double rLc, rLs;                // 1/(L c), 1/(L s)
-    double Lc, Ls;
+    double Lc, Ls, rLc, rLs;        // L*c, L*s and their reciprocals
+    double k;                       // (c+s)/2: half extent of a unit pixel along either dst axis
+    double lo, hi;                  // min(c,s), max(c,s)
+    double rc, rs, rhi, r2cs;       // 1/c, 1/s, 1/hi, 1/(2 c s)
+    // the reference's edge-line parametrisation (Source.cpp:229-240), for the strict replay only
+    int lt45;                       // reduced angle < 45 degrees
+    double tsn, tcs, ttn;           // tmpSin, tmpCos, tmpTan (tan snapped to 0 below DBL_EPSILON)
 };
+
+// Decisions closer than this (in virtual-source pixels) to their threshold are "knife edges": the fast
+// path still answers, but reports the pair so that the strict replay (aai_strict.hpp) can overrule it.
+// fp64 noise on coordinates up to ~3e4 is ~1e-11, generic geometry keeps margins >> 1e-9.
+#define AAI_KNIFE_GUARD 1e-9
 
 AAI_HD double clamp01(double v) { return fmin(fmax(v, 0.0), 1.0); }
 
@@ -60,10 +72,35 @@ AAI_HD double clamp_integral(double e0, double e1, double x0, double m, double i
     return ones + ramp;
 }
 
-// Overlap area of the dst square with the unit source pixel whose top-left corner is the local origin.
-// lx,ly = dst centre in local coordinates.  policy REFERENCE applies the Appendix-B.2 substitution.
-AAI_HD double pair_area(const Frame &f, double lx, double ly, int policy)
+// Overlap area when exactly ONE edge line of the dst square cuts the unit pixel and the pixel lies inside
+// the other three half-planes.  d = signed distance of the pixel centre from that edge (positive inside),
+// |d| < k.  The cut part is a corner triangle, a trapezoid or the complement of a corner triangle; for a
+// left/right edge (isLR) the reference takes the complementary legs for the two corner cases
+// (Source.cpp:1055-1062), which policy REFERENCE reproduces.
+template <bool KNIFE>
+AAI_HD double single_cut_area(const RotLaunch &r, double d, bool isLR, int policy, bool &edgy)
 {
+    const double t = d + r.k;                 // how far the line has entered the pixel, in (0, 2k)
+    // the line passes through a second pixel corner at t == lo and t == hi
+    if (KNIFE) edgy = fabs(t - r.lo) < AAI_KNIFE_GUARD || fabs(t - r.hi) < AAI_KNIFE_GUARD;
+    const bool substitute = isLR && policy == AAI_POLICY_REFERENCE;
+    if (t <= r.lo) {                          // inside part = corner triangle with legs t/c, t/s
+        if (substitute) return 0.5 * (1.0 - t * r.rc) * (1.0 - t * r.rs);
+        return t * t * r.r2cs;
+    }
+    if (t < r.hi) return (t - 0.5 * r.lo) * r.rhi;     // trapezoid: exact for every edge
+    const double u = 2.0 * r.k - t;           // outside part = corner triangle with legs u/c, u/s
+    if (substitute) return 1.0 - 0.5 * (1.0 - u * r.rc) * (1.0 - u * r.rs);
+    return 1.0 - u * u * r.r2cs;
+}
+
+// Overlap area of the dst square with the unit source pixel whose top-left corner is the local origin,
+// for any configuration (two edges, a dst vertex inside, ...).  lx,ly = dst centre in local coordinates.
+// policy REFERENCE applies the Appendix-B.2 substitution when a lone left/right edge SEGMENT cuts a corner.
+template <bool KNIFE>
+AAI_HD double pair_area(const RotLaunch &f, double lx, double ly, int policy, bool &edgy)
+{
+    if (KNIFE) edgy = false;
     const double v0x = lx + f.o0x, v0y = ly + f.o0y;
     const double v1x = lx + f.o1x, v1y = ly + f.o1y;
     const double v2x = lx - f.o1x, v2y = ly - f.o1y;
@@ -75,7 +112,28 @@ AAI_HD double pair_area(const Frame &f, double lx, double ly, int policy)
                 - clamp_integral<false>(v1y, v0y, v1x, f.m2, f.im2)    // top edge
                 - clamp_integral<true>(v0y, v2y, v0x, f.m1, f.im1);    // left edge
     area = clamp01(area);
-    if (policy != AAI_POLICY_REFERENCE) return area;
+
+    // Knife edges, where the reference's answer hangs on its DBL_EPSILON rules (Source.cpp:330-342, 401-408,
+    // 500-564, 1430) and its area jumps: (a) a dst vertex on a side of the pixel, (b) a dst edge through a
+    // corner of the pixel.  "On" = within AAI_KNIFE_GUARD.  (Per-pair form, used by the fix-up pass only; the
+    // production pass tests the dst pixel as a whole with pixel_on_knife_edge below.)
+    if (KNIFE) {
+        const double g = AAI_KNIFE_GUARD, L = 2.0 * f.h;
+        auto onSide = [&](double vx, double vy) {
+            const double ex = fmin(fabs(vx), fabs(vx - 1.0)), ey = fmin(fabs(vy), fabs(vy - 1.0));
+            const bool inx = vx > -g && vx < 1.0 + g, iny = vy > -g && vy < 1.0 + g;
+            return (ex < g && iny) || (ey < g && inx);
+        };
+        if (onSide(v0x, v0y) || onSide(v1x, v1y) || onSide(v2x, v2y) || onSide(v3x, v3y)) edgy = true;
+        // inside-distances of the pixel's top-left corner from the left and the top edge line; the other
+        // corners and edges follow by adding c, s and subtracting from L
+        const double dl0 = -v0x * f.c + v0y * f.s, dt0 = -v0x * f.s - v0y * f.c;
+        auto onEdge = [&](double dl, double dt) {
+            const double dr = L - dl, db = L - dt;
+            return (fmin(fabs(dl), fabs(dr)) < g && dt > -g && db > -g) || (fmin(fabs(dt), fabs(db)) < g && dl > -g && dr > -g);
+        };
+        if (onEdge(dl0, dt0) || onEdge(dl0 + f.c, dt0 + f.s) || onEdge(dl0 - f.s, dt0 + f.c) || onEdge(dl0 + f.c - f.s, dt0 + f.s + f.c)) edgy = true;
+    }
 
     // Which dst edges (as segments) pass through the pixel?  Slab clip of A + t*D, t in [0,1].
     // top/bottom edges run along (c,-s): they enter through the left or bottom side.
@@ -104,6 +162,7 @@ AAI_HD double pair_area(const Frame &f, double lx, double ly, int policy)
     if (!(tin < tout) || !(tin > 0.0) || !(tout < 1.0)) return area;   // misses, or a dst vertex lies inside
     const bool inTop = tya > txa, outRight = txb < tyb;
     if (inTop != outRight) return area;                            // opposite sides: a straight cut, exact
+    if (policy != AAI_POLICY_REFERENCE) return area;
     double tri;
     if (inTop) {   // cuts the top-right corner: reference legs xa and 1-yb
         const double xin = ax + tin * f.Ls, yout = ay + tout * f.Lc;
@@ -127,7 +186,10 @@ AAI_HD int64_t virt_offset(const RotLaunch &r, int X, int Y, int64_t rowStride)
     case 2: sx = r.mW - 1 - X; sy = r.mH - 1 - Y; break;
     case 3: sx = r.mH - 1 - Y; sy = X;            break;
     }
-    if (r.scale > 1) { sx /= r.scale; sy /= r.scale; }
+    if (r.scale > 1) {   // exact: (v + 0.5)/scale is at least 0.5/scale away from an integer
+        sx = (int)((sx + 0.5) * r.invScale);
+        sy = (int)((sy + 0.5) * r.invScale);
+    }
     return (int64_t)sy * rowStride + sx;
 }
 
@@ -139,16 +201,62 @@ AAI_HD void pixel_centre(const RotLaunch &r, int dx, int dy, double &px, double 
     py = -u * r.sn + v * r.cs + r.isoY;
 }
 
-// Fills the per-dst-pixel constants for the area path.
-AAI_HD void frame_init(Frame &f, const RotLaunch &r)
+// How a source pixel relates to the dst square, from its centre's dst-frame coordinates (a along the
+// top edge direction, b along the left edge direction; the square is |a| <= h, |b| <= h).
+enum PairClass { PAIR_OUTSIDE = 0, PAIR_INSIDE = 1, PAIR_CUT_LR = 2, PAIR_CUT_TB = 3, PAIR_GENERAL = 4 };
+
+template <bool KNIFE>
+AAI_HD int classify_pair(const RotLaunch &r, double a, double b, double &d, bool &edgy)
 {
-    f.c = r.cs; f.s = r.sn; f.h = 0.5 * r.side;
-    f.o0x = -f.h * (f.c + f.s); f.o0y = f.h * (f.s - f.c);
-    f.o1x = f.h * (f.c - f.s);  f.o1y = -f.h * (f.s + f.c);
-    f.m1 = f.s / f.c;  f.im1 = f.c / f.s;
-    f.m2 = -f.c / f.s; f.im2 = -f.s / f.c;
-    f.Lc = r.side * f.c; f.Ls = r.side * f.s;
-    f.rLc = 1.0 / f.Lc; f.rLs = 1.0 / f.Ls;
+    const double guard = AAI_KNIFE_GUARD;     // anything this close to a class boundary takes the general path
+    const double ma = r.h - fabs(a), mb = r.h - fabs(b);     // inside-distance from the nearer L/R and T/B edge
+    const double mn = fmin(ma, mb);
+    if (KNIFE) edgy = false;
+    if (mn <= -r.k - guard) return PAIR_OUTSIDE;
+    // an edge line through a pixel corner: |m| == k
+    if (KNIFE) edgy = fabs(fabs(ma) - r.k) < guard || fabs(fabs(mb) - r.k) < guard;
+    if (mn >= r.k + guard) return PAIR_INSIDE;
+    if (mb >= r.k + guard && fabs(ma) < r.k - guard) { d = ma; return PAIR_CUT_LR; }
+    if (ma >= r.k + guard && fabs(mb) < r.k - guard) { d = mb; return PAIR_CUT_TB; }
+    return PAIR_GENERAL;
+}
+
+// Does dst pixel with centre (px,py) have ANY knife edge -- a vertex on a pixel-boundary line, or an edge
+// through a lattice point (pixel corners at half-integers for the area mode, pixel centres at integers for
+// the fast mode)?  A superset of the per-pair tests above at twice their guard, evaluated once per dst pixel
+// by the production pass (about 8 operations per lattice line an edge crosses).
+AAI_HD bool pixel_on_knife_edge(const RotLaunch &r, double px, double py, bool areaMode)
+{
+    const double g2 = 2.0 * AAI_KNIFE_GUARD;
+    const double off = areaMode ? 0.5 : 0.0;
+    auto nearLattice = [&](double v) { const double w = v - off; return fabs(w - floor(w + 0.5)) < 2.0 * g2; };
+    const double vx[4] = {px + r.o0x, px + r.o1x, px - r.o1x, px - r.o0x};
+    const double vy[4] = {py + r.o0y, py + r.o1y, py - r.o1y, py - r.o0y};
+    if (areaMode)
+        for (int i = 0; i < 4; ++i)
+            if (nearLattice(vx[i]) || nearLattice(vy[i])) return true;
+    // left/right edges run along (s,c) from v0 / v1; top/bottom edges along (c,-s) from v0 / v2.  Walk the
+    // lattice lines each edge crosses most squarely so that the slope used is at most 1 in magnitude.
+    const bool steep = r.c >= r.s;            // left/right edges closer to vertical, top/bottom to horizontal
+    for (int e = 0; e < 4; ++e) {
+        const bool lr = e >= 2;
+        const int ia = lr ? (e == 2 ? 0 : 1) : (e == 0 ? 0 : 2);         // start vertex: LR from v0, v1; TB from v0, v2
+        const double ax = vx[ia], ay = vy[ia];
+        const double ex = lr ? r.Ls : r.Lc, ey = lr ? r.Lc : -r.Ls;       // edge vector
+        const bool alongY = lr ? steep : !steep;                          // iterate lattice lines y = j + off
+        if (alongY) {
+            const double lo = fmin(ay, ay + ey), hi = fmax(ay, ay + ey);
+            const double slope = lr ? r.m1 : r.m2;                         // dx/dy
+            for (double y = ceil(lo - off - g2) + off; y <= hi + g2; y += 1.0)
+                if (nearLattice(ax + (y - ay) * slope)) return true;
+        } else {
+            const double lo = fmin(ax, ax + ex), hi = fmax(ax, ax + ex);
+            const double slope = lr ? r.im1 : r.im2;                       // dy/dx
+            for (double x = ceil(lo - off - g2) + off; x <= hi + g2; x += 1.0)
+                if (nearLattice(ay + (x - ax) * slope)) return true;
+        }
+    }
+    return false;
 }
 
 }  // namespace aai

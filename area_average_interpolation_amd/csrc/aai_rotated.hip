@@ -20,94 +20,39 @@
 // the original image at the dst pixel centre mapped through the same affine map, clamp-to-edge taps,
 // 0 outside the image, Keys a = -0.5 for the cubic.
 //
-// One lane per dst pixel, a wave covers a 16x4 dst tile; boundary pairs are first compacted into a
-// per-lane LDS list so that the expensive path runs ~15 times per pixel instead of ~45 (lanes of a wave
-// hit boundary pixels at different window positions).
-#include "aai_kernels.hpp"
-#include "aai_rot_math.hpp"
+// One lane per dst pixel, a wave covers a 16x4 dst tile; pairs cut by a single edge line get a
+// closed form on the spot; pairs near a dst vertex are compacted into a per-lane LDS list so that the
+// general clip runs ~6 times per pixel, dense across the wave, instead of once per window position.
+#include "aai_rotated_kernel.hpp"
 
 namespace aai {
 
 namespace {
 
-constexpr int kListCap = 40;       // boundary-pair slots per lane (overflow is processed in line)
 constexpr int kBlock = 256;
 
-template <int MODE>
-__global__ __launch_bounds__(kBlock) void aai_rotated_kernel(RotLaunch r, const float *__restrict__ src, ImageView sv,
-                                                              float *__restrict__ dst, ImageView dv)
+// ---- knife-edge scan (once per geometry) ------------------------------------------------------------------
+// Same tiling as aai_rotated_kernel: one word per wave says whether any of its 64 dst pixels has a vertex on
+// a pixel-boundary line or an edge through a lattice point (aai_rot_math.hpp: pixel_on_knife_edge);
+// counter[0] counts the flagged waves.  Depends on the geometry only, so the plan runs it once and caches
+// the flags; generic geometries (every BASELINE configuration) flag nothing and never launch the fix-up pass.
+__global__ __launch_bounds__(kRotBlock) void aai_knife_scan_kernel(RotLaunch r, unsigned *__restrict__ waveFlags, unsigned *__restrict__ counter)
 {
-    __shared__ unsigned short pending[kListCap][kBlock];
-
     const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int dx = blockIdx.x * 16 + (tid & 15);
     const int dy = blockIdx.y * 16 + (tid >> 4);
-    if (dx >= r.dW || dy >= r.dH) return;   // no barriers below
-
-    const float *img = src + (int64_t)blockIdx.z * sv.imageStride;
-    float *out = dst + (int64_t)blockIdx.z * dv.imageStride + (int64_t)dy * dv.rowStride + dx;
-
-    Frame f;
-    pixel_centre(r, dx, dy, f.px, f.py);
-    frame_init(f, r);
-
-    // tight bounding box of the square; nothing outside it can overlap (the reference searches a wider
-    // window, Source.cpp:426-429, whose extra pixels all classify as "not included")
-    const double hb = f.h * (f.c + f.s);
-    const int x0 = max(0, (int)floor(f.px - hb + 0.5)), x1 = min(r.mW - 1, (int)ceil(f.px + hb - 0.5));
-    const int y0 = max(0, (int)floor(f.py - hb + 0.5)), y1 = min(r.mH - 1, (int)ceil(f.py + hb - 0.5));
-
-    if (MODE == AAI_MODE_FAST) {
-        // closed-square membership of the pixel centre with the reference's parameter slack
-        const double lim = f.h + DBL_EPSILON * r.side;
-        int count = 0;
-        double acc = 0.0;
-        for (int Y = y0; Y <= y1; ++Y)
-            for (int X = x0; X <= x1; ++X) {
-                const double ex = X - f.px, ey = Y - f.py;
-                const double a = ex * f.c - ey * f.s, b = ex * f.s + ey * f.c;
-                if (fabs(a) <= lim && fabs(b) <= lim) { ++count; acc += (double)img[virt_offset(r, X, Y, sv.rowStride)]; }
-            }
-        *out = count > 0 ? (float)(acc / count) : 0.f;      // Source.cpp:905
-        return;
+    bool knife = false;
+    if (dx < r.dW && dy < r.dH) {
+        double px, py;
+        pixel_centre(r, dx, dy, px, py);
+        knife = pixel_on_knife_edge(r, px, py, r.mode != AAI_MODE_FAST);
     }
-
-    const double k = 0.5 * (f.c + f.s);           // half extent of a unit pixel along either dst axis
-    const double inner = f.h - k - 1e-9, outer = f.h + k + 1e-9;
-
-    double sumA = 0.0, sumVA = 0.0;
-    int nPend = 0;
-    const bool packable = (x1 - x0) < 256 && (y1 - y0) < 256;
-    for (int Y = y0; Y <= y1; ++Y) {
-        for (int X = x0; X <= x1; ++X) {
-            const double ex = X - f.px, ey = Y - f.py;
-            const double a = fabs(ex * f.c - ey * f.s), b = fabs(ex * f.s + ey * f.c);
-            const double m = fmax(a, b);
-            if (m >= outer) continue;                                      // type 0
-            if (m <= inner) {                                              // type 1
-                sumA += 1.0;
-                sumVA += (double)img[virt_offset(r, X, Y, sv.rowStride)];
-                continue;
-            }
-            if (packable && nPend < kListCap) {
-                pending[nPend++][tid] = (unsigned short)(((Y - y0) << 8) | (X - x0));
-            } else {
-                const double area = pair_area(f, f.px - (X - 0.5), f.py - (Y - 0.5), r.policy);
-                sumA += area;
-                sumVA += area * (double)img[virt_offset(r, X, Y, sv.rowStride)];
-            }
-        }
+    const unsigned long long any = __ballot(knife);
+    if ((tid & 63) == 0) {
+        waveFlags[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * (kRotBlock / 64) + wave] = any != 0ull ? 1u : 0u;
+        if (any != 0ull) atomicAdd(counter, 1u);
     }
-    for (int i = 0; i < nPend; ++i) {
-        const unsigned short code = pending[i][tid];
-        const int X = x0 + (code & 255), Y = y0 + (code >> 8);
-        const double area = pair_area(f, f.px - (X - 0.5), f.py - (Y - 0.5), r.policy);
-        if (area > 0.0) {
-            sumA += area;
-            sumVA += area * (double)img[virt_offset(r, X, Y, sv.rowStride)];
-        }
-    }
-    *out = DBL_EPSILON < fabs(sumA) ? (float)(sumVA / sumA) : 0.f;   // Source.cpp:577
 }
 
 // ---- K4/K5 -------------------------------------------------------------------------------------------
@@ -176,8 +121,22 @@ __global__ __launch_bounds__(kBlock) void aai_sample_kernel(RotLaunch r, const f
 
 }  // namespace
 
+size_t rotated_flag_words(const RotLaunch &r)
+{
+    if (r.mode == AAI_MODE_BILINEAR || r.mode == AAI_MODE_BICUBIC) return 0;
+    return (size_t)((r.dW + 15) / 16) * (size_t)((r.dH + 15) / 16) * (kRotBlock / 64);
+}
+
+hipError_t launch_knife_scan(const RotLaunch &r, unsigned *waveFlags, unsigned *counter, hipStream_t stream)
+{
+    if (r.dW <= 0 || r.dH <= 0) return hipSuccess;
+    dim3 grid((r.dW + 15) / 16, (r.dH + 15) / 16, 1);
+    hipLaunchKernelGGL(aai_knife_scan_kernel, grid, dim3(kRotBlock), 0, stream, r, waveFlags, counter);
+    return hipGetLastError();
+}
+
 hipError_t launch_rotated(const RotLaunch &r, const float *src, ImageView sv, float *dst, ImageView dv,
-                          int batch, hipStream_t stream, const char **kernelName)
+                          int batch, const unsigned *waveFlags, hipStream_t stream, const char **kernelName)
 {
     if (r.dW <= 0 || r.dH <= 0 || batch <= 0) return hipSuccess;
     if (r.mode == AAI_MODE_BILINEAR || r.mode == AAI_MODE_BICUBIC) {
@@ -192,13 +151,18 @@ hipError_t launch_rotated(const RotLaunch &r, const float *src, ImageView sv, fl
         return hipGetLastError();
     }
     dim3 grid((r.dW + 15) / 16, (r.dH + 15) / 16, batch);
+    // production pass; then, only for geometries whose scan found knife edges (waveFlags != NULL), the fix-up
+    // pass over the same grid
     if (r.mode == AAI_MODE_FAST) {
         if (kernelName) *kernelName = "aai_rotated_kernel<fast>";
-        hipLaunchKernelGGL(aai_rotated_kernel<AAI_MODE_FAST>, grid, dim3(kBlock), 0, stream, r, src, sv, dst, dv);
+        hipLaunchKernelGGL((aai_rotated_kernel<AAI_MODE_FAST, false>), grid, dim3(kRotBlock), 0, stream, r, src, sv, dst, dv, waveFlags);
     } else {
         if (kernelName) *kernelName = "aai_rotated_kernel<area>";
-        hipLaunchKernelGGL(aai_rotated_kernel<AAI_MODE_AREA>, grid, dim3(kBlock), 0, stream, r, src, sv, dst, dv);
+        hipLaunchKernelGGL((aai_rotated_kernel<AAI_MODE_AREA, false>), grid, dim3(kRotBlock), 0, stream, r, src, sv, dst, dv, waveFlags);
     }
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    if (waveFlags) launch_rotated_fixup(r, grid, src, sv, dst, dv, waveFlags, stream);
     return hipGetLastError();
 }
 

@@ -1,0 +1,138 @@
+// aai_rotated_kernel.hpp -- the rotated-lattice area / fast kernel template (K2/K3), shared by two
+// translation units: aai_rotated.hip instantiates the production pass (STRICT = false, fused multiply-adds
+// allowed) and aai_rotated_strict.hip the knife-edge fix-up pass (STRICT = true, compiled with
+// -ffp-contract=off because it replays the reference's arithmetic operation by operation).
+#pragma once
+
+#include "aai_kernels.hpp"
+#include "aai_rot_math.hpp"
+#include "aai_strict.hpp"
+
+namespace aai {
+
+constexpr int kRotListCap = 24;    // queued vertex-region pairs per lane (overflow is processed in line)
+constexpr int kRotBlock = 256;     // 16 x 16 dst pixels; a wave covers 16 x 4
+
+// STRICT = false: the production pass.  Every pair is answered by the fast path.
+// STRICT = true: the fix-up pass over the same grid, launched only when the plan's knife-edge scan
+//   (aai_knife_scan_kernel, run once per geometry) found flagged waves.  Waves whose flag is clear exit at
+//   once; flagged waves recompute their 64 pixels, replaying the reference's own arithmetic
+//   (aai_strict.hpp) for the knife-edge
+//   pairs.  In generic geometry -- every BASELINE configuration -- no flag is ever raised.
+template <int MODE, bool STRICT>
+__global__ __launch_bounds__(kRotBlock) void aai_rotated_kernel(RotLaunch r, const float *__restrict__ src, ImageView sv,
+                                                              float *__restrict__ dst, ImageView dv,
+                                                              const unsigned *__restrict__ waveFlags)
+{
+    __shared__ unsigned short pending[kRotListCap][kRotBlock];
+
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // knife-edge flags depend on the geometry only, so one set serves every image of a batch
+    if (STRICT && waveFlags[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * (kRotBlock / 64) + wave] == 0u) return;
+
+    const int dx = blockIdx.x * 16 + (tid & 15);
+    const int dy = blockIdx.y * 16 + (tid >> 4);
+    const bool valid = dx < r.dW && dy < r.dH;      // no barriers below
+
+    if (valid) {
+        const float *img = src + (int64_t)blockIdx.z * sv.imageStride;
+        float *out = dst + (int64_t)blockIdx.z * dv.imageStride + (int64_t)dy * dv.rowStride + dx;
+
+        double px, py;
+        pixel_centre(r, dx, dy, px, py);
+
+        // tight bounding box of the square; nothing outside it can overlap (the reference searches a wider
+        // window, Source.cpp:426-429, whose extra pixels all classify as "not included")
+        const double hb = r.h * (r.c + r.s);
+        const int x0 = max(0, (int)floor(px - hb + 0.5 - AAI_KNIFE_GUARD)), x1 = min(r.mW - 1, (int)ceil(px + hb - 0.5 + AAI_KNIFE_GUARD));
+        const int y0 = max(0, (int)floor(py - hb + 0.5 - AAI_KNIFE_GUARD)), y1 = min(r.mH - 1, (int)ceil(py + hb - 0.5 + AAI_KNIFE_GUARD));
+
+        SVec sv4[4];                                 // the reference's vertices, fetched lazily (STRICT only)
+        bool haveVertices = false;
+
+        if (MODE == AAI_MODE_FAST) {
+            // closed-square membership of the pixel centre with the reference's parameter slack
+            const double lim = r.h + DBL_EPSILON * r.side;
+            int count = 0;
+            double acc = 0.0;
+            for (int Y = y0; Y <= y1; ++Y)
+                for (int X = x0; X <= x1; ++X) {
+                    const double ex = X - px, ey = Y - py;
+                    const double a = fabs(ex * r.c - ey * r.s), b = fabs(ex * r.s + ey * r.c);
+                    bool in = a <= lim && b <= lim;
+                    // a centre on (or within the guard of) an edge: the reference's ray cast decides
+                    const bool edgy = STRICT && ((fabs(a - r.h) < AAI_KNIFE_GUARD && b <= r.h + AAI_KNIFE_GUARD) ||
+                                                 (fabs(b - r.h) < AAI_KNIFE_GUARD && a <= r.h + AAI_KNIFE_GUARD));
+                    if (edgy) {
+                        if (STRICT) {
+                            if (!haveVertices) { strict_vertices(r, dx, dy, sv4); haveVertices = true; }
+                            SVec pc; pc.x = X; pc.y = Y;
+                            in = strict_centre_inside(pc, sv4);
+                        }
+                    }
+                    if (in) { ++count; acc += (double)img[virt_offset(r, X, Y, sv.rowStride)]; }
+                }
+            *out = count > 0 ? (float)(acc / count) : 0.f;      // Source.cpp:905
+        } else {
+            // Pass 1 over the window: pairs that are outside, inside, or cut by a single edge line are settled
+            // on the spot (two dot products + a closed form); the rest -- pixels near a dst vertex -- are queued.
+            double sumA = 0.0, sumVA = 0.0;
+            int nPend = 0;
+            const bool packable = (x1 - x0) < 256 && (y1 - y0) < 128;
+            for (int Y = y0; Y <= y1; ++Y) {
+                for (int X = x0; X <= x1; ++X) {
+                    const double ex = X - px, ey = Y - py;
+                    const double a = ex * r.c - ey * r.s, b = ex * r.s + ey * r.c;
+                    double d = 0.0;
+                    bool edgy = false, edgy2 = false;
+                    const int cls = classify_pair<STRICT>(r, a, b, d, edgy);
+                    if (cls == PAIR_OUTSIDE) continue;                              // type 0
+                    double area;
+                    if (cls == PAIR_INSIDE) area = 1.0;                             // type 1
+                    else if (cls == PAIR_GENERAL) {
+                        if (packable && nPend < kRotListCap) {
+                            pending[nPend++][tid] = (unsigned short)((edgy ? 0x8000 : 0) | ((Y - y0) << 8) | (X - x0));
+                            continue;
+                        }
+                        area = pair_area<STRICT>(r, px - (X - 0.5), py - (Y - 0.5), r.policy, edgy2);
+                    } else area = single_cut_area<STRICT>(r, d, cls == PAIR_CUT_LR, r.policy, edgy2);   // types 2, 3, 4
+                    if (STRICT && (edgy || edgy2)) {
+                        {
+                            if (!haveVertices) { strict_vertices(r, dx, dy, sv4); haveVertices = true; }
+                            area = strict_pair_area(sv4, X, Y, r.policy);
+                        }
+                    }
+                    if (area != 0.0) {
+                        sumA += area;
+                        sumVA += area * (double)img[virt_offset(r, X, Y, sv.rowStride)];
+                    }
+                }
+            }
+            // Pass 2: the queued pairs, dense across the lanes of a wave.
+            for (int i = 0; i < nPend; ++i) {
+                const unsigned short code = pending[i][tid];
+                const int X = x0 + (code & 255), Y = y0 + ((code >> 8) & 127);
+                bool edgy = false;
+                double area = pair_area<STRICT>(r, px - (X - 0.5), py - (Y - 0.5), r.policy, edgy);
+                if (STRICT && (edgy || (code & 0x8000))) {
+                    {
+                        if (!haveVertices) { strict_vertices(r, dx, dy, sv4); haveVertices = true; }
+                        area = strict_pair_area(sv4, X, Y, r.policy);
+                    }
+                }
+                if (area != 0.0) {
+                    sumA += area;
+                    sumVA += area * (double)img[virt_offset(r, X, Y, sv.rowStride)];
+                }
+            }
+            *out = DBL_EPSILON < fabs(sumA) ? (float)(sumVA / sumA) : 0.f;   // Source.cpp:577
+        }
+    }
+}
+
+// launches the fix-up pass (defined in aai_rotated_strict.hip)
+void launch_rotated_fixup(const RotLaunch &r, dim3 grid, const float *src, ImageView sv, float *dst, ImageView dv,
+                          const unsigned *waveFlags, hipStream_t stream);
+
+}  // namespace aai

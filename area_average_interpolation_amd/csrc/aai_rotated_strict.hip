@@ -1,0 +1,20 @@
+// aai_rotated_strict.hip -- the knife-edge fix-up pass of the rotated-lattice kernels.
+//
+// Compiled with -ffp-contract=off (see the Makefile): the strict replay (aai_strict.hpp) reproduces the
+// reference's DBL_EPSILON decisions only if every product and sum rounds exactly like the reference build's.
+// Waves whose flag the production pass left clear return immediately, so in generic geometry this launch
+// costs a few microseconds.
+#include "aai_rotated_kernel.hpp"
+
+namespace aai {
+
+void launch_rotated_fixup(const RotLaunch &r, dim3 grid, const float *src, ImageView sv, float *dst, ImageView dv,
+                          const unsigned *waveFlags, hipStream_t stream)
+{
+    if (r.mode == AAI_MODE_FAST)
+        hipLaunchKernelGGL((aai_rotated_kernel<AAI_MODE_FAST, true>), grid, dim3(kRotBlock), 0, stream, r, src, sv, dst, dv, waveFlags);
+    else
+        hipLaunchKernelGGL((aai_rotated_kernel<AAI_MODE_AREA, true>), grid, dim3(kRotBlock), 0, stream, r, src, sv, dst, dv, waveFlags);
+}
+
+}  // namespace aai

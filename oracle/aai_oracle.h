@@ -60,6 +60,10 @@ int aai_oracle_rows(int mode, int policy, const void *src, int srcIsF32, int W, 
 
 void aai_oracle_free(void *p);
 
+/* Per-pair areas of one dst pixel over the reference's search window (test / debug aid). */
+int aai_oracle_pixel_pairs(int policy, int W, int H, double srcResX, double dstResX, double isoX, double isoY,
+                           double angleDeg, int dx, int dy, int cap, int *xs, int *ys, double *areas);
+
 /* SURVEY.md Appendix C.1 synthetic image: fp32 uniform [0,1) from a stateless 64-bit hash. */
 void aai_oracle_synth_f32(float *dst, int W, int H, uint64_t seed);
 

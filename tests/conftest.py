@@ -16,14 +16,15 @@ if ROOT not in sys.path:
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 BUILD = os.path.join(ROOT, "tests", "_build")
 
-# Golden cases sitting on DBL_EPSILON knife edges of the reference's classifier:
-# a dst edge passes exactly through source-pixel corners (reduced angle 30/45/60 degrees with commensurate
-# sizes), so the reference's answer for a handful of pixels is decided by its own last-bit rounding.
-# The CPU oracle reproduces them bit for bit; the GPU path (which does not replay the reference's
-# operation order) is only required to match on all OTHER pixels of these cases.
-#   (case index in small_cases.npz, mode tag) -> max pixels allowed to differ
-KNIFE_EDGE = {(48, "exact"): 8, (49, "exact"): 10, (73, "exact"): 8, (105, "fast"): 6, (108, "exact"): 2,
-              (109, "exact"): 16, (131, "exact"): 18, (132, "exact"): 8}
+# Golden cases sitting on DBL_EPSILON knife edges of the reference's classifier: a dst edge
+# passes exactly through source-pixel corners (reduced angle 30/45/60 degrees with commensurate sizes), so the
+# reference's answer for a handful of pixels is decided by its own last-bit rounding.  The CPU oracle
+# reproduces them bit for bit, and since the strict replay path (csrc/aai_strict.hpp) the GPU path matches
+# them too: NO pixel of any golden case is allowed to differ.  The indices are kept so that tests can
+# assert these cases really exercise the knife-edge machinery.
+KNIFE_EDGE_CASES = [(48, "exact"), (49, "exact"), (73, "exact"), (105, "fast"), (108, "exact"), (109, "exact"),
+                    (131, "exact"), (132, "exact")]
+KNIFE_EDGE = {}      # (case, tag) -> pixels allowed to differ: none
 
 
 def pytest_configure(config):
@@ -88,6 +89,21 @@ def hostemu(aai):
         rc = lib.aai_emu_strip_stats(ctypes.byref(rq), *[ctypes.byref(x) for x in v])
         return rc, [x.value for x in v]
 
+    lib.aai_emu_force_general.restype = None
+    lib.aai_emu_force_general.argtypes = [ctypes.c_int]
+    lib.aai_emu_set_strict.restype = None
+    lib.aai_emu_set_strict.argtypes = [ctypes.c_int]
+    lib.aai_emu_knife_stats.restype = None
+    lib.aai_emu_knife_stats.argtypes = [ctypes.POINTER(ctypes.c_long), ctypes.POINTER(ctypes.c_long)]
+
+    def knife_stats():
+        a, b = ctypes.c_long(), ctypes.c_long()
+        lib.aai_emu_knife_stats(ctypes.byref(a), ctypes.byref(b))
+        return a.value, b.value
+
+    lib.knife_stats = knife_stats
+    lib.aai_emu_missed_knife_pairs.restype = ctypes.c_long
+    lib.aai_emu_missed_knife_pairs.argtypes = []
     lib.resample = resample
     lib.strip_stats = strip_stats
     return lib

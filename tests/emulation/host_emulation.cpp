@@ -13,6 +13,7 @@
 
 #include "../../area_average_interpolation_amd/csrc/aai_plan.cpp"
 #include "../../area_average_interpolation_amd/csrc/aai_rot_math.hpp"
+#include "../../area_average_interpolation_amd/csrc/aai_strict.hpp"
 
 using namespace aai;
 
@@ -64,49 +65,89 @@ static void emu_axis(const Geometry &g, int mode, const float *src, int64_t srcS
     }
 }
 
+static int g_forceGeneral = 0;   // test hook: route every cut pair through pair_area (cross-checks the closed form)
+static int g_strict = 1;         // test hook: 0 = production pass only, 1 = production + knife-edge fix-up pass
+static long g_knifePairs = 0, g_knifePixels = 0, g_missedPairs = 0;   // missed: pair-level knife in a pixel the per-pixel test did not flag
+
 static void emu_rotated(const Geometry &g, const aai_request &rq, const float *img, int64_t srcStride, float *dst, int64_t dstStride)
 {
-    RotLaunch r{};
-    r.fracX = g.fracX; r.fracY = g.fracY; r.side = g.side; r.isoX = g.isoX; r.isoY = g.isoY;
-    r.offX = g.offX; r.offY = g.offY; r.sn = g.sn; r.cs = g.cs;
-    r.reach = g.side * std::sqrt(2.0) / 2 + 1;
-    r.dW = g.dW; r.dH = g.dH; r.mW = g.mW; r.mH = g.mH; r.W = g.W; r.H = g.H;
-    r.scale = g.scale; r.quadrant = g.quadrant; r.mode = rq.mode; r.policy = rq.policy;
+    const RotLaunch r = make_rot_launch(g, rq.mode, rq.policy);
+    g_knifePairs = g_knifePixels = g_missedPairs = 0;
     for (int dy = 0; dy < r.dH; ++dy)
         for (int dx = 0; dx < r.dW; ++dx) {
-            Frame f;
-            pixel_centre(r, dx, dy, f.px, f.py);
-            frame_init(f, r);
-            const double hb = f.h * (f.c + f.s);
-            const int x0 = std::max(0, (int)std::floor(f.px - hb + 0.5)), x1 = std::min(r.mW - 1, (int)std::ceil(f.px + hb - 0.5));
-            const int y0 = std::max(0, (int)std::floor(f.py - hb + 0.5)), y1 = std::min(r.mH - 1, (int)std::ceil(f.py + hb - 0.5));
+            double px, py;
+            pixel_centre(r, dx, dy, px, py);
+            const double hb = r.h * (r.c + r.s);
+            const int x0 = std::max(0, (int)std::floor(px - hb + 0.5 - AAI_KNIFE_GUARD)), x1 = std::min(r.mW - 1, (int)std::ceil(px + hb - 0.5 + AAI_KNIFE_GUARD));
+            const int y0 = std::max(0, (int)std::floor(py - hb + 0.5 - AAI_KNIFE_GUARD)), y1 = std::min(r.mH - 1, (int)std::ceil(py + hb - 0.5 + AAI_KNIFE_GUARD));
             float *out = dst + (int64_t)dy * dstStride + dx;
+            SVec sv4[4];
+            bool haveVertices = false;
+            long knifeHere = 0;
+            // the production pass flags whole dst pixels; only flagged ones reach the strict replay
+            const bool flagged = pixel_on_knife_edge(r, px, py, rq.mode != AAI_MODE_FAST);
             if (rq.mode == AAI_MODE_FAST) {
-                const double lim = f.h + DBL_EPSILON * r.side;
+                const double lim = r.h + DBL_EPSILON * r.side;
                 int count = 0; double acc = 0;
                 for (int Y = y0; Y <= y1; ++Y)
                     for (int X = x0; X <= x1; ++X) {
-                        const double ex = X - f.px, ey = Y - f.py;
-                        const double a = ex * f.c - ey * f.s, b = ex * f.s + ey * f.c;
-                        if (std::fabs(a) <= lim && std::fabs(b) <= lim) { ++count; acc += (double)img[virt_offset(r, X, Y, srcStride)]; }
+                        const double ex = X - px, ey = Y - py;
+                        const double a = std::fabs(ex * r.c - ey * r.s), b = std::fabs(ex * r.s + ey * r.c);
+                        bool in = a <= lim && b <= lim;
+                        const bool edgy = (std::fabs(a - r.h) < AAI_KNIFE_GUARD && b <= r.h + AAI_KNIFE_GUARD) ||
+                                          (std::fabs(b - r.h) < AAI_KNIFE_GUARD && a <= r.h + AAI_KNIFE_GUARD);
+                        if (edgy && !flagged) {
+                            SVec tv[4];
+                            strict_vertices(r, dx, dy, tv);
+                            SVec pc; pc.x = X; pc.y = Y;
+                            if (strict_centre_inside(pc, tv) != in) ++g_missedPairs;
+                        }
+                        if (edgy && flagged) {
+                            ++knifeHere;
+                            if (g_strict) {
+                                if (!haveVertices) { strict_vertices(r, dx, dy, sv4); haveVertices = true; }
+                                SVec pc; pc.x = X; pc.y = Y;
+                                in = strict_centre_inside(pc, sv4);
+                            }
+                        }
+                        if (in) { ++count; acc += (double)img[virt_offset(r, X, Y, srcStride)]; }
                     }
                 *out = count > 0 ? (float)(acc / count) : 0.f;
-                continue;
+            } else {
+                double sumA = 0, sumVA = 0;
+                for (int Y = y0; Y <= y1; ++Y)
+                    for (int X = x0; X <= x1; ++X) {
+                        const double ex = X - px, ey = Y - py;
+                        const double a = ex * r.c - ey * r.s, b = ex * r.s + ey * r.c;
+                        double d = 0;
+                        bool edgy = false, edgy2 = false;
+                        const int cls = classify_pair<true>(r, a, b, d, edgy);
+                        if (cls == PAIR_OUTSIDE) continue;
+                        double area;
+                        if (cls == PAIR_INSIDE) area = 1.0;
+                        else if (cls == PAIR_GENERAL || g_forceGeneral) area = pair_area<true>(r, px - (X - 0.5), py - (Y - 0.5), r.policy, edgy2);
+                        else area = single_cut_area<true>(r, d, cls == PAIR_CUT_LR, r.policy, edgy2);
+                        // A pair-level knife flag in a pixel the per-pixel test let through is harmless as long as
+                        // the strict replay would not have changed the area (e.g. a pixel corner on the EXTENSION
+                        // of an edge line beyond the vertex); anything else is a gap in the per-pixel test.
+                        if ((edgy || edgy2) && !flagged) {
+                            SVec tv[4];
+                            strict_vertices(r, dx, dy, tv);
+                            if (std::fabs(strict_pair_area(tv, X, Y, r.policy) - area) > 1e-9) ++g_missedPairs;
+                        }
+                        if ((edgy || edgy2) && flagged) {
+                            ++knifeHere;
+                            if (g_strict) {
+                                if (!haveVertices) { strict_vertices(r, dx, dy, sv4); haveVertices = true; }
+                                area = strict_pair_area(sv4, X, Y, r.policy);
+                            }
+                        }
+                        if (area != 0.0) { sumA += area; sumVA += area * (double)img[virt_offset(r, X, Y, srcStride)]; }
+                    }
+                *out = DBL_EPSILON < std::fabs(sumA) ? (float)(sumVA / sumA) : 0.f;
             }
-            const double k = 0.5 * (f.c + f.s);
-            const double inner = f.h - k - 1e-9, outer = f.h + k + 1e-9;
-            double sumA = 0, sumVA = 0;
-            for (int Y = y0; Y <= y1; ++Y)
-                for (int X = x0; X <= x1; ++X) {
-                    const double ex = X - f.px, ey = Y - f.py;
-                    const double a = std::fabs(ex * f.c - ey * f.s), b = std::fabs(ex * f.s + ey * f.c);
-                    const double m = std::fmax(a, b);
-                    if (m >= outer) continue;
-                    double area = 1.0;
-                    if (!(m <= inner)) area = pair_area(f, f.px - (X - 0.5), f.py - (Y - 0.5), r.policy);
-                    if (area > 0.0) { sumA += area; sumVA += area * (double)img[virt_offset(r, X, Y, srcStride)]; }
-                }
-            *out = DBL_EPSILON < std::fabs(sumA) ? (float)(sumVA / sumA) : 0.f;
+            g_knifePairs += knifeHere;
+            if (knifeHere) ++g_knifePixels;
         }
 }
 
@@ -126,6 +167,42 @@ int aai_emu_resample(const aai_request *rq, const float *src, float *dst, int *d
     if (axis) emu_axis(g, rq->mode, src, g.W, dst, g.dW);
     else emu_rotated(g, *rq, src, g.W, dst, g.dW);
     return AAI_OK;
+}
+
+void aai_emu_force_general(int on) { g_forceGeneral = on; }
+void aai_emu_set_strict(int on) { g_strict = on; }
+void aai_emu_knife_stats(long *pairs, long *pixels) { *pairs = g_knifePairs; *pixels = g_knifePixels; }
+long aai_emu_missed_knife_pairs(void) { return g_missedPairs; }
+
+// Per-pair dump for one dst pixel of the rotated path: class, knife flag, fast area, strict area.
+int aai_emu_pixel_pairs(const aai_request *rq, int dx, int dy, int cap, int *xs, int *ys, int *cls, int *knife, double *fast, double *strict)
+{
+    Geometry g;
+    std::string msg;
+    if (make_geometry(*rq, g, msg) != AAI_OK) return -1;
+    const RotLaunch r = make_rot_launch(g, rq->mode, rq->policy);
+    double px, py;
+    pixel_centre(r, dx, dy, px, py);
+    const double hb = r.h * (r.c + r.s);
+    const int x0 = std::max(0, (int)std::floor(px - hb + 0.5 - AAI_KNIFE_GUARD)), x1 = std::min(r.mW - 1, (int)std::ceil(px + hb - 0.5 + AAI_KNIFE_GUARD));
+    const int y0 = std::max(0, (int)std::floor(py - hb + 0.5 - AAI_KNIFE_GUARD)), y1 = std::min(r.mH - 1, (int)std::ceil(py + hb - 0.5 + AAI_KNIFE_GUARD));
+    SVec sv4[4];
+    strict_vertices(r, dx, dy, sv4);
+    int n = 0;
+    for (int Y = y0; Y <= y1; ++Y)
+        for (int X = x0; X <= x1; ++X) {
+            const double ex = X - px, ey = Y - py;
+            const double a = ex * r.c - ey * r.s, b = ex * r.s + ey * r.c;
+            double d = 0;
+            bool edgy = false, edgy2 = false;
+            const int c = classify_pair<true>(r, a, b, d, edgy);
+            double area = 0;
+            if (c == PAIR_INSIDE) area = 1;
+            else if (c == PAIR_GENERAL) area = pair_area<true>(r, px - (X - 0.5), py - (Y - 0.5), r.policy, edgy2);
+            else if (c != PAIR_OUTSIDE) area = single_cut_area<true>(r, d, c == PAIR_CUT_LR, r.policy, edgy2);
+            if (n < cap) { xs[n] = X; ys[n] = Y; cls[n] = c; knife[n] = (edgy || edgy2) ? 1 : 0; fast[n] = area; strict[n] = strict_pair_area(sv4, X, Y, r.policy); ++n; }
+        }
+    return n;
 }
 
 // Strip table introspection for the planner tests.

@@ -10,7 +10,7 @@ import ctypes
 import numpy as np
 import pytest
 
-from conftest import KNIFE_EDGE, TOL, load_full, rel_err
+from conftest import KNIFE_EDGE, KNIFE_EDGE_CASES, TOL, load_full, rel_err
 
 pytestmark = pytest.mark.gpu
 
@@ -144,6 +144,33 @@ def test_comparison_samplers_against_cpu_restatement(gpu, po):
             assert dst.shape == gold.shape
             # fp32 taps vs fp64 restatement; cubic weights reach 1.125, values in [0,1)
             assert np.abs(dst - gold).max() <= 2e-5, (k, mode, float(np.abs(dst - gold).max()))
+
+
+def test_knife_edge_geometries_against_oracle(gpu, po):
+    """Structured geometries (edges through pixel corners, vertices on pixel sides): the production pass flags
+    the waves concerned and the fix-up pass replays the reference's own arithmetic (csrc/aai_strict.hpp);
+    every pixel must then match the reference restatement."""
+    import math
+    rng = np.random.default_rng(4)
+    angs = [30, 45, 60, math.degrees(math.atan(0.5)), math.degrees(math.atan(0.75)), 22.5, 135, 210, 315]
+    ratios = [(2, 1), (3, 1), (4, 1), (1, 1), (1, 2), (2.8284271247461903, 1), (1.4142135623730951, 1)]
+    runs = 0
+    for ang in angs:
+        for (sr, dr) in ratios:
+            for kind in range(3):
+                W, H = int(rng.integers(16, 36)), int(rng.integers(16, 36))
+                if dr / sr > 1:
+                    W, H = W // 3 + 4, H // 3 + 4
+                iso = [((W - 1) / 2, (H - 1) / 2), (0.0, 0.0), (float(rng.integers(0, W)), float(rng.integers(0, H)) + 0.5)][kind]
+                src = rng.random((H, W)).astype(np.float32)
+                for mode, omode in ((1, po.MODE_EXACT), (2, po.MODE_FAST)):
+                    gold = po.oracle_run(omode, src.astype(np.float64), sr, dr, iso, ang).dst
+                    dst, _, _ = _host(gpu, src, dict(src_res=float(sr), dst_res=float(dr), iso=iso, angle=float(ang)), mode)
+                    assert dst.shape == gold.shape
+                    assert (rel_err(dst, gold) > TOL).sum() == 0, (W, H, sr, dr, iso, ang, mode)
+                    assert np.array_equal(gold == 0, dst == 0), (W, H, sr, dr, iso, ang, mode)
+                    runs += 1
+    assert runs > 300
 
 
 # ---- (c) properties at full BASELINE sizes -------------------------------------------------------------------

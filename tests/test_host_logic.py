@@ -9,7 +9,7 @@ import subprocess
 import numpy as np
 import pytest
 
-from conftest import GOLDEN, KNIFE_EDGE, ROOT, TOL, load_full, rel_err
+from conftest import GOLDEN, KNIFE_EDGE, KNIFE_EDGE_CASES, ROOT, TOL, load_full, rel_err
 
 
 # ---- ABI surface ---------------------------------------------------------------------------------------
@@ -191,3 +191,86 @@ def test_host_emulation_quadrants_agree_with_oracle(aai, hostemu, po):
             out, axis = hostemu.resample(aai.make_request(W, H, sr, dr, iso, ang, mode=mode), src)
             assert axis and out.shape == gold.shape
             assert rel_err(out, gold).max() <= TOL, (k, mode, W, H, sr, dr, ang, iso)
+
+
+def test_single_cut_closed_form_equals_general_clip(aai, hostemu):
+    """The closed form used for pairs cut by ONE edge line (csrc/aai_rot_math.hpp: single_cut_area, incl.
+    the reference-policy substitution) must agree with the general scan-line clip + slab detection."""
+    rng = np.random.default_rng(21)
+    for k in range(30):
+        W, H = int(rng.integers(6, 60)), int(rng.integers(6, 60))
+        sr, dr = float(rng.uniform(1.0, 6.0)), float(rng.uniform(0.6, 2.0))
+        ang = float(rng.uniform(0.001, 89.999)) + 90 * int(rng.integers(0, 4))
+        if k % 7 == 0:
+            ang = [1e-6, 89.999999, 44.9999, 45.0001, 0.5, 17.5, 33.3][k // 7 % 7]
+        src = rng.random((H, W)).astype(np.float32)
+        for policy in (0, 1):
+            rq = aai.make_request(W, H, sr, dr, ((W - 1) / 2, (H - 1) / 2), ang, policy=policy)
+            hostemu.aai_emu_force_general(0)
+            fast, axis = hostemu.resample(rq, src)
+            hostemu.aai_emu_force_general(1)
+            slow, _ = hostemu.resample(rq, src)
+            hostemu.aai_emu_force_general(0)
+            assert not axis
+            assert np.abs(fast.astype(np.float64) - slow).max() <= 2e-6, (k, policy, ang, sr, dr)
+
+
+def _structured_geometries(rng, n_iso=3):
+    """Geometries full of exact coincidences: rational / special angles, integer and sqrt(2) ratios,
+    isocenters on pixel centres and half-pixels."""
+    import math
+    angs = [30, 45, 60, math.degrees(math.atan(0.5)), math.degrees(math.atan(0.75)), 15, 22.5, 135, 210, 330, 315]
+    ratios = [(2, 1), (3, 1), (4, 1), (1, 1), (1, 2), (3, 2), (2.8284271247461903, 1), (1.4142135623730951, 1)]
+    for ang in angs:
+        for (sr, dr) in ratios:
+            for kind in range(n_iso):
+                W, H = int(rng.integers(16, 36)), int(rng.integers(16, 36))
+                if dr / sr > 1:
+                    W, H = W // 3 + 4, H // 3 + 4
+                iso = [((W - 1) / 2, (H - 1) / 2), (0.0, 0.0), (float(rng.integers(0, W)), float(rng.integers(0, H)) + 0.5)][kind]
+                yield W, H, float(sr), float(dr), iso, float(ang)
+
+
+def test_knife_edge_geometries_match_oracle_exactly_in_class(aai, hostemu, po, small_golden):
+    """Structured geometries where dst edges run through pixel corners and dst vertices sit on pixel sides:
+    the fast path flags those pairs and the strict replay (csrc/aai_strict.hpp) must then agree with the
+    reference restatement on EVERY pixel -- no allowance."""
+    z, manifest = small_golden
+    # the golden knife-edge cases need the strict pass: without it they differ, with it they do not
+    for (i, tag) in KNIFE_EDGE_CASES:
+        c = manifest[i]
+        src = po.synth_image(c["W"], c["H"], c["seed"])
+        rq = aai.make_request(c["W"], c["H"], c["src_res"], c["dst_res"], c["iso"], c["angle"], mode=1 if tag == "exact" else 2)
+        gold = z["c%03d_%s" % (i, tag)]
+        hostemu.aai_emu_set_strict(0)
+        loose, _ = hostemu.resample(rq, src)
+        hostemu.aai_emu_set_strict(1)
+        strict, _ = hostemu.resample(rq, src)
+        pairs, pixels = hostemu.knife_stats()
+        assert pairs > 0 and pixels > 0
+        assert (rel_err(loose, gold) > TOL).sum() > 0, (i, tag)          # the production pass alone is off here
+        assert (rel_err(strict, gold) > TOL).sum() == 0, (i, tag)
+    rng = np.random.default_rng(4)
+    runs = knife = 0
+    for (W, H, sr, dr, iso, ang) in _structured_geometries(rng):
+        src = rng.random((H, W)).astype(np.float32)
+        for mode, omode in ((1, po.MODE_EXACT), (2, po.MODE_FAST)):
+            gold = po.oracle_run(omode, src.astype(np.float64), sr, dr, iso, ang).dst
+            out, axis = hostemu.resample(aai.make_request(W, H, sr, dr, iso, ang, mode=mode), src)
+            knife += hostemu.knife_stats()[0]
+            # the per-pixel knife test of the production pass must cover every pair-level knife edge
+            assert hostemu.aai_emu_missed_knife_pairs() == 0, (W, H, sr, dr, iso, ang, mode)
+            assert out.shape == gold.shape
+            assert (rel_err(out, gold) > TOL).sum() == 0, (W, H, sr, dr, iso, ang, mode)
+            assert np.array_equal(gold == 0, out == 0), (W, H, sr, dr, iso, ang, mode)
+            runs += 1
+    assert runs > 400 and knife > 50000          # the sweep really is made of knife edges
+
+
+def test_baseline_geometries_raise_no_knife_flags(aai, hostemu, po):
+    """BASELINE configs 3 and 5 (at reduced size) never enter the strict path (zero end-point hits)."""
+    for (W, sr, dr, ang) in ((768, 8192.0, 2731.0, 17.5), (96, 1.0, 4.0, 45.0)):
+        src = po.synth_image(W, W, 1)
+        for mode in (1, 2):
+            out, axis = hostemu.resample(aai.make_request(W, W, sr, dr, ((W - 1) / 2, (W - 1) / 2), ang, mode=mode), src)
+            assert not axis and hostemu.knife_stats() == (0, 0), (W, ang, mode, hostemu.knife_stats())
