@@ -78,23 +78,22 @@ __device__ __forceinline__ float row_weight(const Win e, int y)
     return y == e.s0 ? e.wF : (y == e.s1 ? e.wL : e.wM);
 }
 
-// Four source rows of one output row, issued together and unconditionally: rows past the window re-read
-// row s1 with weight 0 (an L1/L2 hit, never extra HBM traffic).
+// Up to four source rows of one output row, issued together.  The window is wave-uniform, so the
+// "row exists" branches are scalar: rows past the window are simply not loaded.
 struct Quad { f4 r0, r1, r2, r3; float w0, w1, w2, w3; };
 
 template <bool NT>
 __device__ __forceinline__ Quad issue_quad(const float *__restrict__ img, int64_t rowStride, int colc, const Win e, int y)
 {
     Quad q;
-    const int y1 = min(y + 1, e.s1), y2 = min(y + 2, e.s1), y3 = min(y + 3, e.s1);
-    q.r0 = load_cols<NT>(img + (int64_t)y * rowStride, colc);
-    q.r1 = load_cols<NT>(img + (int64_t)y1 * rowStride, colc);
-    q.r2 = load_cols<NT>(img + (int64_t)y2 * rowStride, colc);
-    q.r3 = load_cols<NT>(img + (int64_t)y3 * rowStride, colc);
-    q.w0 = row_weight(e, y);
-    q.w1 = y + 1 <= e.s1 ? row_weight(e, y + 1) : 0.f;
-    q.w2 = y + 2 <= e.s1 ? row_weight(e, y + 2) : 0.f;
-    q.w3 = y + 3 <= e.s1 ? row_weight(e, y + 3) : 0.f;
+    const f4 z = {0.f, 0.f, 0.f, 0.f};
+    const float *p = img + (int64_t)y * rowStride;
+    q.r0 = load_cols<NT>(p, colc);
+    q.r1 = z; q.r2 = z; q.r3 = z;
+    if (y + 1 <= e.s1) q.r1 = load_cols<NT>(p + rowStride, colc);
+    if (y + 2 <= e.s1) q.r2 = load_cols<NT>(p + 2 * rowStride, colc);
+    if (y + 3 <= e.s1) q.r3 = load_cols<NT>(p + 3 * rowStride, colc);
+    q.w0 = row_weight(e, y); q.w1 = row_weight(e, y + 1); q.w2 = row_weight(e, y + 2); q.w3 = row_weight(e, y + 3);
     return q;
 }
 
@@ -181,8 +180,34 @@ __global__ __launch_bounds__(kWaves * 64) void aai_axis_kernel(AxisLaunch a, con
             __builtin_amdgcn_wave_barrier();
             if (live) out[outCol + (int64_t)kb * a.outStrideB] = horizontal_pass(line, off, span, c.wF, c.wM, c.wL);
         }
+    } else if (nOut <= 256 && a.outStrideA == 1) {
+        // Ratios between 1 and 4 (65..256 outputs per strip) with dst x along the lanes: four consecutive
+        // outputs per lane, window descriptions in registers, one 16-byte store per lane and output row.
+        const int kq = st.k0 + 4 * lane;
+        const int nq = min(max(st.k1 - kq, 0), 4);                   // how many of this lane's four outputs exist
+        const Win c0 = load_win(laneTab, nq > 0 ? kq : st.k0), c1 = load_win(laneTab, nq > 1 ? kq + 1 : st.k0);
+        const Win c2 = load_win(laneTab, nq > 2 ? kq + 2 : st.k0), c3 = load_win(laneTab, nq > 3 ? kq + 3 : st.k0);
+        for (int kb = rowStart; kb < rowEnd; kb += rowStep) {
+            const Win e = load_win(rowTab, kb);
+            const f4 v = fix_edge(vertical_pass<NT>(img, sv.rowStride, colc, e), shift);
+            __builtin_amdgcn_wave_barrier();
+            *reinterpret_cast<f4 *>(line + 4 * lane) = v;
+            __builtin_amdgcn_wave_barrier();
+            f4 r;
+            r.x = horizontal_pass(line, c0.s0 - st.x0, c0.s1 - c0.s0, c0.wF, c0.wM, c0.wL);
+            r.y = horizontal_pass(line, c1.s0 - st.x0, c1.s1 - c1.s0, c1.wF, c1.wM, c1.wL);
+            r.z = horizontal_pass(line, c2.s0 - st.x0, c2.s1 - c2.s0, c2.wF, c2.wM, c2.wL);
+            r.w = horizontal_pass(line, c3.s0 - st.x0, c3.s1 - c3.s0, c3.wF, c3.wM, c3.wL);
+            float *o = out + kq + (int64_t)kb * a.outStrideB;
+            if (nq == 4) *reinterpret_cast<f4u *>(o) = r;
+            else {
+                if (nq > 0) o[0] = r.x;
+                if (nq > 1) o[1] = r.y;
+                if (nq > 2) o[2] = r.z;
+            }
+        }
     } else {
-        // Many outputs per strip (up-sampling, or ratios below 4): lanes walk the strip's outputs.
+        // Many outputs per strip (up-sampling, transposed quadrants at small ratios): lanes walk the outputs.
         for (int kb = rowStart; kb < rowEnd; kb += rowStep) {
             const Win e = load_win(rowTab, kb);
             const f4 v = fix_edge(vertical_pass<NT>(img, sv.rowStride, colc, e), shift);
@@ -233,9 +258,16 @@ hipError_t launch_axis(const AxisLaunch &a, const float *src, ImageView sv, floa
     }
     // Launch shape (see the kernel comment for the measurements behind the defaults).  Each knob can be
     // overridden for experiments: AAI_AXIS_TUNE="nt=1,rows=1,interleave=0,gy=0".
-    int nt = 1, interleave = 0, gy = 0;
-    // one output row per workgroup when it needs >= 4 source rows; more when rows are cheap
-    int rows = a.maxRowSpan >= 4 ? 1 : (a.maxRowSpan >= 2 ? 2 : 4);
+    // Defaults from the sweeps in profiles/r01_axis_tune_*.txt (8192^2 sources):
+    //   * windows that share source rows between output rows (grid not pixel-aligned) want cached loads and
+    //     two rows per workgroup (5.8 vs 5.2 TB/s at 4:1); disjoint windows want nontemporal loads;
+    //   * >= 4 source rows per output row: one output row per workgroup (6.8 TB/s at 4:1; 5.3 at 8 rows);
+    //   * 2-3 source rows: four (5.0-5.2 TB/s vs 3.7-4.6 at one or two);
+    //   * ratios below 2 (129..256 outputs per strip, write-heavy): 32 rows per workgroup (4.2 TB/s at 1:1
+    //     vs 2.5 at four and 1.4 at one); the up-sampling path (more than 256 outputs per strip) prefers 4.
+    int nt = a.rowsShared ? 0 : 1, interleave = 0, gy = 0;
+    int rows = a.maxRowSpan >= 4 ? (a.rowsShared ? 2 : 1) : 4;
+    if (a.maxOutputsPerStrip > 128 && a.maxOutputsPerStrip <= 256) rows = 32;      // ratios below 2: write-heavy
     if (const char *env = getenv("AAI_AXIS_TUNE")) {
         auto get = [&](const char *key, int &v) {
             const char *p = strstr(env, key);

@@ -194,6 +194,8 @@ int enqueue(const aai_request &rq, int batch, const float *dSrc, int64_t srcStri
         a.srcW = g.W; a.srcH = g.H;
         a.wide = t.wide ? 1 : 0;
         a.maxRowSpan = t.maxRowSpan;
+        a.rowsShared = t.rowsShared ? 1 : 0;
+        a.maxOutputsPerStrip = t.maxOutputsPerStrip;
         // (ka,kb) -> dst element: the lane axis is dst x unless the quadrant transposes; flips run an axis
         // backwards
         const int64_t sa = t.transposed ? dstStride : 1, sb = t.transposed ? 1 : dstStride;

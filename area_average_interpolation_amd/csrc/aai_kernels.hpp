@@ -25,6 +25,8 @@ struct AxisLaunch {
     int64_t outBase, outStrideA, outStrideB;   // dst element = outBase + ka*outStrideA + kb*outStrideB
     int wide;
     int maxRowSpan;             // largest number of source rows any output row needs
+    int rowsShared;             // consecutive output rows share a source row
+    int maxOutputsPerStrip;
 };
 hipError_t launch_axis(const AxisLaunch &a, const float *src, ImageView sv, float *dst, ImageView dv,
                        int batch, hipStream_t stream, const char **kernelName);

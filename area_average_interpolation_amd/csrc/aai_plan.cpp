@@ -287,9 +287,13 @@ void build_axis_tables(const Geometry &g, int mode, AxisTables &t)
 
     t.maxRowSpan = 0;
     for (const auto &e : t.row) t.maxRowSpan = std::max(t.maxRowSpan, e.s1 - e.s0 + 1);
+    t.rowsShared = false;
+    for (size_t i = 0; i + 1 < t.row.size(); ++i)
+        if (t.row[i].wMid + t.row[i].wFirst > 0.f && t.row[i + 1].wMid + t.row[i + 1].wFirst > 0.f && t.row[i].s1 >= t.row[i + 1].s0) { t.rowsShared = true; break; }
 
     // Greedy strips: consecutive lane-axis outputs whose windows fit in STRIP_COLS source columns.
     t.strips.clear();
+    t.maxOutputsPerStrip = 0;
     t.wide = g.W < 4;      // the strip kernel loads whole 4-column vectors
     int k = 0;
     while (k < t.nA) {
@@ -310,6 +314,7 @@ void build_axis_tables(const Geometry &g, int mode, AxisTables &t)
         }
         if (kk == k) { t.wide = true; kk = k + 1; }   // a single window wider than a strip
         s.x0 = x0; s.k1 = kk;
+        t.maxOutputsPerStrip = std::max(t.maxOutputsPerStrip, s.k1 - s.k0);
         t.strips.push_back(s);
         k = kk;
     }

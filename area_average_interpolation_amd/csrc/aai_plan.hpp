@@ -80,6 +80,8 @@ struct AxisTables {
     bool flipA = false, flipB = false;
     bool wide = false;               // some window is wider than a strip -> per-pixel fallback kernel
     int maxRowSpan = 0;              // largest s1-s0+1 over the row table
+    bool rowsShared = false;         // consecutive output rows read a common source row (windows not pixel-aligned)
+    int maxOutputsPerStrip = 0;
 };
 
 // mode: AAI_MODE_AREA (overlap lengths) or AAI_MODE_FAST (centre counts).  Only for g.axisAligned.

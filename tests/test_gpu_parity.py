@@ -113,6 +113,34 @@ def test_random_geometries_against_oracle(gpu, po):
             assert np.array_equal(gold.dst == 0, dst == 0), (k, mode)
 
 
+def test_axis_kernel_code_paths_against_oracle(gpu, po):
+    """Every branch of the axis-aligned path: one output per lane, many outputs per strip (ratios < 4 and
+    up-sampling), the right-edge fix-up (widths not a multiple of 4), the wide fallback (footprints wider than
+    a strip, or images narrower than 4 columns), all four quadrants, both modes."""
+    from area_average_interpolation_amd import _lib as L
+    rng = np.random.default_rng(17)
+    cases = [  # W, H, srcRes, dstRes, expected kernel
+        (517, 40, 4, 1, L.KERNEL_AXIS), (1030, 9, 8, 1, L.KERNEL_AXIS), (300, 33, 3, 1, L.KERNEL_AXIS),
+        (301, 21, 2, 1, L.KERNEL_AXIS), (259, 17, 1, 1, L.KERNEL_AXIS), (70, 50, 1, 2, L.KERNEL_AXIS),
+        (40, 30, 1, 4, L.KERNEL_AXIS), (263, 31, 8192, 2731, L.KERNEL_AXIS), (1500, 20, 10, 9, L.KERNEL_AXIS),
+        (3000, 12, 700, 1, L.KERNEL_AXIS_WIDE), (3, 50, 2, 1, L.KERNEL_AXIS_WIDE), (1, 1, 1, 1, L.KERNEL_AXIS_WIDE),
+        (2, 300, 1, 1, L.KERNEL_AXIS_WIDE), (4, 4, 2, 1, L.KERNEL_AXIS), (5, 700, 3, 1, L.KERNEL_AXIS),
+    ]
+    for (W, H, sr, dr, kern) in cases:
+        for ang in (0, 90, 180, 270):
+            iso = ((W - 1) / 2, (H - 1) / 2) if ang in (0, 180) else (float(rng.uniform(0, W)), float(rng.uniform(0, H)))
+            src = rng.random((H, W)).astype(np.float32)
+            for mode, omode in ((1, po.MODE_EXACT), (2, po.MODE_FAST)):
+                gold = po.oracle_run(omode, src.astype(np.float64), sr, dr, iso, ang)
+                dst, giso, lay = _host(gpu, src, dict(src_res=float(sr), dst_res=float(dr), iso=iso, angle=float(ang)), mode)
+                assert dst.shape == gold.dst.shape and tuple(giso) == gold.dst_iso
+                if ang in (0, 180):
+                    assert lay.kernel == kern, (W, H, sr, dr, ang, lay.kernel)
+                if dst.size:
+                    assert rel_err(dst, gold.dst).max() <= TOL, (W, H, sr, dr, ang, mode, gpu.last_kernel())
+                assert np.array_equal(gold.dst == 0, dst == 0), (W, H, sr, dr, ang, mode)
+
+
 def test_exact_policy_against_oracle(gpu, po):
     rng = np.random.default_rng(12)
     from area_average_interpolation_amd import _lib as L

@@ -13,7 +13,8 @@ import area_average_interpolation_amd as aai
 W = H = int(os.environ.get("TUNE_SIZE", "8192"))
 B = int(os.environ.get("TUNE_BATCH", "4"))
 ROUNDS = int(os.environ.get("TUNE_ROUNDS", "7"))
-rq = aai.make_request(W, H, float(os.environ.get("TUNE_SRCRES", "4")), 1.0, ((W - 1) / 2, (H - 1) / 2), float(os.environ.get("TUNE_ANGLE", "0")))
+SH = float(os.environ.get("TUNE_ISO_SHIFT", "0"))
+rq = aai.make_request(W, H, float(os.environ.get("TUNE_SRCRES", "4")), float(os.environ.get("TUNE_DSTRES", "1")), ((W - 1) / 2 + SH, (H - 1) / 2 + SH), float(os.environ.get("TUNE_ANGLE", "0")))
 rc, msg, lay = aai.query(rq)
 dW, dH = lay.dst_width, lay.dst_height
 aai.set_device(0)
