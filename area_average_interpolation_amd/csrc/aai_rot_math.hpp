@@ -175,6 +175,99 @@ AAI_HD double pair_area(const RotLaunch &f, double lx, double ly, int policy, bo
     return (isLeft == inTop) ? tri : 1.0 - tri;
 }
 
+// integral over eta in [e0,e1] intersect [0,1] of clamp01(x(eta)) for the line x(eta) = xr + (eta-er)*m
+// through the reference point (xr, er); e0 may be -infinity and e1 +infinity (a ray from a vertex).
+template <bool INCREASING>
+AAI_HD double ray_integral(double e0, double e1, double xr, double er, double m, double im)
+{
+    const double a = fmax(e0, 0.0), b = fmin(e1, 1.0);
+    if (!(a < b)) return 0.0;
+    const double t0 = er - xr * im;           // eta where x == 0
+    const double t1 = er + (1.0 - xr) * im;   // eta where x == 1
+    double ones, p, q;
+    if (INCREASING) { ones = fmax(b - fmax(a, t1), 0.0); p = fmax(a, t0); q = fmin(b, t1); }
+    else            { ones = fmax(fmin(b, t1) - a, 0.0); p = fmax(a, t1); q = fmin(b, t0); }
+    double ramp = 0.0;
+    if (q > p) {
+        const double xp = clamp01(xr + (p - er) * m), xq = clamp01(xr + (q - er) * m);
+        ramp = (q - p) * 0.5 * (xp + xq);
+    }
+    return ones + ramp;
+}
+
+// The production form of pair_area.  A unit pixel that is not wholly outside the square lies wholly inside
+// the half-planes of the two FAR edges (h = L/2 exceeds the pixel's half extent k), so only the nearer
+// left/right edge and the nearer top/bottom edge matter: the overlap is pixel (intersect) the quadrant those two
+// edges span at their common vertex V, i.e. two ray integrals instead of four segment integrals, and the
+// reference-policy test only has to look at those two edges.  nearLeft / nearTop say which edges are near
+// (signs of the pixel centre's dst-frame coordinates a, b).
+template <bool KNIFE>
+AAI_HD double wedge_pair_area(const RotLaunch &f, double lx, double ly, bool nearLeft, bool nearTop, int policy, bool &edgy)
+{
+    const double inf = HUGE_VAL;
+    if (KNIFE) edgy = false;
+    // the near vertex: v0 = left/top, v1 = right/top, v2 = left/bottom, v3 = right/bottom
+    const double ox = nearTop ? (nearLeft ? f.o0x : f.o1x) : (nearLeft ? -f.o1x : -f.o0x);
+    const double oy = nearTop ? (nearLeft ? f.o0y : f.o1y) : (nearLeft ? -f.o1y : -f.o0y);
+    const double vx = lx + ox, vy = ly + oy;
+    // m1: dx/dy of the left/right edges (increasing), m2: of the top/bottom edges (decreasing)
+    double area;
+    if (nearTop) {
+        if (nearLeft) area = 1.0 - ray_integral<false>(-inf, vy, vx, vy, f.m2, f.im2) - ray_integral<true>(vy, inf, vx, vy, f.m1, f.im1);
+        else          area = ray_integral<true>(vy, inf, vx, vy, f.m1, f.im1) - ray_integral<false>(vy, inf, vx, vy, f.m2, f.im2);
+    } else {
+        if (nearLeft) area = ray_integral<false>(-inf, vy, vx, vy, f.m2, f.im2) - ray_integral<true>(-inf, vy, vx, vy, f.m1, f.im1);
+        else          area = ray_integral<true>(-inf, vy, vx, vy, f.m1, f.im1) + ray_integral<false>(vy, inf, vx, vy, f.m2, f.im2);
+    }
+    area = clamp01(area);
+
+    if (KNIFE) {   // per-pair knife tests, fix-up pass only (see pair_area)
+        const double g = AAI_KNIFE_GUARD, L = 2.0 * f.h;
+        const double v0x = lx + f.o0x, v0y = ly + f.o0y, v1x = lx + f.o1x, v1y = ly + f.o1y;
+        const double v2x = lx - f.o1x, v2y = ly - f.o1y, v3x = lx - f.o0x, v3y = ly - f.o0y;
+        auto onSide = [&](double px, double py) {
+            const double ex = fmin(fabs(px), fabs(px - 1.0)), ey = fmin(fabs(py), fabs(py - 1.0));
+            const bool inx = px > -g && px < 1.0 + g, iny = py > -g && py < 1.0 + g;
+            return (ex < g && iny) || (ey < g && inx);
+        };
+        if (onSide(v0x, v0y) || onSide(v1x, v1y) || onSide(v2x, v2y) || onSide(v3x, v3y)) edgy = true;
+        const double dl0 = -v0x * f.c + v0y * f.s, dt0 = -v0x * f.s - v0y * f.c;
+        auto onEdge = [&](double dl, double dt) {
+            const double dr = L - dl, db = L - dt;
+            return (fmin(fabs(dl), fabs(dr)) < g && dt > -g && db > -g) || (fmin(fabs(dt), fabs(db)) < g && dl > -g && dr > -g);
+        };
+        if (onEdge(dl0, dt0) || onEdge(dl0 + f.c, dt0 + f.s) || onEdge(dl0 - f.s, dt0 + f.c) || onEdge(dl0 + f.c - f.s, dt0 + f.s + f.c)) edgy = true;
+    }
+    if (policy != AAI_POLICY_REFERENCE) return area;
+
+    // Reference policy: does the near top/bottom edge (as a segment) pass through the pixel?  It starts at
+    // its LEFT vertex (v0 for the top edge, v2 for the bottom edge) and runs along (c,-s).
+    {
+        const double sx = lx + (nearTop ? f.o0x : -f.o1x), sy = ly + (nearTop ? f.o0y : -f.o1y);
+        const double txa = -sx * f.rLc, txb = (1.0 - sx) * f.rLc;
+        const double tya = (sy - 1.0) * f.rLs, tyb = sy * f.rLs;
+        if (fmax(fmax(txa, tya), 0.0) < fmin(fmin(txb, tyb), 1.0)) return area;   // it crosses: two chords or a vertex, exact
+    }
+    // The near left/right edge starts at its TOP vertex (v0 / v1) and runs along (s,c): it enters through the
+    // top or left side and leaves through the bottom or right side.
+    const double ax = lx + (nearLeft ? f.o0x : f.o1x), ay = ly + (nearLeft ? f.o0y : f.o1y);
+    const double txa = -ax * f.rLs, txb = (1.0 - ax) * f.rLs;      // x = 0, x = 1
+    const double tya = -ay * f.rLc, tyb = (1.0 - ay) * f.rLc;      // y = 0, y = 1
+    const double tin = fmax(txa, tya), tout = fmin(txb, tyb);
+    if (!(tin < tout) || !(tin > 0.0) || !(tout < 1.0)) return area;   // misses, or a dst vertex lies inside
+    const bool inTop = tya > txa, outRight = txb < tyb;
+    if (inTop != outRight) return area;                            // opposite sides: a straight cut, exact
+    double tri;
+    if (inTop) {   // cuts the top-right corner: reference legs xa and 1-yb
+        const double xin = ax + tin * f.Ls, yout = ay + tout * f.Lc;
+        tri = 0.5 * xin * (1.0 - yout);
+    } else {       // cuts the bottom-left corner: reference legs 1-xb and ya
+        const double yin = ay + tin * f.Lc, xout = ax + tout * f.Ls;
+        tri = 0.5 * (1.0 - xout) * yin;
+    }
+    return (nearLeft == inTop) ? tri : 1.0 - tri;
+}
+
 // virtual pixel (X,Y) -> element offset in the original image (Source.cpp:164-167)
 AAI_HD int64_t virt_offset(const RotLaunch &r, int X, int Y, int64_t rowStride)
 {

@@ -95,7 +95,7 @@ __global__ __launch_bounds__(kRotBlock) void aai_rotated_kernel(RotLaunch r, con
                             pending[nPend++][tid] = (unsigned short)((edgy ? 0x8000 : 0) | ((Y - y0) << 8) | (X - x0));
                             continue;
                         }
-                        area = pair_area<STRICT>(r, px - (X - 0.5), py - (Y - 0.5), r.policy, edgy2);
+                        area = wedge_pair_area<STRICT>(r, px - (X - 0.5), py - (Y - 0.5), a < 0.0, b < 0.0, r.policy, edgy2);
                     } else area = single_cut_area<STRICT>(r, d, cls == PAIR_CUT_LR, r.policy, edgy2);   // types 2, 3, 4
                     if (STRICT && (edgy || edgy2)) {
                         {
@@ -114,7 +114,9 @@ __global__ __launch_bounds__(kRotBlock) void aai_rotated_kernel(RotLaunch r, con
                 const unsigned short code = pending[i][tid];
                 const int X = x0 + (code & 255), Y = y0 + ((code >> 8) & 127);
                 bool edgy = false;
-                double area = pair_area<STRICT>(r, px - (X - 0.5), py - (Y - 0.5), r.policy, edgy);
+                const double ex = X - px, ey = Y - py;
+                const bool nearLeft = ex * r.c - ey * r.s < 0.0, nearTop = ex * r.s + ey * r.c < 0.0;
+                double area = wedge_pair_area<STRICT>(r, px - (X - 0.5), py - (Y - 0.5), nearLeft, nearTop, r.policy, edgy);
                 if (STRICT && (edgy || (code & 0x8000))) {
                     {
                         if (!haveVertices) { strict_vertices(r, dx, dy, sv4); haveVertices = true; }

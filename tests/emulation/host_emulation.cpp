@@ -125,7 +125,8 @@ static void emu_rotated(const Geometry &g, const aai_request &rq, const float *i
                         if (cls == PAIR_OUTSIDE) continue;
                         double area;
                         if (cls == PAIR_INSIDE) area = 1.0;
-                        else if (cls == PAIR_GENERAL || g_forceGeneral) area = pair_area<true>(r, px - (X - 0.5), py - (Y - 0.5), r.policy, edgy2);
+                        else if (g_forceGeneral) area = pair_area<true>(r, px - (X - 0.5), py - (Y - 0.5), r.policy, edgy2);   // four-edge form
+                        else if (cls == PAIR_GENERAL) area = wedge_pair_area<true>(r, px - (X - 0.5), py - (Y - 0.5), a < 0.0, b < 0.0, r.policy, edgy2);
                         else area = single_cut_area<true>(r, d, cls == PAIR_CUT_LR, r.policy, edgy2);
                         // A pair-level knife flag in a pixel the per-pixel test let through is harmless as long as
                         // the strict replay would not have changed the area (e.g. a pixel corner on the EXTENSION
@@ -198,7 +199,7 @@ int aai_emu_pixel_pairs(const aai_request *rq, int dx, int dy, int cap, int *xs,
             const int c = classify_pair<true>(r, a, b, d, edgy);
             double area = 0;
             if (c == PAIR_INSIDE) area = 1;
-            else if (c == PAIR_GENERAL) area = pair_area<true>(r, px - (X - 0.5), py - (Y - 0.5), r.policy, edgy2);
+            else if (c == PAIR_GENERAL) area = wedge_pair_area<true>(r, px - (X - 0.5), py - (Y - 0.5), a < 0.0, b < 0.0, r.policy, edgy2);
             else if (c != PAIR_OUTSIDE) area = single_cut_area<true>(r, d, c == PAIR_CUT_LR, r.policy, edgy2);
             if (n < cap) { xs[n] = X; ys[n] = Y; cls[n] = c; knife[n] = (edgy || edgy2) ? 1 : 0; fast[n] = area; strict[n] = strict_pair_area(sv4, X, Y, r.policy); ++n; }
         }
