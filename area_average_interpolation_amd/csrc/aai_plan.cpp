@@ -309,6 +309,9 @@ void build_axis_tables(const Geometry &g, int mode, AxisTables &t)
             // also every earlier window must still fit from the (possibly lowered) origin: ascending
             // windows make the last one the binding constraint
             if (need > STRIP_COLS) break;
+            // at most 256 outputs per strip: the kernel then keeps four window descriptions per lane in
+            // registers and stores 16 bytes per lane (up-sampling would otherwise put >1000 outputs in a strip)
+            if (kk - k >= 256) break;
             x0 = lo2;
             ++kk;
         }

@@ -23,6 +23,20 @@ def cli(aai):
     return exe
 
 
+@pytest.fixture(scope="module")
+def shim(aai):
+    os.makedirs(BUILD, exist_ok=True)
+    exe = os.path.join(BUILD, "shim_test")
+    pkg = os.path.join(ROOT, "area_average_interpolation_amd")
+    srcs = [os.path.join(ROOT, "tests", "cpp", "shim_test.cpp"), os.path.join(ROOT, "include", "AreaAverageInterpolation.hpp"),
+            os.path.join(ROOT, "include", "aai.h")]
+    if not os.path.exists(exe) or any(os.path.getmtime(s) > os.path.getmtime(exe) for s in srcs):
+        r = subprocess.run(["g++", "-O2", "-std=c++17", "-I" + os.path.join(ROOT, "include"), srcs[0], "-o", exe,
+                            "-L" + pkg, "-laai_hip", "-Wl,-rpath," + pkg], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+    return exe
+
+
 def _run(exe, *args):
     r = subprocess.run([exe, *args], capture_output=True, text=True)
     return r.returncode, r.stdout
@@ -64,3 +78,26 @@ def test_cli_end_to_end_matches_oracle(cli, po, tmp_path):
         assert got.shape == gold.shape
         # the reference writes 6 significant digits (default ostream precision, Source.cpp:1508)
         assert np.abs(got - gold).max() <= 6e-6 * max(1.0, np.abs(gold).max()) + TOL
+
+
+def test_cpp_class_error_paths_like_the_reference(shim):
+    """{false, message} with the reference's texts, check order, dst / dstIsocenter untouched; ragged rows and
+    NaN arguments (undefined behaviour in the reference) are rejected.  Needs no GPU."""
+    rc, out = _run(shim, "errors")
+    assert rc == 0 and "errors: all ok" in out, out
+
+
+@pytest.mark.gpu
+def test_cpp_class_matches_oracle(shim, po):
+    for (mode, W, H, sr, dr, ix, iy, ang, seed) in ((1, 40, 33, 150, 25.4, 19.5, 16.0, 1.5, 7), (2, 40, 33, 150, 25.4, 19.5, 16.0, 1.5, 7),
+                                                    (1, 64, 64, 4, 1, 31.5, 31.5, 0.0, 8), (1, 30, 20, 1, 2, 14.5, 9.5, 45.0, 9)):
+        rc, out = _run(shim, "run", str(mode), str(W), str(H), repr(float(sr)), repr(float(dr)), repr(float(ix)), repr(float(iy)), repr(float(ang)), str(seed))
+        assert rc == 0, out
+        lines = out.strip().split("\n")
+        dW, dH, isoX, isoY = lines[0].split()
+        got = np.array([[float(v) for v in ln.split()] for ln in lines[1:]], dtype=np.float64).reshape(int(dH), int(dW))
+        src = po.synth_image(W, H, seed).astype(np.float64)
+        gold = po.oracle_run(po.MODE_EXACT if mode == 1 else po.MODE_FAST, src, sr, dr, (ix, iy), ang)
+        assert got.shape == gold.dst.shape and (float(isoX), float(isoY)) == gold.dst_iso
+        err = np.abs(got - gold.dst) / np.maximum(np.abs(gold.dst), 1e-3)
+        assert err.max() <= TOL, (mode, W, H, ang, float(err.max()))
