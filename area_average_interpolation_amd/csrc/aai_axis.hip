@@ -165,7 +165,46 @@ __global__ __launch_bounds__(kWaves * 64) void aai_axis_kernel(AxisLaunch a, con
     const int rowEnd = interleave ? a.nB : min(rowStart + rowsPerBlock, a.nB);
     const int nOut = st.k1 - st.k0;
 
-    if (nOut <= 64) {
+    if (nOut <= 64 && (a.outStrideB == 1 || a.outStrideB == -1) && rowStep == 1) {
+        // Quadrants 1 and 3 (pre-rotation by 90 / 270 degrees): the lane axis runs along dst y, so the output
+        // rows of this workgroup are CONSECUTIVE DST COLUMNS of each lane's dst row.  Keep eight of them in
+        // registers and write them as two 16-byte stores per lane instead of eight 4-byte stores a row pitch
+        // apart.
+        const bool live = lane < nOut;
+        const Win c = load_win(laneTab, live ? st.k0 + lane : st.k0);
+        const int off = c.s0 - st.x0, span = c.s1 - c.s0;
+        float *orow = out + (int64_t)(st.k0 + lane) * a.outStrideA;
+        for (int kb0 = rowStart; kb0 < rowEnd; kb0 += 8) {
+            float acc[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                acc[j] = 0.f;
+                if (kb0 + j < rowEnd) {          // wave-uniform
+                    const Win e = load_win(rowTab, kb0 + j);
+                    const f4 v = fix_edge(vertical_pass<NT>(img, sv.rowStride, colc, e), shift);
+                    __builtin_amdgcn_wave_barrier();
+                    *reinterpret_cast<f4 *>(line + 4 * lane) = v;
+                    __builtin_amdgcn_wave_barrier();
+                    acc[j] = horizontal_pass(line, off, span, c.wF, c.wM, c.wL);
+                }
+            }
+            if (!live) continue;
+            if (kb0 + 8 <= rowEnd) {
+                // ascending dst columns: kb0..kb0+7 when outStrideB = +1, reversed when -1
+                const bool fwd = a.outStrideB == 1;
+                float *p = orow + (int64_t)(fwd ? kb0 : kb0 + 7) * a.outStrideB;
+                f4 lo, hi;
+                lo.x = fwd ? acc[0] : acc[7]; lo.y = fwd ? acc[1] : acc[6]; lo.z = fwd ? acc[2] : acc[5]; lo.w = fwd ? acc[3] : acc[4];
+                hi.x = fwd ? acc[4] : acc[3]; hi.y = fwd ? acc[5] : acc[2]; hi.z = fwd ? acc[6] : acc[1]; hi.w = fwd ? acc[7] : acc[0];
+                *reinterpret_cast<f4u *>(p) = lo;
+                *reinterpret_cast<f4u *>(p + 4) = hi;
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    if (kb0 + j < rowEnd) orow[(int64_t)(kb0 + j) * a.outStrideB] = acc[j];
+            }
+        }
+    } else if (nOut <= 64) {
         // Common case (any down-sampling ratio >= 4 source columns per output): one output per lane,
         // its window description stays in registers for all rows.
         const bool live = lane < nOut;
@@ -267,6 +306,7 @@ hipError_t launch_axis(const AxisLaunch &a, const float *src, ImageView sv, floa
     //     vs 2.5 at four and 1.4 at one); the up-sampling path (more than 256 outputs per strip) prefers 4.
     int nt = a.rowsShared ? 0 : 1, interleave = 0, gy = 0;
     int rows = a.maxRowSpan >= 4 ? (a.rowsShared ? 2 : 1) : 4;
+    if (a.outStrideA != 1 && a.outStrideA != -1) rows = 8;      // transposed quadrants: eight dst columns per lane and store
     if (a.maxOutputsPerStrip > 128 && a.maxOutputsPerStrip <= 256) rows = 32;      // ratios below 2: write-heavy
     if (const char *env = getenv("AAI_AXIS_TUNE")) {
         auto get = [&](const char *key, int &v) {
