@@ -33,10 +33,15 @@ __global__ __launch_bounds__(kRotBlock) void aai_rotated_kernel(RotLaunch r, con
 
     const int dx = blockIdx.x * 16 + (tid & 15);
     const int dy = blockIdx.y * 16 + (tid >> 4);
-    const bool valid = dx < r.dW && dy < r.dH;      // no barriers below
+    const bool valid = dx < r.dW && dy < r.dH;
+    const float *img = src + (int64_t)blockIdx.z * sv.imageStride;
+
+    // (Staging the tile's source footprint in LDS with coalesced loads was measured and rejected: cfg3 1452 ->
+    // 1744 us, cfg3 fast 435 -> 560 us, cfg5 17.3 -> 21.4 ms.  The per-lane 4-byte loads hit L1/L2 and are not the
+    // limiter; the extra pass, the barrier and the lost occupancy cost more.)
+    auto fetch = [&](int X, int Y) -> double { return (double)img[virt_offset(r, X, Y, sv.rowStride)]; };
 
     if (valid) {
-        const float *img = src + (int64_t)blockIdx.z * sv.imageStride;
         float *out = dst + (int64_t)blockIdx.z * dv.imageStride + (int64_t)dy * dv.rowStride + dx;
 
         double px, py;
@@ -51,7 +56,25 @@ __global__ __launch_bounds__(kRotBlock) void aai_rotated_kernel(RotLaunch r, con
         SVec sv4[4];                                 // the reference's vertices, fetched lazily (STRICT only)
         bool haveVertices = false;
 
-        if (MODE == AAI_MODE_FAST) {
+        if (MODE == AAI_MODE_FAST && !STRICT) {
+            // Production pass of the fast mode.  The centres inside the closed square form one interval per
+            // source row (two pairs of parallel edges = two interval constraints on X), so there is no
+            // per-pixel test: bounds from four multiplications per row, then loads and adds.  Centres within
+            // 2e-9 of an edge would make the integer bounds ambiguous -- exactly the pixels the knife-edge scan
+            // flags and the fix-up pass (the per-pixel loop below) redoes.
+            int count = 0;
+            double acc = 0.0;
+            for (int Y = y0; Y <= y1; ++Y) {
+                const double ey = Y - py;
+                const double es = ey * r.s, ec = ey * r.c;
+                const double lo = fmax((es - r.h) * r.rc, (-r.h - ec) * r.rs);
+                const double hi = fmin((es + r.h) * r.rc, (r.h - ec) * r.rs);
+                const int xa = max(0, (int)ceil(px + lo)), xb = min(r.mW - 1, (int)floor(px + hi));
+                for (int X = xa; X <= xb; ++X) acc += fetch(X, Y);
+                count += max(0, xb - xa + 1);
+            }
+            *out = count > 0 ? (float)(acc / count) : 0.f;      // Source.cpp:905
+        } else if (MODE == AAI_MODE_FAST) {
             // closed-square membership of the pixel centre with the reference's parameter slack
             const double lim = r.h + DBL_EPSILON * r.side;
             int count = 0;
@@ -71,7 +94,7 @@ __global__ __launch_bounds__(kRotBlock) void aai_rotated_kernel(RotLaunch r, con
                             in = strict_centre_inside(pc, sv4);
                         }
                     }
-                    if (in) { ++count; acc += (double)img[virt_offset(r, X, Y, sv.rowStride)]; }
+                    if (in) { ++count; acc += fetch(X, Y); }
                 }
             *out = count > 0 ? (float)(acc / count) : 0.f;      // Source.cpp:905
         } else {
@@ -105,7 +128,7 @@ __global__ __launch_bounds__(kRotBlock) void aai_rotated_kernel(RotLaunch r, con
                     }
                     if (area != 0.0) {
                         sumA += area;
-                        sumVA += area * (double)img[virt_offset(r, X, Y, sv.rowStride)];
+                        sumVA += area * fetch(X, Y);
                     }
                 }
             }
@@ -125,7 +148,7 @@ __global__ __launch_bounds__(kRotBlock) void aai_rotated_kernel(RotLaunch r, con
                 }
                 if (area != 0.0) {
                     sumA += area;
-                    sumVA += area * (double)img[virt_offset(r, X, Y, sv.rowStride)];
+                    sumVA += area * fetch(X, Y);
                 }
             }
             *out = DBL_EPSILON < fabs(sumA) ? (float)(sumVA / sumA) : 0.f;   // Source.cpp:577

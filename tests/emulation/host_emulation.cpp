@@ -86,7 +86,19 @@ static void emu_rotated(const Geometry &g, const aai_request &rq, const float *i
             long knifeHere = 0;
             // the production pass flags whole dst pixels; only flagged ones reach the strict replay
             const bool flagged = pixel_on_knife_edge(r, px, py, rq.mode != AAI_MODE_FAST);
-            if (rq.mode == AAI_MODE_FAST) {
+            if (rq.mode == AAI_MODE_FAST && !flagged) {
+                // production pass: one interval of centres per source row (see aai_rotated_kernel)
+                int count = 0; double acc = 0;
+                for (int Y = y0; Y <= y1; ++Y) {
+                    const double ey = Y - py, es = ey * r.s, ec = ey * r.c;
+                    const double lo = std::fmax((es - r.h) * r.rc, (-r.h - ec) * r.rs);
+                    const double hi = std::fmin((es + r.h) * r.rc, (r.h - ec) * r.rs);
+                    const int xa = std::max(0, (int)std::ceil(px + lo)), xb = std::min(r.mW - 1, (int)std::floor(px + hi));
+                    for (int X = xa; X <= xb; ++X) acc += (double)img[virt_offset(r, X, Y, srcStride)];
+                    count += std::max(0, xb - xa + 1);
+                }
+                *out = count > 0 ? (float)(acc / count) : 0.f;
+            } else if (rq.mode == AAI_MODE_FAST) {
                 const double lim = r.h + DBL_EPSILON * r.side;
                 int count = 0; double acc = 0;
                 for (int Y = y0; Y <= y1; ++Y)
