@@ -69,9 +69,12 @@ __global__ __launch_bounds__(kRotBlock) void aai_rotated_kernel(RotLaunch r, con
                 const double es = ey * r.s, ec = ey * r.c;
                 const double lo = fmax((es - r.h) * r.rc, (-r.h - ec) * r.rs);
                 const double hi = fmin((es + r.h) * r.rc, (r.h - ec) * r.rs);
-                const int xa = max(0, (int)ceil(px + lo)), xb = min(r.mW - 1, (int)floor(px + hi));
+                // clamp in double before converting: near-axis rotations make the unconstrained bounds astronomically large
+                const double da = fmax(ceil(px + lo), 0.0), db = fmin(floor(px + hi), (double)(r.mW - 1));
+                if (!(da <= db)) continue;
+                const int xa = (int)da, xb = (int)db;
                 for (int X = xa; X <= xb; ++X) acc += fetch(X, Y);
-                count += max(0, xb - xa + 1);
+                count += xb - xa + 1;
             }
             *out = count > 0 ? (float)(acc / count) : 0.f;      // Source.cpp:905
         } else if (MODE == AAI_MODE_FAST) {

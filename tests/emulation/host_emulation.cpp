@@ -93,9 +93,11 @@ static void emu_rotated(const Geometry &g, const aai_request &rq, const float *i
                     const double ey = Y - py, es = ey * r.s, ec = ey * r.c;
                     const double lo = std::fmax((es - r.h) * r.rc, (-r.h - ec) * r.rs);
                     const double hi = std::fmin((es + r.h) * r.rc, (r.h - ec) * r.rs);
-                    const int xa = std::max(0, (int)std::ceil(px + lo)), xb = std::min(r.mW - 1, (int)std::floor(px + hi));
+                    const double da = std::fmax(std::ceil(px + lo), 0.0), db = std::fmin(std::floor(px + hi), (double)(r.mW - 1));
+                    if (!(da <= db)) continue;
+                    const int xa = (int)da, xb = (int)db;
                     for (int X = xa; X <= xb; ++X) acc += (double)img[virt_offset(r, X, Y, srcStride)];
-                    count += std::max(0, xb - xa + 1);
+                    count += xb - xa + 1;
                 }
                 *out = count > 0 ? (float)(acc / count) : 0.f;
             } else if (rq.mode == AAI_MODE_FAST) {

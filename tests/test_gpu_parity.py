@@ -141,6 +141,22 @@ def test_axis_kernel_code_paths_against_oracle(gpu, po):
                 assert np.array_equal(gold.dst == 0, dst == 0), (W, H, sr, dr, ang, mode)
 
 
+def test_near_axis_rotations_against_oracle(gpu, po):
+    """Rotations a hair away from a multiple of 90 degrees: the rotated kernels run with sin or cos around 1e-9
+    (1/sin ~ 1e9 inside the closed forms), or the request snaps to the axis-aligned kernel (|tan| < DBL_EPSILON)."""
+    rng = np.random.default_rng(3)
+    for ang in (1e-13, 1e-10, 1e-7, 1e-4, 0.01, 89.99, 89.9999999, 90 - 1e-10, 90 + 1e-9, 179.9999, 359.999999):
+        for (sr, dr) in ((3, 1), (1, 1), (2.5, 1)):
+            W, H, iso = 37, 29, (17.3, 12.1)
+            src = rng.random((H, W)).astype(np.float32)
+            for mode, omode in ((1, po.MODE_EXACT), (2, po.MODE_FAST)):
+                gold = po.oracle_run(omode, src.astype(np.float64), sr, dr, iso, ang).dst
+                dst, _, lay = _host(gpu, src, dict(src_res=float(sr), dst_res=float(dr), iso=iso, angle=float(ang)), mode)
+                assert dst.shape == gold.shape
+                assert rel_err(dst, gold).max() <= TOL, (ang, sr, dr, mode, lay.kernel)
+                assert np.array_equal(gold == 0, dst == 0), (ang, sr, dr, mode)
+
+
 def test_exact_policy_against_oracle(gpu, po):
     rng = np.random.default_rng(12)
     from area_average_interpolation_amd import _lib as L
