@@ -1,6 +1,6 @@
 """MI355X-native area-average image interpolation: Python plumbing over the C ABI in include/aai.h."""
 from . import _lib
-from ._lib import (MODE_AREA, MODE_FAST, MODE_BILINEAR, MODE_BICUBIC, POLICY_REFERENCE, POLICY_EXACT,
+from ._lib import (DTYPE_F32, DTYPE_U8, DTYPE_U16, MODE_AREA, MODE_FAST, MODE_BILINEAR, MODE_BICUBIC, POLICY_REFERENCE, POLICY_EXACT,
                    Request, Layout)
 from .api import (AreaAverageInterpolation, AaiError, make_request, query, resample_host, resample_device,
                   synth_device, device_count, set_device, synchronize, last_kernel, last_error)
@@ -8,4 +8,4 @@ from .api import (AreaAverageInterpolation, AaiError, make_request, query, resam
 __all__ = ["AreaAverageInterpolation", "AaiError", "make_request", "query", "resample_host", "resample_device",
            "synth_device", "device_count", "set_device", "synchronize", "last_kernel", "last_error",
            "MODE_AREA", "MODE_FAST", "MODE_BILINEAR", "MODE_BICUBIC", "POLICY_REFERENCE", "POLICY_EXACT",
-           "Request", "Layout"]
+           "Request", "Layout", "DTYPE_F32", "DTYPE_U8", "DTYPE_U16"]

@@ -23,6 +23,7 @@ ERR_HIP = 9
 
 MODE_AREA, MODE_FAST, MODE_BILINEAR, MODE_BICUBIC = 1, 2, 3, 4
 POLICY_REFERENCE, POLICY_EXACT = 0, 1
+DTYPE_F32, DTYPE_U8, DTYPE_U16 = 0, 1, 2
 KERNEL_AXIS, KERNEL_ROTATED, KERNEL_FAST, KERNEL_SAMPLE, KERNEL_AXIS_WIDE = 1, 2, 3, 4, 5
 
 
@@ -62,6 +63,8 @@ SYMBOLS = {
     "aai_resample_f64": (ctypes.c_int, [_RQ, _P, _I64, _P, _I64, _LY]),
     "aai_resample_device_f32": (ctypes.c_int, [_RQ, _P, _I64, _P, _I64, _P]),
     "aai_resample_batch_device_f32": (ctypes.c_int, [_RQ, ctypes.c_int32, _P, _I64, _I64, _P, _I64, _I64, _P]),
+    "aai_resample_batch_device": (ctypes.c_int, [_RQ, ctypes.c_int32, _P, ctypes.c_int32, _I64, _I64, _P, _I64, _I64, _P]),
+    "aai_resample_host": (ctypes.c_int, [_RQ, _P, ctypes.c_int32, _I64, _P, _I64, _LY]),
     "aai_synth_device_f32": (ctypes.c_int, [_P, ctypes.c_int32, ctypes.c_int32, _I64, ctypes.c_uint64, _P]),
     "aai_last_kernel": (ctypes.c_char_p, []),
 }

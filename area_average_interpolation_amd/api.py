@@ -82,6 +82,21 @@ def resample_host(src, src_resolution, dst_resolution, src_isocenter, rotation_a
     Returns (code, message, dst ndarray or None, (dstIsoX, dstIsoY) or None, Layout or None)."""
     lib = L.load()
     a = np.asarray(src)
+    if a.ndim == 2 and a.dtype in (np.uint8, np.uint16):
+        # typed entry (aai_resample_host): 8/16-bit source, fp32 output
+        a = np.ascontiguousarray(a)
+        H, W = a.shape
+        rq = make_request(W, H, src_resolution, dst_resolution, src_isocenter, rotation_angle, mode, policy)
+        rc, msg, lay = query(rq)
+        if rc != L.OK:
+            return rc, msg, None, None, None
+        dst = np.empty((lay.dst_height, lay.dst_width), dtype=np.float32)
+        out_lay = L.Layout()
+        rc = lib.aai_resample_host(ctypes.byref(rq), a.ctypes.data, L.DTYPE_U8 if a.dtype == np.uint8 else L.DTYPE_U16, W,
+                                   dst.ctypes.data, max(lay.dst_width, 1), ctypes.byref(out_lay))
+        if rc != L.OK:
+            return rc, last_error(), None, None, None
+        return rc, "", dst, (out_lay.dst_iso_x, out_lay.dst_iso_y), out_lay
     if a.ndim != 2:
         # the reference's two "no data" errors (Source.cpp:123-132)
         a = a.reshape(0, 0) if a.size == 0 else a
@@ -103,9 +118,16 @@ def resample_host(src, src_resolution, dst_resolution, src_isocenter, rotation_a
 
 
 def resample_device(request, src_ptr, src_stride, dst_ptr, dst_stride, stream=0, batch=None,
-                    src_image_stride=0, dst_image_stride=0):
-    """Device-resident path: raw device pointers (ints) and a hipStream_t handle (int, 0 = default)."""
+                    src_image_stride=0, dst_image_stride=0, src_dtype=L.DTYPE_F32):
+    """Device-resident path: raw device pointers (ints) and a hipStream_t handle (int, 0 = default).
+    src_dtype: DTYPE_F32 (default) / DTYPE_U8 / DTYPE_U16 -- strides are in source elements."""
     lib = L.load()
+    if src_dtype != L.DTYPE_F32:
+        rc = lib.aai_resample_batch_device(ctypes.byref(request), 1 if batch is None else int(batch), src_ptr, int(src_dtype),
+                                           src_stride, src_image_stride, dst_ptr, dst_stride, dst_image_stride, stream)
+        if rc != L.OK:
+            raise AaiError(rc, last_error())
+        return
     if batch is None:
         rc = lib.aai_resample_device_f32(ctypes.byref(request), src_ptr, src_stride, dst_ptr, dst_stride, stream)
     else:

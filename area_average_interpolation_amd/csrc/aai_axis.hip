@@ -48,6 +48,29 @@ __device__ __forceinline__ f4 load_cols(const float *__restrict__ row, int colc)
     return NT ? __builtin_nontemporal_load(p) : *p;
 }
 
+// 8- and 16-bit sources: the same four columns per lane are one 4- or 8-byte load,
+// widened to fp32 in registers; everything downstream is unchanged.
+typedef unsigned int u32u __attribute__((aligned(1)));
+typedef unsigned int u32x2u __attribute__((ext_vector_type(2), aligned(2)));
+
+template <bool NT>
+__device__ __forceinline__ f4 load_cols(const unsigned char *__restrict__ row, int colc)
+{
+    const u32u *p = reinterpret_cast<const u32u *>(row + colc);
+    const unsigned w = NT ? __builtin_nontemporal_load(p) : *p;
+    f4 v = {(float)(w & 255u), (float)((w >> 8) & 255u), (float)((w >> 16) & 255u), (float)(w >> 24)};
+    return v;
+}
+
+template <bool NT>
+__device__ __forceinline__ f4 load_cols(const unsigned short *__restrict__ row, int colc)
+{
+    const u32x2u *p = reinterpret_cast<const u32x2u *>(row + colc);
+    const u32x2u w = NT ? __builtin_nontemporal_load(p) : *p;
+    f4 v = {(float)(w.x & 65535u), (float)(w.x >> 16), (float)(w.y & 65535u), (float)(w.y >> 16)};
+    return v;
+}
+
 // v holds columns [colc, colc+4); return columns [colc+shift, colc+shift+4) with zeros past the edge.
 __device__ __forceinline__ f4 fix_edge(f4 v, int shift)
 {
@@ -82,12 +105,12 @@ __device__ __forceinline__ float row_weight(const Win e, int y)
 // "row exists" branches are scalar: rows past the window are simply not loaded.
 struct Quad { f4 r0, r1, r2, r3; float w0, w1, w2, w3; };
 
-template <bool NT>
-__device__ __forceinline__ Quad issue_quad(const float *__restrict__ img, int64_t rowStride, int colc, const Win e, int y)
+template <bool NT, typename T>
+__device__ __forceinline__ Quad issue_quad(const T *__restrict__ img, int64_t rowStride, int colc, const Win e, int y)
 {
     Quad q;
     const f4 z = {0.f, 0.f, 0.f, 0.f};
-    const float *p = img + (int64_t)y * rowStride;
+    const T *p = img + (int64_t)y * rowStride;
     q.r0 = load_cols<NT>(p, colc);
     q.r1 = z; q.r2 = z; q.r3 = z;
     if (y + 1 <= e.s1) q.r1 = load_cols<NT>(p + rowStride, colc);
@@ -107,11 +130,11 @@ __device__ __forceinline__ f4 reduce_quad(const Quad &q, f4 acc)
 }
 
 // Vertical pass for one output row: sum_y w(y) * src[y][colc..colc+3], rows issued four at a time.
-template <bool NT>
-__device__ __forceinline__ f4 vertical_pass(const float *__restrict__ img, int64_t rowStride, int colc, const Win e)
+template <bool NT, typename T>
+__device__ __forceinline__ f4 vertical_pass(const T *__restrict__ img, int64_t rowStride, int colc, const Win e)
 {
     f4 acc = {0.f, 0.f, 0.f, 0.f};
-    for (int y = e.s0; y <= e.s1; y += 4) acc = reduce_quad(issue_quad<NT>(img, rowStride, colc, e, y), acc);
+    for (int y = e.s0; y <= e.s1; y += 4) acc = reduce_quad(issue_quad<NT, T>(img, rowStride, colc, e, y), acc);
     return acc;
 }
 
@@ -136,10 +159,10 @@ __device__ __forceinline__ float horizontal_pass(const float *line, int off, int
 // time, whereas tall workgroups open 2048 independent streams 32 KiB apart.  A software-pipelined variant
 // (two output rows in flight per wave) bought 2 % at 2+ rows per workgroup and nothing at 1, so the kernel
 // keeps the simple form: 4 source rows (4 KiB per wave) in flight, latency covered by 8 waves per SIMD.
-template <bool NT>
+template <bool NT, typename T>
 __global__ __launch_bounds__(kWaves * 64) void aai_axis_kernel(AxisLaunch a, const AxisEntry *__restrict__ laneTab,
                                                                 const AxisEntry *__restrict__ rowTab, const AxisStrip *__restrict__ strips,
-                                                                const float *__restrict__ src, ImageView sv,
+                                                                const T *__restrict__ src, ImageView sv,
                                                                 float *__restrict__ dst, ImageView dv,
                                                                 int rowsPerBlock, int interleave)
 {
@@ -153,7 +176,7 @@ __global__ __launch_bounds__(kWaves * 64) void aai_axis_kernel(AxisLaunch a, con
     typedef int i4s __attribute__((ext_vector_type(4)));
     const i4s stq = reinterpret_cast<const i4s *>(strips)[strip];
     struct { int k0, k1, x0; } st = {stq.x, stq.y, stq.z};
-    const float *img = src + (int64_t)blockIdx.z * sv.imageStride;
+    const T *img = src + (int64_t)blockIdx.z * sv.imageStride;
     float *out = dst + (int64_t)blockIdx.z * dv.imageStride + a.outBase;
     float *line = lds[wave];
     const int col = st.x0 + 4 * lane;
@@ -181,7 +204,7 @@ __global__ __launch_bounds__(kWaves * 64) void aai_axis_kernel(AxisLaunch a, con
                 acc[j] = 0.f;
                 if (kb0 + j < rowEnd) {          // wave-uniform
                     const Win e = load_win(rowTab, kb0 + j);
-                    const f4 v = fix_edge(vertical_pass<NT>(img, sv.rowStride, colc, e), shift);
+                    const f4 v = fix_edge(vertical_pass<NT, T>(img, sv.rowStride, colc, e), shift);
                     __builtin_amdgcn_wave_barrier();
                     *reinterpret_cast<f4 *>(line + 4 * lane) = v;
                     __builtin_amdgcn_wave_barrier();
@@ -213,7 +236,7 @@ __global__ __launch_bounds__(kWaves * 64) void aai_axis_kernel(AxisLaunch a, con
         const int64_t outCol = (int64_t)(st.k0 + lane) * a.outStrideA;
         for (int kb = rowStart; kb < rowEnd; kb += rowStep) {
             const Win e = load_win(rowTab, kb);
-            const f4 v = fix_edge(vertical_pass<NT>(img, sv.rowStride, colc, e), shift);
+            const f4 v = fix_edge(vertical_pass<NT, T>(img, sv.rowStride, colc, e), shift);
             __builtin_amdgcn_wave_barrier();
             *reinterpret_cast<f4 *>(line + 4 * lane) = v;
             __builtin_amdgcn_wave_barrier();
@@ -228,7 +251,7 @@ __global__ __launch_bounds__(kWaves * 64) void aai_axis_kernel(AxisLaunch a, con
         const Win c2 = load_win(laneTab, nq > 2 ? kq + 2 : st.k0), c3 = load_win(laneTab, nq > 3 ? kq + 3 : st.k0);
         for (int kb = rowStart; kb < rowEnd; kb += rowStep) {
             const Win e = load_win(rowTab, kb);
-            const f4 v = fix_edge(vertical_pass<NT>(img, sv.rowStride, colc, e), shift);
+            const f4 v = fix_edge(vertical_pass<NT, T>(img, sv.rowStride, colc, e), shift);
             __builtin_amdgcn_wave_barrier();
             *reinterpret_cast<f4 *>(line + 4 * lane) = v;
             __builtin_amdgcn_wave_barrier();
@@ -249,7 +272,7 @@ __global__ __launch_bounds__(kWaves * 64) void aai_axis_kernel(AxisLaunch a, con
         // Many outputs per strip (up-sampling, transposed quadrants at small ratios): lanes walk the outputs.
         for (int kb = rowStart; kb < rowEnd; kb += rowStep) {
             const Win e = load_win(rowTab, kb);
-            const f4 v = fix_edge(vertical_pass<NT>(img, sv.rowStride, colc, e), shift);
+            const f4 v = fix_edge(vertical_pass<NT, T>(img, sv.rowStride, colc, e), shift);
             __builtin_amdgcn_wave_barrier();
             *reinterpret_cast<f4 *>(line + 4 * lane) = v;
             __builtin_amdgcn_wave_barrier();
@@ -264,20 +287,21 @@ __global__ __launch_bounds__(kWaves * 64) void aai_axis_kernel(AxisLaunch a, con
 
 // Fallback for footprints wider than one strip (down-sampling by more than ~250:1): one thread per output
 // pixel walks its whole window.  Correct, not fast; such ratios leave almost no output to write.
-__global__ __launch_bounds__(256) void aai_axis_wide_kernel(AxisLaunch a, const float *__restrict__ src, ImageView sv,
+template <typename T>
+__global__ __launch_bounds__(256) void aai_axis_wide_kernel(AxisLaunch a, const T *__restrict__ src, ImageView sv,
                                                              float *__restrict__ dst, ImageView dv)
 {
     const int ka = blockIdx.x * 64 + (threadIdx.x & 63);
     const int kb = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (ka >= a.nA || kb >= a.nB) return;
     const Win c = load_win(a.laneTab, ka), e = load_win(a.rowTab, kb);
-    const float *img = src + (int64_t)blockIdx.z * sv.imageStride;
+    const T *img = src + (int64_t)blockIdx.z * sv.imageStride;
     float acc = 0.f;
     for (int y = e.s0; y <= e.s1; ++y) {
-        const float *row = img + (int64_t)y * sv.rowStride;
+        const T *row = img + (int64_t)y * sv.rowStride;
         float h = 0.f;
         for (int x = c.s0; x <= c.s1; ++x)
-            h += row_weight(c, x) * row[x];
+            h += row_weight(c, x) * (float)row[x];
         acc += row_weight(e, y) * h;
     }
     dst[(int64_t)blockIdx.z * dv.imageStride + a.outBase + (int64_t)ka * a.outStrideA + (int64_t)kb * a.outStrideB] = acc;
@@ -285,14 +309,29 @@ __global__ __launch_bounds__(256) void aai_axis_wide_kernel(AxisLaunch a, const 
 
 }  // namespace
 
-hipError_t launch_axis(const AxisLaunch &a, const float *src, ImageView sv, float *dst, ImageView dv,
+template <typename T>
+static hipError_t launch_axis_typed(const AxisLaunch &a, const T *src, ImageView sv, float *dst, ImageView dv,
+                                    int batch, hipStream_t stream, const char **kernelName);
+
+hipError_t launch_axis(const AxisLaunch &a, const void *src, int srcType, ImageView sv, float *dst, ImageView dv,
                        int batch, hipStream_t stream, const char **kernelName)
+{
+    switch (srcType) {
+    case SRC_U8: return launch_axis_typed(a, static_cast<const unsigned char *>(src), sv, dst, dv, batch, stream, kernelName);
+    case SRC_U16: return launch_axis_typed(a, static_cast<const unsigned short *>(src), sv, dst, dv, batch, stream, kernelName);
+    default: return launch_axis_typed(a, static_cast<const float *>(src), sv, dst, dv, batch, stream, kernelName);
+    }
+}
+
+template <typename T>
+static hipError_t launch_axis_typed(const AxisLaunch &a, const T *src, ImageView sv, float *dst, ImageView dv,
+                                    int batch, hipStream_t stream, const char **kernelName)
 {
     if (a.nA <= 0 || a.nB <= 0 || batch <= 0) return hipSuccess;
     if (a.wide) {
         dim3 grid((a.nA + 63) / 64, (a.nB + 3) / 4, batch);
         if (kernelName) *kernelName = "aai_axis_wide_kernel";
-        hipLaunchKernelGGL(aai_axis_wide_kernel, grid, dim3(256), 0, stream, a, src, sv, dst, dv);
+        hipLaunchKernelGGL((aai_axis_wide_kernel<T>), grid, dim3(256), 0, stream, a, src, sv, dst, dv);
         return hipGetLastError();
     }
     // Launch shape (see the kernel comment for the measurements behind the defaults).  Each knob can be
@@ -322,8 +361,8 @@ hipError_t launch_axis(const AxisLaunch &a, const float *src, ImageView sv, floa
     while (blocksY > 65535) { rows *= 2; blocksY = (a.nB + rows - 1) / rows; }
     dim3 grid(blocksX, blocksY, batch), block(kWaves * 64);
     if (kernelName) *kernelName = "aai_axis_kernel";
-    if (nt) hipLaunchKernelGGL((aai_axis_kernel<true>), grid, block, 0, stream, a, a.laneTab, a.rowTab, a.strips, src, sv, dst, dv, rows, interleave);
-    else hipLaunchKernelGGL((aai_axis_kernel<false>), grid, block, 0, stream, a, a.laneTab, a.rowTab, a.strips, src, sv, dst, dv, rows, interleave);
+    if (nt) hipLaunchKernelGGL((aai_axis_kernel<true, T>), grid, block, 0, stream, a, a.laneTab, a.rowTab, a.strips, src, sv, dst, dv, rows, interleave);
+    else hipLaunchKernelGGL((aai_axis_kernel<false, T>), grid, block, 0, stream, a, a.laneTab, a.rowTab, a.strips, src, sv, dst, dv, rows, interleave);
     return hipGetLastError();
 }
 

@@ -171,7 +171,7 @@ int get_plan(const aai_request &rq, Plan **out)
     return AAI_OK;
 }
 
-int enqueue(const aai_request &rq, int batch, const float *dSrc, int64_t srcStride, int64_t srcImageStride,
+int enqueue(const aai_request &rq, int batch, const void *dSrc, int srcType, int64_t srcStride, int64_t srcImageStride,
             float *dDst, int64_t dstStride, int64_t dstImageStride, hipStream_t stream)
 {
     std::lock_guard<std::mutex> lock(g_planMutex);
@@ -202,10 +202,10 @@ int enqueue(const aai_request &rq, int batch, const float *dSrc, int64_t srcStri
         a.outStrideA = t.flipA ? -sa : sa;
         a.outStrideB = t.flipB ? -sb : sb;
         a.outBase = (t.flipA ? (int64_t)(t.nA - 1) * sa : 0) + (t.flipB ? (int64_t)(t.nB - 1) * sb : 0);
-        e = aai::launch_axis(a, dSrc, sv, dDst, dv, batch, stream, &name);
+        e = aai::launch_axis(a, dSrc, srcType, sv, dDst, dv, batch, stream, &name);
     } else {
         const aai::RotLaunch r = aai::make_rot_launch(g, rq.mode, rq.policy);
-        e = aai::launch_rotated(r, dSrc, sv, dDst, dv, batch, p->dFlags, stream, &name);
+        e = aai::launch_rotated(r, dSrc, srcType, sv, dDst, dv, batch, p->dFlags, stream, &name);
     }
     g_lastKernel = name;
     if (e != hipSuccess) return hip_fail(e, name);
@@ -269,7 +269,7 @@ int resample_host(const aai_request *req, const T *src, int64_t srcStride, T *ds
         if (nDst) AAI_HIP_C(hipMalloc((void **)&dDstT, sizeof(T) * nDst));
     }
     if (nDst) {
-        rc = enqueue(*req, 1, dSrc, g.W, 0, dDst, g.dW, 0, stream);
+        rc = enqueue(*req, 1, dSrc, aai::SRC_F32, g.W, 0, dDst, g.dW, 0, stream);
         if (rc != AAI_OK) { cleanup(); return rc; }
         if (sizeof(T) != sizeof(float))
             AAI_HIP_C(aai::launch_f32_to_f64(dDst, reinterpret_cast<double *>(dDstT), nDst, stream));
@@ -348,12 +348,13 @@ int aai_device_synchronize(void)
     return AAI_OK;
 }
 
-int aai_resample_batch_device_f32(const aai_request *req, int32_t batch,
-                                  const float *d_src, int64_t src_stride, int64_t src_image_stride,
-                                  float *d_dst, int64_t dst_stride, int64_t dst_image_stride, void *stream)
+static int resample_batch_device_typed(const aai_request *req, int32_t batch, const void *d_src, int32_t src_dtype,
+                                       int64_t src_stride, int64_t src_image_stride,
+                                       float *d_dst, int64_t dst_stride, int64_t dst_image_stride, void *stream)
 {
     int rc = check_request(req);
     if (rc != AAI_OK) return rc;
+    if (src_dtype != AAI_DTYPE_F32 && src_dtype != AAI_DTYPE_U8 && src_dtype != AAI_DTYPE_U16) return fail(AAI_ERR_BAD_ARGUMENT, "Unknown source element type.");
     if (batch < 0 || batch > 65535) return fail(AAI_ERR_BAD_ARGUMENT, "Batch must be in [0, 65535].");
     // argument errors are reported before the device is touched, like the reference reports them first
     {
@@ -365,9 +366,23 @@ int aai_resample_batch_device_f32(const aai_request *req, int32_t batch,
     if (!d_src || !d_dst) return fail(AAI_ERR_BAD_ARGUMENT, "Null image pointer.");
     rc = require_device();
     if (rc != AAI_OK) return rc;
-    rc = enqueue(*req, batch, d_src, src_stride, src_image_stride, d_dst, dst_stride, dst_image_stride, (hipStream_t)stream);
+    rc = enqueue(*req, batch, d_src, src_dtype, src_stride, src_image_stride, d_dst, dst_stride, dst_image_stride, (hipStream_t)stream);
     if (rc == AAI_OK) g_lastError.clear();
     return rc;
+}
+
+int aai_resample_batch_device_f32(const aai_request *req, int32_t batch,
+                                  const float *d_src, int64_t src_stride, int64_t src_image_stride,
+                                  float *d_dst, int64_t dst_stride, int64_t dst_image_stride, void *stream)
+{
+    return resample_batch_device_typed(req, batch, d_src, AAI_DTYPE_F32, src_stride, src_image_stride, d_dst, dst_stride, dst_image_stride, stream);
+}
+
+int aai_resample_batch_device(const aai_request *req, int32_t batch, const void *d_src, int32_t src_dtype,
+                              int64_t src_stride, int64_t src_image_stride,
+                              float *d_dst, int64_t dst_stride, int64_t dst_image_stride, void *stream)
+{
+    return resample_batch_device_typed(req, batch, d_src, src_dtype, src_stride, src_image_stride, d_dst, dst_stride, dst_image_stride, stream);
 }
 
 int aai_resample_device_f32(const aai_request *req, const float *d_src, int64_t src_stride,
@@ -382,6 +397,48 @@ int aai_synth_device_f32(float *d_dst, int32_t width, int32_t height, int64_t st
     int rc = require_device();
     if (rc != AAI_OK) return rc;
     AAI_HIP(aai::launch_synth(d_dst, width, height, stride, seed, (hipStream_t)stream));
+    return AAI_OK;
+}
+
+int aai_resample_host(const aai_request *req, const void *src, int32_t src_dtype, int64_t src_stride,
+                      float *dst, int64_t dst_stride, aai_layout *layout)
+{
+    int rc = check_request(req);
+    if (rc != AAI_OK) return rc;
+    const size_t esz = src_dtype == AAI_DTYPE_F32 ? 4 : src_dtype == AAI_DTYPE_U8 ? 1 : src_dtype == AAI_DTYPE_U16 ? 2 : 0;
+    if (!esz) return fail(AAI_ERR_BAD_ARGUMENT, "Unknown source element type.");
+    aai::Geometry g;
+    std::string msg;
+    rc = aai::make_geometry(*req, g, msg);
+    if (rc != AAI_OK) return fail(rc, msg);
+    if (!src || !dst) return fail(AAI_ERR_BAD_ARGUMENT, "Null image pointer.");
+    if (src_stride < g.W) return fail(AAI_ERR_BAD_ARGUMENT, "Source stride smaller than the image width.");
+    if (dst_stride < g.dW) return fail(AAI_ERR_BAD_ARGUMENT, "Destination stride smaller than the output width.");
+    rc = require_device();
+    if (rc != AAI_OK) return rc;
+    void *dSrc = nullptr;
+    float *dDst = nullptr;
+    const size_t nDst = (size_t)g.dW * g.dH;
+    auto cleanup = [&]() { if (dSrc) (void)hipFree(dSrc); if (dDst) (void)hipFree(dDst); };
+#define AAI_HIP_C(call)                                                        \
+    do {                                                                       \
+        hipError_t e__ = (call);                                               \
+        if (e__ != hipSuccess) { cleanup(); return hip_fail(e__, #call); }     \
+    } while (0)
+    // +16 bytes: the last lanes of a strip may read a whole 4-column vector that ends past the final element
+    AAI_HIP_C(hipMalloc(&dSrc, esz * (size_t)g.W * g.H + 16));
+    AAI_HIP_C(hipMemcpy2D(dSrc, esz * g.W, src, esz * src_stride, esz * g.W, g.H, hipMemcpyHostToDevice));
+    if (nDst) {
+        AAI_HIP_C(hipMalloc((void **)&dDst, sizeof(float) * nDst));
+        rc = enqueue(*req, 1, dSrc, src_dtype, g.W, 0, dDst, g.dW, 0, nullptr);
+        if (rc != AAI_OK) { cleanup(); return rc; }
+        AAI_HIP_C(hipStreamSynchronize(nullptr));
+        AAI_HIP_C(hipMemcpy2D(dst, sizeof(float) * dst_stride, dDst, sizeof(float) * g.dW, sizeof(float) * g.dW, g.dH, hipMemcpyDeviceToHost));
+    }
+    cleanup();
+#undef AAI_HIP_C
+    if (layout) fill_layout(g, resolved_kernel(*req, g), layout);
+    g_lastError.clear();
     return AAI_OK;
 }
 

@@ -10,6 +10,9 @@
 namespace aai {
 
 // Image addressing shared by every kernel: element (x,y) of image b is base[b*imageStride + y*rowStride + x].
+// Source element types (AAI_DTYPE_* in include/aai.h).  Outputs are always fp32.
+enum SrcType { SRC_F32 = 0, SRC_U8 = 1, SRC_U16 = 2 };
+
 struct ImageView {
     int64_t rowStride;
     int64_t imageStride;
@@ -28,7 +31,7 @@ struct AxisLaunch {
     int rowsShared;             // consecutive output rows share a source row
     int maxOutputsPerStrip;
 };
-hipError_t launch_axis(const AxisLaunch &a, const float *src, ImageView sv, float *dst, ImageView dv,
+hipError_t launch_axis(const AxisLaunch &a, const void *src, int srcType, ImageView sv, float *dst, ImageView dv,
                        int batch, hipStream_t stream, const char **kernelName);
 
 // ---- K2/K3/K4/K5: per-output-pixel kernels on the rotated lattice --------------------------------------
@@ -36,7 +39,7 @@ hipError_t launch_axis(const AxisLaunch &a, const float *src, ImageView sv, floa
 // them and counts the flagged waves in counter[0]; launch_rotated runs the fix-up pass iff waveFlags != NULL.
 size_t rotated_flag_words(const RotLaunch &r);
 hipError_t launch_knife_scan(const RotLaunch &r, unsigned *waveFlags, unsigned *counter, hipStream_t stream);
-hipError_t launch_rotated(const RotLaunch &r, const float *src, ImageView sv, float *dst, ImageView dv,
+hipError_t launch_rotated(const RotLaunch &r, const void *src, int srcType, ImageView sv, float *dst, ImageView dv,
                           int batch, const unsigned *waveFlags, hipStream_t stream, const char **kernelName);
 
 // ---- utilities -----------------------------------------------------------------------------------------

@@ -56,11 +56,12 @@ __global__ __launch_bounds__(kRotBlock) void aai_knife_scan_kernel(RotLaunch r, 
 }
 
 // ---- K4/K5 -------------------------------------------------------------------------------------------
-__device__ __forceinline__ float tap(const float *img, int64_t rowStride, int W, int H, int x, int y)
+template <typename T>
+__device__ __forceinline__ float tap(const T *img, int64_t rowStride, int W, int H, int x, int y)
 {
     x = min(max(x, 0), W - 1);
     y = min(max(y, 0), H - 1);
-    return img[(int64_t)y * rowStride + x];
+    return (float)img[(int64_t)y * rowStride + x];
 }
 
 __device__ __forceinline__ void keys(float t, float w[4])
@@ -72,14 +73,14 @@ __device__ __forceinline__ void keys(float t, float w[4])
     w[3] = a * (t2 - t3);
 }
 
-template <int MODE>
-__global__ __launch_bounds__(kBlock) void aai_sample_kernel(RotLaunch r, const float *__restrict__ src, ImageView sv,
+template <int MODE, typename T>
+__global__ __launch_bounds__(kBlock) void aai_sample_kernel(RotLaunch r, const T *__restrict__ src, ImageView sv,
                                                              float *__restrict__ dst, ImageView dv)
 {
     const int dx = blockIdx.x * 64 + (threadIdx.x & 63);
     const int dy = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (dx >= r.dW || dy >= r.dH) return;
-    const float *img = src + (int64_t)blockIdx.z * sv.imageStride;
+    const T *img = src + (int64_t)blockIdx.z * sv.imageStride;
     double X, Y;
     pixel_centre(r, dx, dy, X, Y);
     // continuous virtual coordinates -> continuous original-image coordinates (pixel centres at integers)
@@ -135,18 +136,19 @@ hipError_t launch_knife_scan(const RotLaunch &r, unsigned *waveFlags, unsigned *
     return hipGetLastError();
 }
 
-hipError_t launch_rotated(const RotLaunch &r, const float *src, ImageView sv, float *dst, ImageView dv,
-                          int batch, const unsigned *waveFlags, hipStream_t stream, const char **kernelName)
+template <typename T>
+static hipError_t launch_rotated_typed(const RotLaunch &r, const T *src, int srcType, ImageView sv, float *dst, ImageView dv,
+                                       int batch, const unsigned *waveFlags, hipStream_t stream, const char **kernelName)
 {
     if (r.dW <= 0 || r.dH <= 0 || batch <= 0) return hipSuccess;
     if (r.mode == AAI_MODE_BILINEAR || r.mode == AAI_MODE_BICUBIC) {
         dim3 grid((r.dW + 63) / 64, (r.dH + 3) / 4, batch);
         if (r.mode == AAI_MODE_BILINEAR) {
             if (kernelName) *kernelName = "aai_sample_kernel<bilinear>";
-            hipLaunchKernelGGL(aai_sample_kernel<AAI_MODE_BILINEAR>, grid, dim3(kBlock), 0, stream, r, src, sv, dst, dv);
+            hipLaunchKernelGGL((aai_sample_kernel<AAI_MODE_BILINEAR, T>), grid, dim3(kBlock), 0, stream, r, src, sv, dst, dv);
         } else {
             if (kernelName) *kernelName = "aai_sample_kernel<bicubic>";
-            hipLaunchKernelGGL(aai_sample_kernel<AAI_MODE_BICUBIC>, grid, dim3(kBlock), 0, stream, r, src, sv, dst, dv);
+            hipLaunchKernelGGL((aai_sample_kernel<AAI_MODE_BICUBIC, T>), grid, dim3(kBlock), 0, stream, r, src, sv, dst, dv);
         }
         return hipGetLastError();
     }
@@ -155,15 +157,25 @@ hipError_t launch_rotated(const RotLaunch &r, const float *src, ImageView sv, fl
     // pass over the same grid
     if (r.mode == AAI_MODE_FAST) {
         if (kernelName) *kernelName = "aai_rotated_kernel<fast>";
-        hipLaunchKernelGGL((aai_rotated_kernel<AAI_MODE_FAST, false>), grid, dim3(kRotBlock), 0, stream, r, src, sv, dst, dv, waveFlags);
+        hipLaunchKernelGGL((aai_rotated_kernel<AAI_MODE_FAST, false, T>), grid, dim3(kRotBlock), 0, stream, r, src, sv, dst, dv, waveFlags);
     } else {
         if (kernelName) *kernelName = "aai_rotated_kernel<area>";
-        hipLaunchKernelGGL((aai_rotated_kernel<AAI_MODE_AREA, false>), grid, dim3(kRotBlock), 0, stream, r, src, sv, dst, dv, waveFlags);
+        hipLaunchKernelGGL((aai_rotated_kernel<AAI_MODE_AREA, false, T>), grid, dim3(kRotBlock), 0, stream, r, src, sv, dst, dv, waveFlags);
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
-    if (waveFlags) launch_rotated_fixup(r, grid, src, sv, dst, dv, waveFlags, stream);
+    if (waveFlags) launch_rotated_fixup(r, grid, src, srcType, sv, dst, dv, waveFlags, stream);
     return hipGetLastError();
+}
+
+hipError_t launch_rotated(const RotLaunch &r, const void *src, int srcType, ImageView sv, float *dst, ImageView dv,
+                          int batch, const unsigned *waveFlags, hipStream_t stream, const char **kernelName)
+{
+    switch (srcType) {
+    case SRC_U8: return launch_rotated_typed(r, static_cast<const unsigned char *>(src), srcType, sv, dst, dv, batch, waveFlags, stream, kernelName);
+    case SRC_U16: return launch_rotated_typed(r, static_cast<const unsigned short *>(src), srcType, sv, dst, dv, batch, waveFlags, stream, kernelName);
+    default: return launch_rotated_typed(r, static_cast<const float *>(src), srcType, sv, dst, dv, batch, waveFlags, stream, kernelName);
+    }
 }
 
 }  // namespace aai

@@ -19,8 +19,8 @@ constexpr int kRotBlock = 256;     // 16 x 16 dst pixels; a wave covers 16 x 4
 //   once; flagged waves recompute their 64 pixels, replaying the reference's own arithmetic
 //   (aai_strict.hpp) for the knife-edge
 //   pairs.  In generic geometry -- every BASELINE configuration -- no flag is ever raised.
-template <int MODE, bool STRICT>
-__global__ __launch_bounds__(kRotBlock) void aai_rotated_kernel(RotLaunch r, const float *__restrict__ src, ImageView sv,
+template <int MODE, bool STRICT, typename T>
+__global__ __launch_bounds__(kRotBlock) void aai_rotated_kernel(RotLaunch r, const T *__restrict__ src, ImageView sv,
                                                               float *__restrict__ dst, ImageView dv,
                                                               const unsigned *__restrict__ waveFlags)
 {
@@ -34,7 +34,7 @@ __global__ __launch_bounds__(kRotBlock) void aai_rotated_kernel(RotLaunch r, con
     const int dx = blockIdx.x * 16 + (tid & 15);
     const int dy = blockIdx.y * 16 + (tid >> 4);
     const bool valid = dx < r.dW && dy < r.dH;
-    const float *img = src + (int64_t)blockIdx.z * sv.imageStride;
+    const T *img = src + (int64_t)blockIdx.z * sv.imageStride;
 
     // (Staging the tile's source footprint in LDS with coalesced loads was measured and rejected: cfg3 1452 ->
     // 1744 us, cfg3 fast 435 -> 560 us, cfg5 17.3 -> 21.4 ms.  The per-lane 4-byte loads hit L1/L2 and are not the
@@ -160,7 +160,7 @@ __global__ __launch_bounds__(kRotBlock) void aai_rotated_kernel(RotLaunch r, con
 }
 
 // launches the fix-up pass (defined in aai_rotated_strict.hip)
-void launch_rotated_fixup(const RotLaunch &r, dim3 grid, const float *src, ImageView sv, float *dst, ImageView dv,
+void launch_rotated_fixup(const RotLaunch &r, dim3 grid, const void *src, int srcType, ImageView sv, float *dst, ImageView dv,
                           const unsigned *waveFlags, hipStream_t stream);
 
 }  // namespace aai

@@ -128,6 +128,8 @@ def main():
     ap.add_argument("--batch", type=int, default=4, help="images per GPU per step")
     ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
     ap.add_argument("--policy", default="reference", choices=["reference", "exact"])
+    ap.add_argument("--src-dtype", default="f32", choices=["f32", "u8", "u16"],
+                    help="source element type (the headline metric is f32; u8/u16 exercise the typed entry points)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend; nccl (= RCCL) is the real one, gloo lets two ranks rehearse on one GPU")
@@ -170,10 +172,15 @@ def main():
     stream = torch.cuda.current_stream().cuda_stream
     for b in range(B):
         aai.synth_device(src[b].data_ptr(), W, H, W, first + b + 1, stream)       # image g uses seed g+1
+    esz, dcode = {"f32": (4, aai.DTYPE_F32), "u8": (1, aai.DTYPE_U8), "u16": (2, aai.DTYPE_U16)}[args.src_dtype]
+    if args.src_dtype == "u8":
+        src = (src * 256.0).to(torch.uint8)
+    elif args.src_dtype == "u16":
+        src = (src * 65536.0).to(torch.int32).to(torch.int16)                       # bit pattern of the uint16 value
 
     def step():
         aai.resample_device(rq, src.data_ptr(), W, dst.data_ptr(), dW, stream, batch=B,
-                            src_image_stride=W * H, dst_image_stride=dW * dH)
+                            src_image_stride=W * H, dst_image_stride=dW * dH, src_dtype=dcode)
 
     def fence():
         torch.cuda.synchronize()
@@ -212,12 +219,12 @@ def main():
 
     if rank == 0:
         out_pix = total_images * dW * dH * args.steps
-        alg_bytes = B * (4 * W * H + 4 * dW * dH)                             # per launch, per GPU
+        alg_bytes = B * (esz * W * H + 4 * dW * dH)                           # per launch, per GPU
         achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
         traffic = None                                                        # measured HBM bytes per launch (rocprofv3 PMC)
         try:
             pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json"))).get(args.workload)
-            if pmc and pmc["batch"] == B:
+            if pmc and pmc["batch"] == B and args.src_dtype == "f32":
                 traffic = pmc["bytes_per_launch"]
         except Exception:
             pass
@@ -228,14 +235,14 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            "dtype": "f32", "data": "synthetic" if args.src_dtype == "f32" else "synthetic (%s source)" % args.src_dtype,
             "config": {"workload": "%s: %s, area-average, %s weight policy, isocenter = image centre" % (args.workload, desc, args.policy)
                        if mode == aai.MODE_AREA else "%s: %s" % (args.workload, desc),
-                       "images_per_gpu_per_step": B, "src_bytes_per_gpu": 4 * W * H * B, "parallelism": "batch-sharded x%d" % world},
+                       "images_per_gpu_per_step": B, "src_bytes_per_gpu": esz * W * H * B, "parallelism": "batch-sharded x%d" % world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                          "kernel": kernel_name, "kernel_ms_per_launch": kernel_ms, "algorithmic_bytes_per_launch": alg_bytes},
-            "src_gbps_input_rate": 4 * W * H * B / (kernel_ms * 1e-3) / 1e9,
+            "src_gbps_input_rate": esz * W * H * B / (kernel_ms * 1e-3) / 1e9,
         }
         if gather_ms is not None:
             line["gather_ms"] = gather_ms

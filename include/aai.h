@@ -63,6 +63,10 @@ enum {
                                  that are not multiples of 90 degrees) */
 };
 
+/* Source element types of the typed entry points (real images are rarely double).
+ * Pixel values are used as they are (0..255, 0..65535); the output is always fp32. */
+enum { AAI_DTYPE_F32 = 0, AAI_DTYPE_U8 = 1, AAI_DTYPE_U16 = 2 };
+
 /* One resampling request = the by-value arguments of Source.cpp:55-57 plus the engine's mode switches. */
 typedef struct aai_request {
     int32_t mode;            /* AAI_MODE_*    */
@@ -138,6 +142,16 @@ int aai_resample_batch_device_f32(const aai_request *req, int32_t batch,
                                   const float *d_src, int64_t src_stride, int64_t src_image_stride,
                                   float *d_dst, int64_t dst_stride, int64_t dst_image_stride,
                                   void *stream);
+
+/* ---- typed sources (8-bit / 16-bit unsigned, or fp32): SURVEY.md section 8(f) N3 ----------------------------
+ * Same semantics as the f32 entries above with `src` holding elements of `src_dtype` (AAI_DTYPE_*); strides are
+ * in source ELEMENTS.  The reference only accepts doubles (Source.cpp:31); callers holding 8/16-bit images would
+ * otherwise widen them on the host and move 4-8x the bytes over PCIe and HBM. */
+int aai_resample_batch_device(const aai_request *req, int32_t batch, const void *d_src, int32_t src_dtype,
+                              int64_t src_stride, int64_t src_image_stride,
+                              float *d_dst, int64_t dst_stride, int64_t dst_image_stride, void *stream);
+int aai_resample_host(const aai_request *req, const void *src, int32_t src_dtype, int64_t src_stride,
+                      float *dst, int64_t dst_stride, aai_layout *layout);
 
 /* ---- synthetic input ------------------------------------------------------------
  * Fill a device image with the stateless-hash fp32 uniform [0,1) pattern used by every benchmark and

@@ -157,6 +157,39 @@ def test_near_axis_rotations_against_oracle(gpu, po):
                 assert np.array_equal(gold == 0, dst == 0), (ang, sr, dr, mode)
 
 
+def test_typed_sources_u8_u16_against_oracle(gpu, po):
+    """8-bit and 16-bit unsigned sources through aai_resample_host /
+    aai_resample_batch_device; pixel values are used as they are, output fp32."""
+    import torch
+    from area_average_interpolation_amd import _lib as L
+    rng = np.random.default_rng(23)
+    geoms = [(257, 130, 4, 1, 0.0, 1), (300, 64, 2, 1, 0.0, 1), (131, 97, 3, 1, 90.0, 1), (90, 70, 3, 1, 17.5, 1),
+             (90, 70, 3, 1, 17.5, 2), (40, 30, 1, 2, 45.0, 1), (3000, 650, 600, 1, 0.0, 1), (64, 64, 4, 1, 180.0, 2)]
+    for (W, H, sr, dr, ang, mode) in geoms:
+        iso = ((W - 1) / 2, (H - 1) / 2)
+        for npdt, code, hi in ((np.uint8, L.DTYPE_U8, 256), (np.uint16, L.DTYPE_U16, 65536)):
+            src = rng.integers(0, hi, size=(H, W)).astype(npdt)
+            gold = po.oracle_run(po.MODE_EXACT if mode == 1 else po.MODE_FAST, src.astype(np.float64), sr, dr, iso, ang).dst
+            dst, giso, lay = _host(gpu, src, dict(src_res=float(sr), dst_res=float(dr), iso=iso, angle=float(ang)), mode)
+            assert dst.dtype == np.float32 and dst.shape == gold.shape
+            assert (np.abs(dst - gold) / np.maximum(np.abs(gold), 1e-3 * hi)).max() <= TOL, (W, H, sr, dr, ang, mode, npdt)
+            assert np.array_equal(gold == 0, dst == 0)
+            # device-resident typed batch of two images, with a padded source stride
+            pad = 5
+            t = torch.zeros((2, H, W + pad), dtype=torch.uint8 if npdt == np.uint8 else torch.int16, device="cuda")
+            view = src if npdt == np.uint8 else src.view(np.int16)
+            t[0, :, :W] = torch.from_numpy(view.copy()).cuda()
+            t[1, :, :W] = torch.from_numpy(view[::-1].copy()).cuda()
+            out = torch.empty((2, lay.dst_height, lay.dst_width), dtype=torch.float32, device="cuda")
+            rq = gpu.make_request(W, H, sr, dr, iso, ang, mode=mode)
+            gpu.resample_device(rq, t.data_ptr(), W + pad, out.data_ptr(), lay.dst_width, torch.cuda.current_stream().cuda_stream,
+                                batch=2, src_image_stride=H * (W + pad), dst_image_stride=lay.dst_width * lay.dst_height, src_dtype=code)
+            torch.cuda.synchronize()
+            assert np.array_equal(out[0].cpu().numpy(), dst)
+            gold2 = po.oracle_run(po.MODE_EXACT if mode == 1 else po.MODE_FAST, src[::-1].astype(np.float64), sr, dr, iso, ang).dst
+            assert (np.abs(out[1].cpu().numpy() - gold2) / np.maximum(np.abs(gold2), 1e-3 * hi)).max() <= TOL
+
+
 def test_exact_policy_against_oracle(gpu, po):
     rng = np.random.default_rng(12)
     from area_average_interpolation_amd import _lib as L
