@@ -137,6 +137,23 @@ def resample_device(request, src_ptr, src_stride, dst_ptr, dst_stride, stream=0,
         raise AaiError(rc, last_error())
 
 
+def band_source_rows(request, dst_row0, dst_row1):
+    """aai_band_source_rows: source rows [a, b) that dst rows [dst_row0, dst_row1) read.  Needs no GPU."""
+    a, b = ctypes.c_int32(), ctypes.c_int32()
+    rc = L.load().aai_band_source_rows(ctypes.byref(request), int(dst_row0), int(dst_row1), ctypes.byref(a), ctypes.byref(b))
+    if rc != L.OK:
+        raise AaiError(rc, last_error())
+    return a.value, b.value
+
+
+def resample_band_device(request, dst_row0, dst_row1, src_rows_ptr, src_stride, dst_rows_ptr, dst_stride, stream=0):
+    """aai_resample_band_device_f32: src_rows_ptr addresses source row band_source_rows(...)[0], dst_rows_ptr output row dst_row0."""
+    rc = L.load().aai_resample_band_device_f32(ctypes.byref(request), int(dst_row0), int(dst_row1), src_rows_ptr, src_stride,
+                                               dst_rows_ptr, dst_stride, stream)
+    if rc != L.OK:
+        raise AaiError(rc, last_error())
+
+
 def synth_device(dst_ptr, width, height, stride, seed, stream=0):
     rc = L.load().aai_synth_device_f32(dst_ptr, int(width), int(height), int(stride), int(seed), stream)
     if rc != L.OK:

@@ -44,6 +44,8 @@ int hip_fail(hipError_t e, const char *what)
 // ---- plan cache ------------------------------------------------------------------------------------
 struct Plan {
     aai_request key{};
+    int band0 = -1, band1 = -1;      // dst row band this plan serves (-1: the whole image)
+    int srcRow0 = 0, srcRow1 = 0;     // source rows the band reads; the source pointer addresses row srcRow0
     int device = -1;
     aai::Geometry g;
     int kernel = 0;
@@ -114,12 +116,12 @@ void fill_layout(const aai::Geometry &g, int kernel, aai_layout *out)
 
 // Finds or builds the plan for (request, current device).  Returns a pointer valid until evicted; callers
 // hold g_planMutex for the duration of the launch (launches only enqueue, so this is short).
-int get_plan(const aai_request &rq, Plan **out)
+int get_plan(const aai_request &rq, int band0, int band1, Plan **out)
 {
     int dev = -1;
     AAI_HIP(hipGetDevice(&dev));
     for (auto it = g_plans.begin(); it != g_plans.end(); ++it) {
-        if (it->device == dev && same_request(it->key, rq)) {
+        if (it->device == dev && it->band0 == band0 && it->band1 == band1 && same_request(it->key, rq)) {
             g_plans.splice(g_plans.begin(), g_plans, it);
             *out = &g_plans.front();
             return AAI_OK;
@@ -132,9 +134,11 @@ int get_plan(const aai_request &rq, Plan **out)
 
     g_plans.emplace_front();
     Plan &p = g_plans.front();
-    p.key = rq; p.device = dev; p.g = g; p.kernel = pick_kernel(rq, g);
+    p.key = rq; p.band0 = band0; p.band1 = band1; p.device = dev; p.g = g; p.kernel = pick_kernel(rq, g);
+    p.srcRow0 = 0; p.srcRow1 = g.H;
     if (p.kernel == AAI_KERNEL_AXIS) {
         aai::build_axis_tables(g, rq.mode, p.tabs);
+        if (band0 >= 0) aai::restrict_axis_tables_to_band(g, p.tabs, band0, band1, p.srcRow0, p.srcRow1);
         if (p.tabs.wide) p.kernel = AAI_KERNEL_AXIS_WIDE;
         auto upload = [&](const void *h, size_t bytes, void **d) -> hipError_t {
             if (!bytes) { *d = nullptr; return hipSuccess; }
@@ -147,6 +151,8 @@ int get_plan(const aai_request &rq, Plan **out)
         if (e == hipSuccess) e = upload(p.tabs.strips.data(), p.tabs.strips.size() * sizeof(aai::AxisStrip), (void **)&p.dStrips);
         if (e != hipSuccess) { g_plans.pop_front(); return hip_fail(e, "uploading axis tables"); }
     }
+    if (band0 >= 0 && p.kernel != AAI_KERNEL_AXIS && p.kernel != AAI_KERNEL_AXIS_WIDE)
+        aai::rotated_band_source_rows(g, band0, band1, p.kernel == AAI_KERNEL_SAMPLE, p.srcRow0, p.srcRow1);
     if (p.kernel == AAI_KERNEL_ROTATED || p.kernel == AAI_KERNEL_FAST) {
         // one-off knife-edge scan of this geometry (see aai_knife_scan_kernel); keeps the flags only if any
         const aai::RotLaunch r = aai::make_rot_launch(g, rq.mode, rq.policy);
@@ -172,11 +178,11 @@ int get_plan(const aai_request &rq, Plan **out)
 }
 
 int enqueue(const aai_request &rq, int batch, const void *dSrc, int srcType, int64_t srcStride, int64_t srcImageStride,
-            float *dDst, int64_t dstStride, int64_t dstImageStride, hipStream_t stream)
+            float *dDst, int64_t dstStride, int64_t dstImageStride, hipStream_t stream, int band0 = -1, int band1 = -1)
 {
     std::lock_guard<std::mutex> lock(g_planMutex);
     Plan *p = nullptr;
-    int rc = get_plan(rq, &p);
+    int rc = get_plan(rq, band0, band1, &p);
     if (rc != AAI_OK) return rc;
     const aai::Geometry &g = p->g;
     if (srcStride < g.W) return fail(AAI_ERR_BAD_ARGUMENT, "Source stride smaller than the image width.");
@@ -204,7 +210,8 @@ int enqueue(const aai_request &rq, int batch, const void *dSrc, int srcType, int
         a.outBase = (t.flipA ? (int64_t)(t.nA - 1) * sa : 0) + (t.flipB ? (int64_t)(t.nB - 1) * sb : 0);
         e = aai::launch_axis(a, dSrc, srcType, sv, dDst, dv, batch, stream, &name);
     } else {
-        const aai::RotLaunch r = aai::make_rot_launch(g, rq.mode, rq.policy);
+        aai::RotLaunch r = aai::make_rot_launch(g, rq.mode, rq.policy);
+        if (band0 >= 0) { r.dyBase = band0; r.dyEnd = band1; r.srcRow0 = p->srcRow0; }
         e = aai::launch_rotated(r, dSrc, srcType, sv, dDst, dv, batch, p->dFlags, stream, &name);
     }
     g_lastKernel = name;
@@ -389,6 +396,45 @@ int aai_resample_device_f32(const aai_request *req, const float *d_src, int64_t 
                             float *d_dst, int64_t dst_stride, void *stream)
 {
     return aai_resample_batch_device_f32(req, 1, d_src, src_stride, 0, d_dst, dst_stride, 0, stream);
+}
+
+int aai_band_source_rows(const aai_request *req, int32_t dst_row0, int32_t dst_row1, int32_t *src_row0, int32_t *src_row1)
+{
+    int rc = check_request(req);
+    if (rc != AAI_OK) return rc;
+    if (!src_row0 || !src_row1) return fail(AAI_ERR_BAD_ARGUMENT, "Null output pointer.");
+    aai::Geometry g;
+    std::string msg;
+    rc = aai::make_geometry(*req, g, msg);
+    if (rc != AAI_OK) return fail(rc, msg);
+    if (dst_row0 < 0 || dst_row1 > g.dH || dst_row0 >= dst_row1) return fail(AAI_ERR_BAD_ARGUMENT, "Band rows out of range.");
+    const int kernel = pick_kernel(*req, g);
+    int a = 0, b = g.H;
+    if (kernel == AAI_KERNEL_AXIS) {
+        aai::AxisTables t;
+        aai::build_axis_tables(g, req->mode, t);
+        aai::restrict_axis_tables_to_band(g, t, dst_row0, dst_row1, a, b);
+    } else {
+        if (dst_row0 % 16 != 0) return fail(AAI_ERR_BAD_ARGUMENT, "Band start must be a multiple of 16 rows for rotated requests.");
+        aai::rotated_band_source_rows(g, dst_row0, dst_row1, kernel == AAI_KERNEL_SAMPLE, a, b);
+    }
+    *src_row0 = a; *src_row1 = b;
+    g_lastError.clear();
+    return AAI_OK;
+}
+
+int aai_resample_band_device_f32(const aai_request *req, int32_t dst_row0, int32_t dst_row1,
+                                 const float *d_src_rows, int64_t src_stride, float *d_dst_rows, int64_t dst_stride, void *stream)
+{
+    int32_t a, b;
+    int rc = aai_band_source_rows(req, dst_row0, dst_row1, &a, &b);      // validates request and band
+    if (rc != AAI_OK) return rc;
+    if (!d_src_rows || !d_dst_rows) return fail(AAI_ERR_BAD_ARGUMENT, "Null image pointer.");
+    rc = require_device();
+    if (rc != AAI_OK) return rc;
+    rc = enqueue(*req, 1, d_src_rows, aai::SRC_F32, src_stride, 0, d_dst_rows, dst_stride, 0, (hipStream_t)stream, dst_row0, dst_row1);
+    if (rc == AAI_OK) g_lastError.clear();
+    return rc;
 }
 
 int aai_synth_device_f32(float *d_dst, int32_t width, int32_t height, int64_t stride, uint64_t seed, void *stream)

@@ -124,6 +124,7 @@ RotLaunch make_rot_launch(const Geometry &g, int mode, int policy)
     r.reach = g.side * std::sqrt(2.0) / 2 + 1;
     r.dW = g.dW; r.dH = g.dH; r.mW = g.mW; r.mH = g.mH; r.W = g.W; r.H = g.H;
     r.scale = g.scale; r.quadrant = g.quadrant; r.mode = mode; r.policy = policy;
+    r.dyBase = 0; r.dyEnd = g.dH; r.srcRow0 = 0;
     r.invScale = 1.0 / g.scale;
     const double c = g.cs, s = g.sn, h = 0.5 * g.side;
     r.c = c; r.s = s; r.h = h;
@@ -140,6 +141,31 @@ RotLaunch make_rot_launch(const Geometry &g, int mode, int policy)
     r.rc = 1.0 / c; r.rs = 1.0 / s; r.rhi = 1.0 / r.hi; r.r2cs = 1.0 / (2.0 * c * s);
     r.lt45 = g.lt45 ? 1 : 0; r.tsn = g.tsn; r.tcs = g.tcs; r.ttn = g.ttn;
     return r;
+}
+
+void rotated_band_source_rows(const Geometry &g, int row0, int row1, bool sampler, int &srcRow0, int &srcRow1)
+{
+    // virtual-lattice bounding box of the band: centres are affine in (dx,dy), so its four corner pixels bound it
+    // area / fast kernels reach half a rotated dst pixel (+1); the samplers' taps reach 2 original pixels
+    const double hb = 0.5 * g.side * (std::fabs(g.cs) + std::fabs(g.sn)) + 1.0 + (sampler ? 3.0 * g.scale : 0.0);
+    double minX = 1e300, maxX = -1e300, minY = 1e300, maxY = -1e300;
+    for (int c = 0; c < 4; ++c) {
+        double px, py;
+        dst_centre(g, (c & 1) ? g.dW - 1 : 0, (c & 2) ? row1 - 1 : row0, px, py);
+        minX = std::min(minX, px); maxX = std::max(maxX, px); minY = std::min(minY, py); maxY = std::max(maxY, py);
+    }
+    auto clampi = [](double v, int lo, int hi) { return (int)std::min((double)hi, std::max((double)lo, v)); };
+    const int X0 = clampi(std::floor(minX - hb), 0, g.mW - 1), X1 = clampi(std::ceil(maxX + hb), 0, g.mW - 1);
+    const int Y0 = clampi(std::floor(minY - hb), 0, g.mH - 1), Y1 = clampi(std::ceil(maxY + hb), 0, g.mH - 1);
+    int a, b;      // source rows of the virtual box (Source.cpp:164-167)
+    switch (g.quadrant) {
+    default:
+    case 0: a = Y0 / g.scale; b = Y1 / g.scale; break;
+    case 1: a = (g.mW - 1 - X1) / g.scale; b = (g.mW - 1 - X0) / g.scale; break;
+    case 2: a = (g.mH - 1 - Y1) / g.scale; b = (g.mH - 1 - Y0) / g.scale; break;
+    case 3: a = X0 / g.scale; b = X1 / g.scale; break;
+    }
+    srcRow0 = std::max(0, std::min(a, b)); srcRow1 = std::min(g.H, std::max(a, b) + 1);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -242,42 +268,10 @@ AxisEntry fold(const VirtRange &vr, int m, int scale, bool reversed, double othe
 
 }  // namespace
 
-void build_axis_tables(const Geometry &g, int mode, AxisTables &t)
+// Derived data of a (possibly band-restricted) pair of tables: parked empties, row statistics, strips.
+static void finalize_axis_tables(const Geometry &g, AxisTables &t)
 {
-    // Which virtual axis reads which source axis (SURVEY.md A.2, Source.cpp:164-167):
-    //   q0: X -> src x (+), Y -> src y (+)      q1: X -> src y (-), Y -> src x (+)
-    //   q2: X -> src x (-), Y -> src y (-)      q3: X -> src y (+), Y -> src x (-)
-    const bool transposed = (g.quadrant & 1) != 0;
-    const bool revX = (g.quadrant == 1 || g.quadrant == 2);
-    const bool revY = (g.quadrant == 2 || g.quadrant == 3);
-
-    std::vector<AxisEntry> alongX(g.dW), alongY(g.dH);
-    double lo = edge_along_x(g, 0);
-    for (int k = 0; k < g.dW; ++k) {
-        const double hi = edge_along_x(g, k + 1);
-        const VirtRange vr = (mode == AAI_MODE_FAST) ? fast_range(lo, hi, g.mW) : area_range(lo, hi, g.mW);
-        alongX[k] = fold(vr, g.mW, g.scale, revX, g.side);
-        lo = hi;
-    }
-    lo = edge_along_y(g, 0);
-    for (int k = 0; k < g.dH; ++k) {
-        const double hi = edge_along_y(g, k + 1);
-        const VirtRange vr = (mode == AAI_MODE_FAST) ? fast_range(lo, hi, g.mH) : area_range(lo, hi, g.mH);
-        alongY[k] = fold(vr, g.mH, g.scale, revY, g.side);
-        lo = hi;
-    }
-
-    // Lane axis = the virtual axis that reads source x; put both tables in ascending source order.
-    std::vector<AxisEntry> &laneSrc = transposed ? alongY : alongX;
-    std::vector<AxisEntry> &rowSrc = transposed ? alongX : alongY;
-    t.transposed = transposed;
-    t.flipA = transposed ? revY : revX;     // lane-axis output index runs against source x
-    t.flipB = transposed ? revX : revY;
-    t.lane = laneSrc; t.row = rowSrc;
-    if (t.flipA) std::reverse(t.lane.begin(), t.lane.end());
-    if (t.flipB) std::reverse(t.row.begin(), t.row.end());
     t.nA = (int)t.lane.size(); t.nB = (int)t.row.size();
-
     // Empty entries (dst pixels off the image) carry s0 = s1 = 0; park them on a neighbour's window so
     // that strips stay compact.
     int lastS = 0;
@@ -321,6 +315,66 @@ void build_axis_tables(const Geometry &g, int mode, AxisTables &t)
         t.strips.push_back(s);
         k = kk;
     }
+}
+
+void build_axis_tables(const Geometry &g, int mode, AxisTables &t)
+{
+    // Which virtual axis reads which source axis (SURVEY.md A.2, Source.cpp:164-167):
+    //   q0: X -> src x (+), Y -> src y (+)      q1: X -> src y (-), Y -> src x (+)
+    //   q2: X -> src x (-), Y -> src y (-)      q3: X -> src y (+), Y -> src x (-)
+    const bool transposed = (g.quadrant & 1) != 0;
+    const bool revX = (g.quadrant == 1 || g.quadrant == 2);
+    const bool revY = (g.quadrant == 2 || g.quadrant == 3);
+
+    std::vector<AxisEntry> alongX(g.dW), alongY(g.dH);
+    double lo = edge_along_x(g, 0);
+    for (int k = 0; k < g.dW; ++k) {
+        const double hi = edge_along_x(g, k + 1);
+        const VirtRange vr = (mode == AAI_MODE_FAST) ? fast_range(lo, hi, g.mW) : area_range(lo, hi, g.mW);
+        alongX[k] = fold(vr, g.mW, g.scale, revX, g.side);
+        lo = hi;
+    }
+    lo = edge_along_y(g, 0);
+    for (int k = 0; k < g.dH; ++k) {
+        const double hi = edge_along_y(g, k + 1);
+        const VirtRange vr = (mode == AAI_MODE_FAST) ? fast_range(lo, hi, g.mH) : area_range(lo, hi, g.mH);
+        alongY[k] = fold(vr, g.mH, g.scale, revY, g.side);
+        lo = hi;
+    }
+
+    // Lane axis = the virtual axis that reads source x; put both tables in ascending source order.
+    std::vector<AxisEntry> &laneSrc = transposed ? alongY : alongX;
+    std::vector<AxisEntry> &rowSrc = transposed ? alongX : alongY;
+    t.transposed = transposed;
+    t.flipA = transposed ? revY : revX;     // lane-axis output index runs against source x
+    t.flipB = transposed ? revX : revY;
+    t.lane = laneSrc; t.row = rowSrc;
+    if (t.flipA) std::reverse(t.lane.begin(), t.lane.end());
+    if (t.flipB) std::reverse(t.row.begin(), t.row.end());
+    t.nA = (int)t.lane.size(); t.nB = (int)t.row.size();
+
+    finalize_axis_tables(g, t);
+}
+
+// Keep only the dst rows [row0,row1) (row bands of one image on different GPUs, or an
+// image larger than device memory).  dst rows run along the row table (quadrants 0, 2) or along the lane table
+// (quadrants 1, 3); the other table is kept whole.  Source rows are re-based to srcRow0 = the first source row any
+// remaining window touches, which is returned together with the row after the last one.
+void restrict_axis_tables_to_band(const Geometry &g, AxisTables &t, int row0, int row1, int &srcRow0, int &srcRow1)
+{
+    std::vector<AxisEntry> &rowsOfDst = t.transposed ? t.lane : t.row;     // table indexed by (possibly flipped) dst row
+    const bool flip = t.transposed ? t.flipA : t.flipB;
+    const int n = (int)rowsOfDst.size();
+    const int k0 = flip ? n - row1 : row0, k1 = flip ? n - row0 : row1;
+    rowsOfDst = std::vector<AxisEntry>(rowsOfDst.begin() + k0, rowsOfDst.begin() + k1);
+    // source rows touched: the row table indexes source y in both layouts
+    int lo = g.H, hi = -1;
+    for (const auto &e : t.row)
+        if (e.wFirst != 0.f || e.wMid != 0.f || e.wLast != 0.f) { lo = std::min(lo, e.s0); hi = std::max(hi, e.s1); }
+    if (hi < lo) { lo = 0; hi = 0; }
+    for (auto &e : t.row) { e.s0 = std::max(e.s0, lo) - lo; e.s1 = std::max(e.s1, lo) - lo; }
+    srcRow0 = lo; srcRow1 = hi + 1;
+    finalize_axis_tables(g, t);
 }
 
 }  // namespace aai

@@ -31,6 +31,8 @@ struct RotLaunch {
     double reach;        // side*sqrt(2)/2 + 1, the reference's search-window half width (Source.cpp:426-429)
     int dW, dH, mW, mH, W, H, scale, quadrant;
     int mode, policy;
+    int dyBase, dyEnd;   // dst rows [dyBase, dyEnd) are computed (a band; the whole image by default); dyBase % 16 == 0
+    int srcRow0;         // the source pointer addresses source row srcRow0 (band buffers hold only the rows needed)
     double invScale;     // 1/scale: virtual index -> original index is (int)((X + 0.5) * invScale), exact
     // the dst square in the reduced frame: c = cos, s = sin of the reduced angle (both > 0), h = L/2
     double c, s, h;
@@ -283,7 +285,7 @@ AAI_HD int64_t virt_offset(const RotLaunch &r, int X, int Y, int64_t rowStride)
         sx = (int)((sx + 0.5) * r.invScale);
         sy = (int)((sy + 0.5) * r.invScale);
     }
-    return (int64_t)sy * rowStride + sx;
+    return (int64_t)(sy - r.srcRow0) * rowStride + sx;
 }
 
 AAI_HD void pixel_centre(const RotLaunch &r, int dx, int dy, double &px, double &py)

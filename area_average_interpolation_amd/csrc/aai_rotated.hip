@@ -57,11 +57,11 @@ __global__ __launch_bounds__(kRotBlock) void aai_knife_scan_kernel(RotLaunch r, 
 
 // ---- K4/K5 -------------------------------------------------------------------------------------------
 template <typename T>
-__device__ __forceinline__ float tap(const T *img, int64_t rowStride, int W, int H, int x, int y)
+__device__ __forceinline__ float tap(const T *img, int64_t rowStride, int W, int H, int x, int y, int srcRow0 = 0)
 {
     x = min(max(x, 0), W - 1);
     y = min(max(y, 0), H - 1);
-    return (float)img[(int64_t)y * rowStride + x];
+    return (float)img[(int64_t)(y - srcRow0) * rowStride + x];
 }
 
 __device__ __forceinline__ void keys(float t, float w[4])
@@ -78,8 +78,8 @@ __global__ __launch_bounds__(kBlock) void aai_sample_kernel(RotLaunch r, const T
                                                              float *__restrict__ dst, ImageView dv)
 {
     const int dx = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int dy = blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (dx >= r.dW || dy >= r.dH) return;
+    const int dy = r.dyBase + blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (dx >= r.dW || dy >= r.dyEnd) return;
     const T *img = src + (int64_t)blockIdx.z * sv.imageStride;
     double X, Y;
     pixel_centre(r, dx, dy, X, Y);
@@ -99,8 +99,8 @@ __global__ __launch_bounds__(kBlock) void aai_sample_kernel(RotLaunch r, const T
         const int ix = (int)fx, iy = (int)fy;
         const float tx = (float)(sx - fx), ty = (float)(sy - fy);
         if (MODE == AAI_MODE_BILINEAR) {
-            const float v00 = tap(img, sv.rowStride, r.W, r.H, ix, iy), v10 = tap(img, sv.rowStride, r.W, r.H, ix + 1, iy);
-            const float v01 = tap(img, sv.rowStride, r.W, r.H, ix, iy + 1), v11 = tap(img, sv.rowStride, r.W, r.H, ix + 1, iy + 1);
+            const float v00 = tap(img, sv.rowStride, r.W, r.H, ix, iy, r.srcRow0), v10 = tap(img, sv.rowStride, r.W, r.H, ix + 1, iy, r.srcRow0);
+            const float v01 = tap(img, sv.rowStride, r.W, r.H, ix, iy + 1, r.srcRow0), v11 = tap(img, sv.rowStride, r.W, r.H, ix + 1, iy + 1, r.srcRow0);
             const float top = v00 + (v10 - v00) * tx, bot = v01 + (v11 - v01) * tx;
             v = top + (bot - top) * ty;
         } else {
@@ -111,13 +111,13 @@ __global__ __launch_bounds__(kBlock) void aai_sample_kernel(RotLaunch r, const T
             for (int j = 0; j < 4; ++j) {
                 float row = 0.f;
 #pragma unroll
-                for (int i = 0; i < 4; ++i) row += wx[i] * tap(img, sv.rowStride, r.W, r.H, ix - 1 + i, iy - 1 + j);
+                for (int i = 0; i < 4; ++i) row += wx[i] * tap(img, sv.rowStride, r.W, r.H, ix - 1 + i, iy - 1 + j, r.srcRow0);
                 acc += wy[j] * row;
             }
             v = acc;
         }
     }
-    dst[(int64_t)blockIdx.z * dv.imageStride + (int64_t)dy * dv.rowStride + dx] = v;
+    dst[(int64_t)blockIdx.z * dv.imageStride + (int64_t)(dy - r.dyBase) * dv.rowStride + dx] = v;
 }
 
 }  // namespace
@@ -140,9 +140,9 @@ template <typename T>
 static hipError_t launch_rotated_typed(const RotLaunch &r, const T *src, int srcType, ImageView sv, float *dst, ImageView dv,
                                        int batch, const unsigned *waveFlags, hipStream_t stream, const char **kernelName)
 {
-    if (r.dW <= 0 || r.dH <= 0 || batch <= 0) return hipSuccess;
+    if (r.dW <= 0 || r.dyEnd <= r.dyBase || batch <= 0) return hipSuccess;
     if (r.mode == AAI_MODE_BILINEAR || r.mode == AAI_MODE_BICUBIC) {
-        dim3 grid((r.dW + 63) / 64, (r.dH + 3) / 4, batch);
+        dim3 grid((r.dW + 63) / 64, (r.dyEnd - r.dyBase + 3) / 4, batch);
         if (r.mode == AAI_MODE_BILINEAR) {
             if (kernelName) *kernelName = "aai_sample_kernel<bilinear>";
             hipLaunchKernelGGL((aai_sample_kernel<AAI_MODE_BILINEAR, T>), grid, dim3(kBlock), 0, stream, r, src, sv, dst, dv);
@@ -152,7 +152,7 @@ static hipError_t launch_rotated_typed(const RotLaunch &r, const T *src, int src
         }
         return hipGetLastError();
     }
-    dim3 grid((r.dW + 15) / 16, (r.dH + 15) / 16, batch);
+    dim3 grid((r.dW + 15) / 16, (r.dyEnd - r.dyBase + 15) / 16, batch);
     // production pass; then, only for geometries whose scan found knife edges (waveFlags != NULL), the fix-up
     // pass over the same grid
     if (r.mode == AAI_MODE_FAST) {

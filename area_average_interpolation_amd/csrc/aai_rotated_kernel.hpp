@@ -29,11 +29,11 @@ __global__ __launch_bounds__(kRotBlock) void aai_rotated_kernel(RotLaunch r, con
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     // knife-edge flags depend on the geometry only, so one set serves every image of a batch
-    if (STRICT && waveFlags[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * (kRotBlock / 64) + wave] == 0u) return;
+    if (STRICT && waveFlags[((size_t)(blockIdx.y + r.dyBase / 16) * gridDim.x + blockIdx.x) * (kRotBlock / 64) + wave] == 0u) return;
 
     const int dx = blockIdx.x * 16 + (tid & 15);
-    const int dy = blockIdx.y * 16 + (tid >> 4);
-    const bool valid = dx < r.dW && dy < r.dH;
+    const int dy = r.dyBase + blockIdx.y * 16 + (tid >> 4);
+    const bool valid = dx < r.dW && dy < r.dyEnd;
     const T *img = src + (int64_t)blockIdx.z * sv.imageStride;
 
     // (Staging the tile's source footprint in LDS with coalesced loads was measured and rejected: cfg3 1452 ->
@@ -42,7 +42,7 @@ __global__ __launch_bounds__(kRotBlock) void aai_rotated_kernel(RotLaunch r, con
     auto fetch = [&](int X, int Y) -> double { return (double)img[virt_offset(r, X, Y, sv.rowStride)]; };
 
     if (valid) {
-        float *out = dst + (int64_t)blockIdx.z * dv.imageStride + (int64_t)dy * dv.rowStride + dx;
+        float *out = dst + (int64_t)blockIdx.z * dv.imageStride + (int64_t)(dy - r.dyBase) * dv.rowStride + dx;
 
         double px, py;
         pixel_centre(r, dx, dy, px, py);

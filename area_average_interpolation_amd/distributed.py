@@ -23,6 +23,15 @@ def shard_bounds(n_items, rank, world):
     return (rank * n_items) // world, ((rank + 1) * n_items) // world
 
 
+def shard_rows(n_rows, rank, world, align=16):
+    """Row band of ONE image for rank `rank`: contiguous, starts aligned to `align`
+    rows (rotated requests need multiples of 16), the last band takes the remainder.  Returns (row0, row1),
+    possibly empty when there are more ranks than aligned bands."""
+    blocks = (n_rows + align - 1) // align
+    b0, b1 = shard_bounds(blocks, rank, world)
+    return min(b0 * align, n_rows), min(b1 * align, n_rows)
+
+
 def request_to_tensor(request, device="cpu"):
     raw = bytes(ctypes.string_at(ctypes.byref(request), ctypes.sizeof(request)))
     return torch.tensor(list(raw), dtype=torch.uint8, device=device)

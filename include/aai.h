@@ -153,6 +153,17 @@ int aai_resample_batch_device(const aai_request *req, int32_t batch, const void 
 int aai_resample_host(const aai_request *req, const void *src, int32_t src_dtype, int64_t src_stride,
                       float *dst, int64_t dst_stride, aai_layout *layout);
 
+/* ---- row bands of one image -------------------------------------------------------
+ * dst rows [dst_row0, dst_row1) only: for sharding ONE image over several GPUs (each rank computes a band, no
+ * collective: a band only reads its own source footprint) or for images larger than device memory.
+ * aai_band_source_rows (host only) tells which source rows [src_row0, src_row1) the band reads; the device call
+ * takes d_src_rows = address of source row src_row0 (a buffer holding just those rows is enough) and
+ * d_dst_rows = address of output row dst_row0.  For rotated requests dst_row0 must be a multiple of 16.  The band
+ * results are bit-identical to the same rows of the full-image call. */
+int aai_band_source_rows(const aai_request *req, int32_t dst_row0, int32_t dst_row1, int32_t *src_row0, int32_t *src_row1);
+int aai_resample_band_device_f32(const aai_request *req, int32_t dst_row0, int32_t dst_row1,
+                                 const float *d_src_rows, int64_t src_stride, float *d_dst_rows, int64_t dst_stride, void *stream);
+
 /* ---- synthetic input ------------------------------------------------------------
  * Fill a device image with the stateless-hash fp32 uniform [0,1) pattern used by every benchmark and
  * known-answer test: idx = y*width + x, seed as given (image b of a batch uses seed b+1). */

@@ -78,3 +78,26 @@ def test_shard_bounds_partition():
             assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
             assert max(b - a for a, b in spans) - min(b - a for a, b in spans) <= 1
     assert [shard_bounds(64, r, 8) for r in range(8)] == [(8 * r, 8 * r + 8) for r in range(8)]
+
+
+def test_shard_rows_partition_and_band_footprints(aai):
+    """Row-band sharding of one image: aligned contiguous bands that cover every row,
+    and source footprints (aai_band_source_rows, host only) that are in range and -- for an un-rotated
+    down-sampling -- about 1/world of the image each."""
+    from area_average_interpolation_amd.distributed import shard_rows
+    for n in (1, 15, 16, 17, 2048, 3426):
+        for world in (1, 2, 3, 8):
+            spans = [shard_rows(n, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
+            assert all(a % 16 == 0 for a, b in spans if a < b)
+    rq = aai.make_request(8192, 8192, 4, 1, (4095.5, 4095.5), 0.0)
+    for r in range(8):
+        r0, r1 = shard_rows(2048, r, 8)
+        a, b = aai.band_source_rows(rq, r0, r1)
+        assert 0 <= a < b <= 8192 and 1020 <= b - a <= 1030        # 256 dst rows x 4 source rows; the last band loses the 2 rows past the image
+    rq = aai.make_request(8192, 8192, 8192, 2731, (4095.5, 4095.5), 17.5)
+    for r in range(8):
+        r0, r1 = shard_rows(3426, r, 8)
+        a, b = aai.band_source_rows(rq, r0, r1)
+        assert 0 <= a < b <= 8192 and b - a < 8192 * 0.6            # a rotated band still reads a bounded strip

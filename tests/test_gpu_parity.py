@@ -335,6 +335,46 @@ def test_batch_equals_singles_and_strides(gpu):
     assert torch.equal(b2[3], _device_run(gpu, rq2, src[3]))
 
 
+def test_row_bands_equal_full_image(gpu):
+    """dst row bands computed from buffers holding only their source footprint are
+    bit-identical to the same rows of the full-image call -- every kernel family, all quadrants."""
+    import torch
+    from area_average_interpolation_amd.distributed import shard_rows
+    rng = np.random.default_rng(29)
+    cases = [(1024, 768, 4, 1, 0.0, 1), (1024, 768, 4, 1, 180.0, 1), (700, 900, 3, 1, 90.0, 1), (700, 900, 3, 1, 270.0, 2),
+             (640, 480, 3, 1, 17.5, 1), (640, 480, 3, 1, 200.0, 2), (200, 160, 1, 3, 45.0, 1), (300, 200, 1, 2, 30.0, 4),
+             (300, 200, 2, 1, 0.0, 3), (512, 512, 8192, 2731, 0.0, 1)]
+    for (W, H, sr, dr, ang, mode) in cases:
+        rq = gpu.make_request(W, H, sr, dr, ((W - 1) / 2, (H - 1) / 2), ang, mode=mode)
+        rc, msg, lay = gpu.query(rq)
+        assert rc == 0, msg
+        src = torch.from_numpy(rng.random((H, W)).astype(np.float32)).cuda()
+        full = torch.empty((lay.dst_height, lay.dst_width), dtype=torch.float32, device="cuda")
+        st = torch.cuda.current_stream().cuda_stream
+        gpu.resample_device(rq, src.data_ptr(), W, full.data_ptr(), lay.dst_width, st)
+        world = 3
+        covered = 0
+        for rank in range(world):
+            r0, r1 = shard_rows(lay.dst_height, rank, world)
+            if r0 >= r1:
+                continue
+            a, b = gpu.band_source_rows(rq, r0, r1)
+            assert 0 <= a < b <= H
+            band_src = src[a:b].clone()                       # ONLY the footprint rows live in this buffer
+            band_dst = torch.full((r1 - r0, lay.dst_width), -3.0, dtype=torch.float32, device="cuda")
+            gpu.resample_band_device(rq, r0, r1, band_src.data_ptr(), W, band_dst.data_ptr(), lay.dst_width, st)
+            torch.cuda.synchronize()
+            assert torch.equal(band_dst, full[r0:r1]), (W, H, sr, dr, ang, mode, rank, r0, r1, a, b)
+            covered += r1 - r0
+        assert covered == lay.dst_height
+    # argument checks: unaligned band start on a rotated request, rows out of range
+    rq = gpu.make_request(640, 480, 3, 1, (319.5, 239.5), 17.5)
+    with pytest.raises(gpu.AaiError):
+        gpu.band_source_rows(rq, 8, 40)
+    with pytest.raises(gpu.AaiError):
+        gpu.band_source_rows(rq, 0, 100000)
+
+
 def test_device_synth_matches_appendix_c_generator(gpu, po):
     import torch
     t = torch.empty((300, 517), dtype=torch.float32, device="cuda")
