@@ -89,6 +89,8 @@ def hostemu(aai):
         rc = lib.aai_emu_strip_stats(ctypes.byref(rq), *[ctypes.byref(x) for x in v])
         return rc, [x.value for x in v]
 
+    lib.aai_emu_axis_invariants.restype = ctypes.c_int
+    lib.aai_emu_axis_invariants.argtypes = [ctypes.POINTER(L.Request)]
     lib.aai_emu_force_general.restype = None
     lib.aai_emu_force_general.argtypes = [ctypes.c_int]
     lib.aai_emu_set_strict.restype = None

@@ -220,6 +220,56 @@ int aai_emu_pixel_pairs(const aai_request *rq, int dx, int dy, int cap, int *xs,
     return n;
 }
 
+// Planner invariants for a fuzzed geometry (axis-aligned requests only): returns 0 if all hold, else a code.
+int aai_emu_axis_invariants(const aai_request *rq)
+{
+    Geometry g;
+    std::string msg;
+    if (make_geometry(*rq, g, msg) != AAI_OK) return -1;
+    if (!g.axisAligned) return -2;
+    AxisTables t;
+    build_axis_tables(g, rq->mode, t);
+    if (t.nA != (t.transposed ? g.dH : g.dW) || t.nB != (t.transposed ? g.dW : g.dH)) return 1;
+    auto entry_ok = [](const AxisEntry &e, int extent) {
+        if (e.s0 < 0 || e.s1 < e.s0 || e.s1 >= extent) return false;
+        if (e.wFirst < 0.f || e.wMid < 0.f || e.wLast < 0.f) return false;
+        const double total = (double)e.wFirst + (e.s1 > e.s0 ? (double)e.wLast + (double)e.wMid * (e.s1 - e.s0 - 1) : 0.0);
+        const bool empty = e.wFirst == 0.f && e.wMid == 0.f && e.wLast == 0.f;
+        return empty || std::fabs(total - 1.0) < 1e-5;
+    };
+    for (const auto &en : t.lane) if (!entry_ok(en, g.W)) return 2;
+    for (const auto &en : t.row) if (!entry_ok(en, g.H)) return 3;
+    // strips partition the lane axis in order, hold <= 256 outputs, and contain their windows
+    int next = 0;
+    for (const auto &s : t.strips) {
+        if (s.k0 != next || s.k1 <= s.k0 || s.k1 - s.k0 > 256) return 4;
+        for (int k = s.k0; k < s.k1; ++k)
+            if (!t.wide && (t.lane[k].s0 < s.x0 || t.lane[k].s1 >= s.x0 + STRIP_COLS)) return 5;
+        next = s.k1;
+    }
+    if (next != t.nA) return 6;
+    // band slicing: three bands re-create the table of dst rows, re-based to their own first source row
+    const int n = g.dH;
+    for (int part = 0; part < 3 && n >= 3; ++part) {
+        const int r0 = part * n / 3, r1 = (part + 1) * n / 3;
+        AxisTables b;
+        build_axis_tables(g, rq->mode, b);
+        int a = 0, z = 0;
+        restrict_axis_tables_to_band(g, b, r0, r1, a, z);
+        if (a < 0 || z > g.H || a >= z) return 7;
+        const std::vector<AxisEntry> &full = t.transposed ? t.lane : t.row, &band = b.transposed ? b.lane : b.row;
+        const bool flip = t.transposed ? t.flipA : t.flipB;
+        if ((int)band.size() != r1 - r0) return 8;
+        for (int i = 0; i < r1 - r0; ++i) {
+            const AxisEntry &f = full[(flip ? n - r1 : r0) + i], &q = band[i];
+            const bool empty = f.wFirst == 0.f && f.wMid == 0.f && f.wLast == 0.f;
+            if (q.wFirst != f.wFirst || q.wMid != f.wMid || q.wLast != f.wLast) return 9;
+            if (!empty && !t.transposed && (q.s0 + a != f.s0 || q.s1 + a != f.s1)) return 10;
+        }
+    }
+    return 0;
+}
+
 // Strip table introspection for the planner tests.
 int aai_emu_strip_stats(const aai_request *rq, int *nStrips, int *maxOutputsPerStrip, int *wide, int *maxRowSpan)
 {

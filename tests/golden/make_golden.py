@@ -10,6 +10,7 @@ source text.  Run from the repo root in the build container (the reference is ab
     python tests/golden/make_golden.py errors         # tests/golden/error_paths.json
     python tests/golden/make_golden.py full cfg2      # tests/golden/full_cfg2.npz         (minutes, 1 core)
     python tests/golden/make_golden.py full all       # every BASELINE.json config that is CPU-feasible
+    python tests/golden/make_golden.py oraclefull cfg5  # full-size config 5 through the CPU oracle (8 processes, minutes)
 
 `full` stores, for the BASELINE-size runs, the long-double sum, the zero count, a strided sample
 grid of the output and a few complete rows (SURVEY.md Appendix C style known answers), not the
@@ -139,6 +140,68 @@ def gen_full(name):
     print("wrote", path, os.path.getsize(path), "bytes")
 
 
+def _oracle_band(args):
+    """Worker: rows [r0, r1) of one configuration through oracle/aai_oracle.c (aai_oracle_rows, f32 source)."""
+    import ctypes
+    name, mode, r0, r1 = args
+    c = ORACLE_FULL[name]
+    W, H = c["W"], c["H"]
+    lib = po._load_oracle()
+    lib.aai_oracle_rows.restype = ctypes.c_int
+    lib.aai_oracle_rows.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int] + \
+        [ctypes.c_double] * 7 + [ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int]
+    src = np.empty((H, W), np.float32)
+    lib.aai_oracle_synth_f32(src.ctypes.data, W, H, 1)
+    dW = c["dW"]
+    out = np.empty((r1 - r0, dW), np.float64)
+    err = ctypes.create_string_buffer(256)
+    ok = lib.aai_oracle_rows(mode, 0, src.ctypes.data, 1, W, H, c["src_res"], c["src_res"], c["dst_res"], c["dst_res"],
+                             (W - 1) / 2.0, (H - 1) / 2.0, c["angle"], r0, r1, out.ctypes.data, err, 256)
+    assert ok, err.value
+    step, rows = c["step"], c["rows"]
+    grid_rows = [r for r in range(r0, r1) if r % step == 0]
+    return dict(r0=r0, sum=float(np.sum(out.astype(np.longdouble))), zeros=int((out == 0).sum()),
+                grid={r: out[r - r0, ::step].copy() for r in grid_rows},
+                rows={r: out[r - r0].copy() for r in rows if r0 <= r < r1})
+
+
+# Configurations whose full-size reference run is infeasible (BASELINE.md: cfg5 needs ~2 h and ~20 GiB on one core):
+# known answers come from the CPU oracle instead, which is bit-identical to the reference on every golden vector
+# and on randomised runs against the real reference (tests/test_oracle.py).  Clearly labelled as such in the file.
+ORACLE_FULL = {
+    "cfg5": dict(W=4096, H=4096, src_res=1.0, dst_res=4.0, angle=45.0, dW=23170, dH=23170, modes=("exact",)),
+}
+
+
+def gen_oracle_full(name, workers=8):
+    from multiprocessing import Pool
+    c = ORACLE_FULL[name]
+    h, w = c["dH"], c["dW"]
+    c["step"] = max(1, min(h, w) // 48)
+    c["rows"] = sorted(set([0, 1, h // 3, h // 2, (2 * h) // 3, h - 2, h - 1]))
+    store, meta = {}, dict(name=name, W=c["W"], H=c["H"], seed=1, src_res=c["src_res"], dst_res=c["dst_res"],
+                           iso=[(c["W"] - 1) / 2.0, (c["H"] - 1) / 2.0], angle=c["angle"],
+                           source="oracle/aai_oracle.c (the unmodified reference needs ~2 h and ~20 GiB at this size)")
+    for tag in c["modes"]:
+        mode = po.MODE_EXACT if tag == "exact" else po.MODE_FAST
+        bands = [(name, mode, r, min(r + 256, h)) for r in range(0, h, 256)]
+        t0 = time.time()
+        with Pool(workers) as pool:
+            parts = pool.map(_oracle_band, bands)
+        dt = time.time() - t0
+        parts.sort(key=lambda p: p["r0"])
+        grid_rows = sorted(r for p in parts for r in p["grid"])
+        store[tag + "_grid"] = np.stack([next(p["grid"][r] for p in parts if r in p["grid"]) for r in grid_rows])
+        store[tag + "_rows"] = np.stack([next(p["rows"][r] for p in parts if r in p["rows"]) for r in c["rows"]])
+        meta[tag] = dict(shape=[h, w], dst_iso=None, sum=repr(sum(p["sum"] for p in parts)), zeros=sum(p["zeros"] for p in parts),
+                         step=c["step"], rows=c["rows"], oracle_seconds=dt)
+        print(name, tag, (h, w), "%.1fs" % dt, meta[tag]["sum"], meta[tag]["zeros"], flush=True)
+    store["meta"] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
+    path = os.path.join(HERE, "full_%s.npz" % name)
+    np.savez_compressed(path, **store)
+    print("wrote", path, os.path.getsize(path), "bytes")
+
+
 if __name__ == "__main__":
     if not po.have_ref():
         po.build()
@@ -147,6 +210,11 @@ if __name__ == "__main__":
         gen_small()
     elif what == "errors":
         gen_errors()
+    elif what == "oraclefull":
+        if not po.have_oracle():
+            po.build()
+        for n in sys.argv[2:]:
+            gen_oracle_full(n)
     elif what == "full":
         names = list(FULL) if sys.argv[2] == "all" else sys.argv[2:]
         for n in names:

@@ -62,10 +62,11 @@ def test_small_golden_cases_f64_entry(gpu, po, small_golden):
         assert rel_err(dst, z["c%03d_exact" % i]).max() <= TOL, i
 
 
-@pytest.mark.parametrize("name", ["cfg1", "cfg2", "cfg3", "cfg4", "cfg5s"])
+@pytest.mark.parametrize("name", ["cfg1", "cfg2", "cfg3", "cfg4", "cfg5s", "cfg5"])
 def test_baseline_configs_against_reference_known_answers(gpu, name):
-    """BASELINE.json configs at full size (cfg5 at 1/8 linear scale, as BASELINE.md section 4 prescribes):
-    strided sample grid, complete rows, sum and zero count of the unmodified reference's output."""
+    """BASELINE.json configs at full size: strided sample grid, complete rows, sum and zero count of the
+    unmodified reference's output (cfg1-4, cfg5 at 1/8 linear scale = cfg5s), and of the CPU oracle's output for
+    the full 4096^2 -> 23170^2 config 5, which the reference cannot run in reasonable time."""
     import torch
     z, meta = load_full(name)
     W, H = meta["W"], meta["H"]
@@ -77,18 +78,22 @@ def test_baseline_configs_against_reference_known_answers(gpu, name):
         m = meta[tag]
         rq = gpu.make_request(W, H, meta["src_res"], meta["dst_res"], meta["iso"], meta["angle"], mode=mode)
         rc, msg, lay = gpu.query(rq)
-        assert rc == 0 and [lay.dst_height, lay.dst_width] == m["shape"] and [lay.dst_iso_x, lay.dst_iso_y] == m["dst_iso"]
+        assert rc == 0 and [lay.dst_height, lay.dst_width] == m["shape"]
+        if m.get("dst_iso") is not None:
+            assert [lay.dst_iso_x, lay.dst_iso_y] == m["dst_iso"]
         dst = torch.full((lay.dst_height, lay.dst_width), -1.0, dtype=torch.float32, device="cuda")
         gpu.resample_device(rq, src.data_ptr(), W, dst.data_ptr(), lay.dst_width, torch.cuda.current_stream().cuda_stream)
         torch.cuda.synchronize()
-        out = dst.cpu().numpy()
         step = m["step"]
-        assert rel_err(out[::step, ::step], z[tag + "_grid"]).max() <= TOL, (name, tag)
-        assert rel_err(out[m["rows"], :], z[tag + "_rows"]).max() <= TOL, (name, tag)
-        assert np.array_equal(out[m["rows"], :] == 0, z[tag + "_rows"] == 0)
-        assert int((out == 0).sum()) == m["zeros"], (name, tag)
-        total = float(out.astype(np.float64).sum())
+        grid = dst[::step, ::step].cpu().numpy()
+        rows = dst[m["rows"], :].cpu().numpy()
+        assert rel_err(grid, z[tag + "_grid"]).max() <= TOL, (name, tag)
+        assert rel_err(rows, z[tag + "_rows"]).max() <= TOL, (name, tag)
+        assert np.array_equal(rows == 0, z[tag + "_rows"] == 0)
+        assert int((dst == 0).sum().item()) == m["zeros"], (name, tag)
+        total = float(dst.sum(dtype=torch.float64).item())
         assert abs(total - float(m["sum"])) <= 2e-7 * float(m["sum"]), (name, tag, total, m["sum"])
+        del dst
 
 
 # ---- (b) oracle on the same seeded inputs -------------------------------------------------------------------

@@ -274,3 +274,25 @@ def test_baseline_geometries_raise_no_knife_flags(aai, hostemu, po):
         for mode in (1, 2):
             out, axis = hostemu.resample(aai.make_request(W, W, sr, dr, ((W - 1) / 2, (W - 1) / 2), ang, mode=mode), src)
             assert not axis and hostemu.knife_stats() == (0, 0), (W, ang, mode, hostemu.knife_stats())
+
+
+def test_planner_invariants_fuzzed(aai, hostemu):
+    """Fuzz the axis-aligned planner (hypothesis): table sizes, window ranges, weights summing to one, strips that
+    partition the lane axis with at most 256 outputs and contain their windows, and band slices that re-create the
+    full tables (csrc/aai_plan.cpp)."""
+    from hypothesis import given, settings, strategies as st
+
+    @settings(max_examples=300, deadline=None)
+    @given(W=st.integers(1, 3000), H=st.integers(1, 400), sr=st.floats(0.2, 50.0), dr=st.floats(0.2, 5.0),
+           quadrant=st.integers(0, 3), mode=st.sampled_from([1, 2]),
+           fx=st.floats(-0.2, 1.2), fy=st.floats(-0.2, 1.2))
+    def check(W, H, sr, dr, quadrant, mode, fx, fy):
+        if dr / sr > 4 or (W * dr / sr) * (H * dr / sr) > 4e6:
+            return
+        rq = aai.make_request(W, H, sr, dr, (fx * (W - 1), fy * (H - 1)), 90.0 * quadrant, mode=mode)
+        rc, msg, lay = aai.query(rq)
+        if rc != 0 or lay.dst_width == 0 or lay.dst_height == 0:
+            return
+        assert hostemu.aai_emu_axis_invariants(ctypes.byref(rq)) == 0, (W, H, sr, dr, quadrant, mode, fx, fy)
+
+    check()

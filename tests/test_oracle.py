@@ -66,7 +66,7 @@ def test_oracle_cfg1_known_answers(po):
     assert meta["exact"]["sum"] == "32765.606647133827"          # SURVEY.md Appendix C, cfg 1
 
 
-@pytest.mark.parametrize("name", ["cfg2", "cfg3", "cfg4", "cfg5s"])
+@pytest.mark.parametrize("name", ["cfg2", "cfg3", "cfg4", "cfg5s", "cfg5"])
 def test_oracle_rows_of_full_size_configs(po, name):
     """A few complete output rows of the BASELINE-size runs, recomputed with aai_oracle_rows."""
     import ctypes
