@@ -1,0 +1,66 @@
+#!/usr/bin/env python3
+"""Randomised GPU-vs-oracle parity sweep (longer than the test-suite allows): random sizes, ratios, isocenters,
+rotations (generic and structured), modes, policies, source types, batches with padded strides, and row bands.
+usage: python tools/fuzz_parity.py [cases] [seed]"""
+import os, sys, math
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+import torch
+import area_average_interpolation_amd as aai
+from area_average_interpolation_amd import _lib as L
+from oracle import pyoracle as po          # checker only (this is a test tool)
+
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 300
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+aai.set_device(0)
+st = torch.cuda.current_stream().cuda_stream
+special = [0, 30, 45, 60, 90, 180, 270, math.degrees(math.atan(0.5)), 17.5, 1e-6, 89.999999]
+worst, bad = 0.0, 0
+for k in range(N):
+    W, H = int(rng.integers(1, 140)), int(rng.integers(1, 140))
+    sr = float(rng.choice([1, 2, 3, 4, 5])) if k % 3 == 0 else float(rng.uniform(0.4, 8))
+    dr = float(rng.choice([1, 2])) if k % 3 == 0 else float(rng.uniform(0.4, 3))
+    if dr / sr > 2.2:
+        dr = sr * 2.2
+    ang = float(rng.choice(special)) + 90 * int(rng.integers(0, 4)) if k % 4 == 0 else float(rng.uniform(-400, 400))
+    iso = ((W - 1) / 2, (H - 1) / 2) if k % 5 == 0 else (float(rng.uniform(-3, W + 3)), float(rng.uniform(-3, H + 3)))
+    mode = int(rng.choice([1, 1, 2, 3, 4]))
+    policy = int(rng.integers(0, 2)) if mode == 1 else 0
+    dt = rng.choice(["f32", "u8", "u16"]) if mode in (1, 2) else "f32"
+    if dt == "f32":
+        src = rng.random((H, W)).astype(np.float32)
+    else:
+        src = rng.integers(0, 256 if dt == "u8" else 65536, size=(H, W)).astype(np.uint8 if dt == "u8" else np.uint16)
+    scale = 1.0 if dt == "f32" else (256.0 if dt == "u8" else 65536.0)
+    omode = {1: po.MODE_EXACT, 2: po.MODE_FAST, 3: 3, 4: 4}[mode]
+    gold = po.oracle_run(omode, src.astype(np.float64), sr, dr, iso, ang, policy=policy)
+    rc, msg, dst, giso, lay = aai.resample_host(src, sr, dr, iso, ang, mode=mode, policy=policy)
+    assert rc == 0, msg
+    tol = 2e-5 * scale if mode in (3, 4) else None
+    if dst.size:
+        if tol is not None:
+            e = np.abs(dst - gold.dst).max() / tol * 1e-5
+        else:
+            e = (np.abs(dst - gold.dst) / np.maximum(np.abs(gold.dst), 1e-3 * scale)).max()
+        zm = 0 if mode in (3, 4) else int(((gold.dst == 0) != (dst == 0)).sum())
+        worst = max(worst, e)
+        if e > 1e-5 or zm or dst.shape != gold.dst.shape or tuple(giso) != gold.dst_iso:
+            bad += 1
+            print("MISMATCH case", k, dict(W=W, H=H, sr=sr, dr=dr, ang=ang, iso=iso, mode=mode, policy=policy, dt=str(dt)), "err", e, "zero-mismatch", zm, aai.last_kernel())
+    # row bands of the f32 cases must equal the full result bit for bit
+    if dt == "f32" and lay.dst_height >= 32 and k % 2 == 0:
+        rq = aai.make_request(W, H, sr, dr, iso, ang, mode=mode, policy=policy)
+        t = torch.from_numpy(src).cuda()
+        r0 = 16 * int(rng.integers(0, lay.dst_height // 16))
+        r1 = int(rng.integers(r0 + 1, lay.dst_height + 1))
+        a, b = aai.band_source_rows(rq, r0, r1)
+        bs = t[a:b].clone()
+        bd = torch.empty((r1 - r0, lay.dst_width), dtype=torch.float32, device="cuda")
+        aai.resample_band_device(rq, r0, r1, bs.data_ptr(), W, bd.data_ptr(), lay.dst_width, st)
+        torch.cuda.synchronize()
+        if not np.array_equal(bd.cpu().numpy(), dst[r0:r1]):
+            bad += 1
+            print("BAND MISMATCH case", k, dict(W=W, H=H, sr=sr, dr=dr, ang=ang, iso=iso, mode=mode), r0, r1, a, b)
+print("cases", N, "mismatching", bad, "worst relative error", worst)
+sys.exit(1 if bad else 0)
