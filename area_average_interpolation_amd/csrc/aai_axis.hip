@@ -28,59 +28,58 @@ namespace aai {
 namespace {
 
 constexpr int kWaves = 4;
-constexpr int kLdsLine = STRIP_COLS + 8;   // floats per wave; +8 keeps lines 16-byte aligned and apart
+constexpr int VEC = 4;         // source columns per lane and load: STRIP_COLS = 64 * VEC
 
 typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));   // dword-aligned 16-byte access
 typedef float f4 __attribute__((ext_vector_type(4)));
 
-// One 16-byte load of four consecutive source columns of a row.  Branch-free: near the right image edge
-// the lane loads the last in-range vector instead (colc = min(col, W-4)) and fix_edge() shifts the
-// REDUCED vector afterwards (the shift is linear, so it is applied once per output row, not per load).
-// Keeping loads unconditional lets the compiler count them (s_waitcnt vmcnt(N)) and overlap the next
-// output row's loads with the current row's reduction.
+// Raw<T>: VEC = 4 consecutive source columns of one row, as loaded (one 16-, 8- or 4-byte load per lane for fp32,
+// 16-bit and 8-bit sources), and their widening to fp32.
+// Loads only assume element alignment (x0 and the row stride are arbitrary).
+// (Fatter strips for the narrow types -- 8 / 16 columns per lane so that every load is 16 bytes, with a padded LDS
+// line and outputs interleaved across the wave -- were built and measured: 8192^2 u8 -> 2048^2 took 21.0 us per
+// image against 21.2 us for this layout at 8 rows per workgroup; 16-bit sources got slower.  These kernels are
+// bound by issue and wait time of the whole pipeline, not by load width; see profiles/r01_typed_sources.txt.)
 // NT = nontemporal (streaming) load: the source is read exactly once, so it should not displace the
 // tables and the output lines in L2 / Infinity Cache.  Measured on MI355X (tools/membw.hip): plain
 // 16-byte reads stream at ~6.3 TB/s, nontemporal ones at ~7.1 TB/s.
-template <bool NT>
-__device__ __forceinline__ f4 load_cols(const float *__restrict__ row, int colc)
-{
-    const f4u *p = reinterpret_cast<const f4u *>(row + colc);
-    return NT ? __builtin_nontemporal_load(p) : *p;
-}
+template <typename T> struct Raw;
 
-// 8- and 16-bit sources: the same four columns per lane are one 4- or 8-byte load,
-// widened to fp32 in registers; everything downstream is unchanged.
-typedef unsigned int u32u __attribute__((aligned(1)));
-typedef unsigned int u32x2u __attribute__((ext_vector_type(2), aligned(2)));
+template <> struct Raw<float> {
+    f4 q;
+    __device__ __forceinline__ void zero() { q = (f4){0.f, 0.f, 0.f, 0.f}; }
+    template <bool NT> __device__ __forceinline__ void load(const float *p)
+    {
+        const f4u *v = reinterpret_cast<const f4u *>(p);
+        q = NT ? __builtin_nontemporal_load(v) : *v;
+    }
+    __device__ __forceinline__ float get(int i) const { return q[i]; }
+};
 
-template <bool NT>
-__device__ __forceinline__ f4 load_cols(const unsigned char *__restrict__ row, int colc)
-{
-    const u32u *p = reinterpret_cast<const u32u *>(row + colc);
-    const unsigned w = NT ? __builtin_nontemporal_load(p) : *p;
-    f4 v = {(float)(w & 255u), (float)((w >> 8) & 255u), (float)((w >> 16) & 255u), (float)(w >> 24)};
-    return v;
-}
+template <> struct Raw<unsigned char> {
+    typedef unsigned int word __attribute__((aligned(1)));
+    unsigned w;
+    __device__ __forceinline__ void zero() { w = 0u; }
+    template <bool NT> __device__ __forceinline__ void load(const unsigned char *p)
+    {
+        const word *v = reinterpret_cast<const word *>(p);
+        w = NT ? __builtin_nontemporal_load(v) : *v;
+    }
+    __device__ __forceinline__ float get(int i) const { return (float)((w >> (8 * i)) & 255u); }     // v_cvt_f32_ubyte<i>
+};
 
-template <bool NT>
-__device__ __forceinline__ f4 load_cols(const unsigned short *__restrict__ row, int colc)
-{
-    const u32x2u *p = reinterpret_cast<const u32x2u *>(row + colc);
-    const u32x2u w = NT ? __builtin_nontemporal_load(p) : *p;
-    f4 v = {(float)(w.x & 65535u), (float)(w.x >> 16), (float)(w.y & 65535u), (float)(w.y >> 16)};
-    return v;
-}
-
-// v holds columns [colc, colc+4); return columns [colc+shift, colc+shift+4) with zeros past the edge.
-__device__ __forceinline__ f4 fix_edge(f4 v, int shift)
-{
-    f4 r;
-    r.x = shift == 0 ? v.x : shift == 1 ? v.y : shift == 2 ? v.z : shift == 3 ? v.w : 0.f;
-    r.y = shift == 0 ? v.y : shift == 1 ? v.z : shift == 2 ? v.w : 0.f;
-    r.z = shift == 0 ? v.z : shift == 1 ? v.w : 0.f;
-    r.w = shift == 0 ? v.w : 0.f;
-    return r;
-}
+template <> struct Raw<unsigned short> {
+    typedef unsigned int word2 __attribute__((ext_vector_type(2), aligned(2)));
+    unsigned w0, w1;
+    __device__ __forceinline__ void zero() { w0 = 0u; w1 = 0u; }
+    template <bool NT> __device__ __forceinline__ void load(const unsigned short *p)
+    {
+        const word2 *v = reinterpret_cast<const word2 *>(p);
+        const word2 x = NT ? __builtin_nontemporal_load(v) : *v;
+        w0 = x.x; w1 = x.y;
+    }
+    __device__ __forceinline__ float get(int i) const { return (float)(((i < 2 ? w0 : w1) >> (16 * (i & 1))) & 65535u); }
+};
 
 // A table entry unpacked into plain scalars (keeps it in registers: a struct copy of AxisEntry would be
 // turned into a private array and promoted to LDS).
@@ -101,41 +100,54 @@ __device__ __forceinline__ float row_weight(const Win e, int y)
     return y == e.s0 ? e.wF : (y == e.s1 ? e.wL : e.wM);
 }
 
-// Up to four source rows of one output row, issued together.  The window is wave-uniform, so the
-// "row exists" branches are scalar: rows past the window are simply not loaded.
-struct Quad { f4 r0, r1, r2, r3; float w0, w1, w2, w3; };
+struct Cols { float v[VEC]; };
 
+// Vertical pass for one output row: sum_y w(y) * src[y][colc .. colc+VEC-1].  Up to four source rows are issued
+// together; the window is wave-uniform, so the "row exists" branches are scalar and rows past the window are
+// simply not loaded.
 template <bool NT, typename T>
-__device__ __forceinline__ Quad issue_quad(const T *__restrict__ img, int64_t rowStride, int colc, const Win e, int y)
+__device__ __forceinline__ Cols vertical_pass(const T *__restrict__ img, int64_t rowStride, int colc, const Win e)
 {
-    Quad q;
-    const f4 z = {0.f, 0.f, 0.f, 0.f};
-    const T *p = img + (int64_t)y * rowStride;
-    q.r0 = load_cols<NT>(p, colc);
-    q.r1 = z; q.r2 = z; q.r3 = z;
-    if (y + 1 <= e.s1) q.r1 = load_cols<NT>(p + rowStride, colc);
-    if (y + 2 <= e.s1) q.r2 = load_cols<NT>(p + 2 * rowStride, colc);
-    if (y + 3 <= e.s1) q.r3 = load_cols<NT>(p + 3 * rowStride, colc);
-    q.w0 = row_weight(e, y); q.w1 = row_weight(e, y + 1); q.w2 = row_weight(e, y + 2); q.w3 = row_weight(e, y + 3);
-    return q;
-}
-
-__device__ __forceinline__ f4 reduce_quad(const Quad &q, f4 acc)
-{
-    acc += q.w0 * q.r0;
-    acc += q.w1 * q.r1;
-    acc += q.w2 * q.r2;
-    acc += q.w3 * q.r3;
+    Cols acc;
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) acc.v[i] = 0.f;
+    for (int y = e.s0; y <= e.s1; y += 4) {
+        Raw<T> r0, r1, r2, r3;
+        const T *p = img + (int64_t)y * rowStride + colc;
+        r0.template load<NT>(p);
+        r1.zero(); r2.zero(); r3.zero();
+        if (y + 1 <= e.s1) r1.template load<NT>(p + rowStride);
+        if (y + 2 <= e.s1) r2.template load<NT>(p + 2 * rowStride);
+        if (y + 3 <= e.s1) r3.template load<NT>(p + 3 * rowStride);
+        const float w0 = row_weight(e, y), w1 = row_weight(e, y + 1), w2 = row_weight(e, y + 2), w3 = row_weight(e, y + 3);
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) {
+            acc.v[i] += w0 * r0.get(i);
+            acc.v[i] += w1 * r1.get(i);
+            acc.v[i] += w2 * r2.get(i);
+            acc.v[i] += w3 * r3.get(i);
+        }
+    }
     return acc;
 }
 
-// Vertical pass for one output row: sum_y w(y) * src[y][colc..colc+3], rows issued four at a time.
-template <bool NT, typename T>
-__device__ __forceinline__ f4 vertical_pass(const T *__restrict__ img, int64_t rowStride, int colc, const Win e)
+// Park the lane's VEC vertical sums in the wave's LDS line (position = column - strip origin).  Near the right
+// image edge a lane loaded the last in-range vector instead of its own (colc = min(col, W - VEC), shift =
+// col - colc): it then holds columns [colc, colc + VEC) and writes only those at or right of its own first column
+// (the others belong to the lane before it, which writes them itself).
+__device__ __forceinline__ void park(float *line, int lane, int shift, const Cols &c)
 {
-    f4 acc = {0.f, 0.f, 0.f, 0.f};
-    for (int y = e.s0; y <= e.s1; y += 4) acc = reduce_quad(issue_quad<NT, T>(img, rowStride, colc, e, y), acc);
-    return acc;
+    if (shift == 0) {
+#pragma unroll
+        for (int j = 0; j < VEC; j += 4) {
+            const f4 v = {c.v[j], c.v[j + 1], c.v[j + 2], c.v[j + 3]};
+            *reinterpret_cast<f4 *>(line + VEC * lane + j) = v;
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < VEC; ++i)
+            if (i >= shift) line[VEC * lane + i - shift] = c.v[i];
+    }
 }
 
 // Horizontal pass for one output pixel from the wave's LDS line (indices relative to the strip origin).
@@ -166,7 +178,7 @@ __global__ __launch_bounds__(kWaves * 64) void aai_axis_kernel(AxisLaunch a, con
                                                                 float *__restrict__ dst, ImageView dv,
                                                                 int rowsPerBlock, int interleave)
 {
-    __shared__ __attribute__((aligned(16))) float lds[kWaves][kLdsLine];
+    __shared__ __attribute__((aligned(16))) float lds[kWaves][64 * VEC + 8];   // +8 keeps the lines 16-byte aligned and apart
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform: strip/row tables load through the scalar cache
@@ -179,8 +191,8 @@ __global__ __launch_bounds__(kWaves * 64) void aai_axis_kernel(AxisLaunch a, con
     const T *img = src + (int64_t)blockIdx.z * sv.imageStride;
     float *out = dst + (int64_t)blockIdx.z * dv.imageStride + a.outBase;
     float *line = lds[wave];
-    const int col = st.x0 + 4 * lane;
-    const int colc = min(col, a.srcW - 4);          // srcW >= 4 here (narrower images use the wide kernel)
+    const int col = st.x0 + VEC * lane;
+    const int colc = min(col, a.srcW - VEC);        // srcW >= VEC here (narrower images use the wide kernel)
     const int shift = col - colc;                    // 0 away from the right edge
 
     const int rowStart = interleave ? (int)blockIdx.y : (int)blockIdx.y * rowsPerBlock;
@@ -204,9 +216,9 @@ __global__ __launch_bounds__(kWaves * 64) void aai_axis_kernel(AxisLaunch a, con
                 acc[j] = 0.f;
                 if (kb0 + j < rowEnd) {          // wave-uniform
                     const Win e = load_win(rowTab, kb0 + j);
-                    const f4 v = fix_edge(vertical_pass<NT, T>(img, sv.rowStride, colc, e), shift);
+                    const Cols v = vertical_pass<NT, T>(img, sv.rowStride, colc, e);
                     __builtin_amdgcn_wave_barrier();
-                    *reinterpret_cast<f4 *>(line + 4 * lane) = v;
+                    park(line, lane, shift, v);
                     __builtin_amdgcn_wave_barrier();
                     acc[j] = horizontal_pass(line, off, span, c.wF, c.wM, c.wL);
                 }
@@ -236,9 +248,9 @@ __global__ __launch_bounds__(kWaves * 64) void aai_axis_kernel(AxisLaunch a, con
         const int64_t outCol = (int64_t)(st.k0 + lane) * a.outStrideA;
         for (int kb = rowStart; kb < rowEnd; kb += rowStep) {
             const Win e = load_win(rowTab, kb);
-            const f4 v = fix_edge(vertical_pass<NT, T>(img, sv.rowStride, colc, e), shift);
+            const Cols v = vertical_pass<NT, T>(img, sv.rowStride, colc, e);
             __builtin_amdgcn_wave_barrier();
-            *reinterpret_cast<f4 *>(line + 4 * lane) = v;
+            park(line, lane, shift, v);
             __builtin_amdgcn_wave_barrier();
             if (live) out[outCol + (int64_t)kb * a.outStrideB] = horizontal_pass(line, off, span, c.wF, c.wM, c.wL);
         }
@@ -251,9 +263,9 @@ __global__ __launch_bounds__(kWaves * 64) void aai_axis_kernel(AxisLaunch a, con
         const Win c2 = load_win(laneTab, nq > 2 ? kq + 2 : st.k0), c3 = load_win(laneTab, nq > 3 ? kq + 3 : st.k0);
         for (int kb = rowStart; kb < rowEnd; kb += rowStep) {
             const Win e = load_win(rowTab, kb);
-            const f4 v = fix_edge(vertical_pass<NT, T>(img, sv.rowStride, colc, e), shift);
+            const Cols v = vertical_pass<NT, T>(img, sv.rowStride, colc, e);
             __builtin_amdgcn_wave_barrier();
-            *reinterpret_cast<f4 *>(line + 4 * lane) = v;
+            park(line, lane, shift, v);
             __builtin_amdgcn_wave_barrier();
             f4 r;
             r.x = horizontal_pass(line, c0.s0 - st.x0, c0.s1 - c0.s0, c0.wF, c0.wM, c0.wL);
@@ -272,9 +284,9 @@ __global__ __launch_bounds__(kWaves * 64) void aai_axis_kernel(AxisLaunch a, con
         // Many outputs per strip (up-sampling, transposed quadrants at small ratios): lanes walk the outputs.
         for (int kb = rowStart; kb < rowEnd; kb += rowStep) {
             const Win e = load_win(rowTab, kb);
-            const f4 v = fix_edge(vertical_pass<NT, T>(img, sv.rowStride, colc, e), shift);
+            const Cols v = vertical_pass<NT, T>(img, sv.rowStride, colc, e);
             __builtin_amdgcn_wave_barrier();
-            *reinterpret_cast<f4 *>(line + 4 * lane) = v;
+            park(line, lane, shift, v);
             __builtin_amdgcn_wave_barrier();
             for (int k = st.k0 + lane; k < st.k1; k += 64) {
                 const Win c = load_win(laneTab, k);
@@ -342,9 +354,17 @@ static hipError_t launch_axis_typed(const AxisLaunch &a, const T *src, ImageView
     //   * >= 4 source rows per output row: one output row per workgroup (6.8 TB/s at 4:1; 5.3 at 8 rows);
     //   * 2-3 source rows: four (5.0-5.2 TB/s vs 3.7-4.6 at one or two);
     //   * ratios below 2 (129..256 outputs per strip, write-heavy): 32 rows per workgroup (4.2 TB/s at 1:1
-    //     vs 2.5 at four and 1.4 at one); the up-sampling path (more than 256 outputs per strip) prefers 4.
+    //     vs 2.5 at four and 1.4 at one); the up-sampling path (more than 256 outputs per strip) prefers 4;
+    //   * 8- and 16-bit sources move 4x / 2x fewer bytes and are bound by per-wave latency, not by HBM: eight / four
+    //     rows per workgroup (8192^2 u8 -> 2048^2: 28 us at one row, 21 at eight; profiles/r01_typed_sources.txt).
     int nt = a.rowsShared ? 0 : 1, interleave = 0, gy = 0;
     int rows = a.maxRowSpan >= 4 ? (a.rowsShared ? 2 : 1) : 4;
+    if (sizeof(T) < 4) {
+        // ... as long as that leaves a few workgroups per CU
+        const int want = sizeof(T) == 1 ? 8 : 4;
+        const int64_t stripBlocks = (int64_t)((a.nStrips + kWaves - 1) / kWaves) * batch;
+        while (rows < want && stripBlocks * ((a.nB + 2 * rows - 1) / (2 * rows)) >= 2048) rows *= 2;
+    }
     if (a.outStrideA != 1 && a.outStrideA != -1) rows = 8;      // transposed quadrants: eight dst columns per lane and store
     if (a.maxOutputsPerStrip > 128 && a.maxOutputsPerStrip <= 256) rows = 32;      // ratios below 2: write-heavy
     if (const char *env = getenv("AAI_AXIS_TUNE")) {
