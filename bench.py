@@ -127,6 +127,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=4, help="images per GPU per step")
     ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
+    ap.add_argument("--custom", default=None, metavar="W,H,srcRes,dstRes,angle[,fast]",
+                    help="explore another geometry (not a BASELINE configuration); e.g. 8192,8192,4,1,0.5")
     ap.add_argument("--policy", default="reference", choices=["reference", "exact"])
     ap.add_argument("--src-dtype", default="f32", choices=["f32", "u8", "u16"],
                     help="source element type (the headline metric is f32; u8/u16 exercise the typed entry points)")
@@ -155,6 +157,12 @@ def main():
     cdev = dev if (world == 1 or args.backend == "nccl") else torch.device("cpu")     # where collective payloads live
     aai.set_device(local)
 
+    if args.custom:
+        f = args.custom.split(",")
+        WORKLOADS["custom"] = (int(f[0]), int(f[1]), float(f[2]), float(f[3]), float(f[4]),
+                               aai.MODE_FAST if len(f) > 5 and f[5] == "fast" else aai.MODE_AREA,
+                               "custom %sx%s fp32, resolution %s -> %s, rotation %s" % tuple(f[:5]))
+        args.workload = "custom"
     W, H, sr, dr, ang, mode, desc = WORKLOADS[args.workload]
     policy = aai.POLICY_REFERENCE if args.policy == "reference" else aai.POLICY_EXACT
     rq = aai.make_request(W, H, sr, dr, ((W - 1) / 2, (H - 1) / 2), ang, mode=mode, policy=policy)
