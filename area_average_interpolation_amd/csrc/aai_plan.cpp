@@ -140,6 +140,9 @@ RotLaunch make_rot_launch(const Geometry &g, int mode, int policy)
     r.lo = std::min(c, s); r.hi = std::max(c, s);
     r.rc = 1.0 / c; r.rs = 1.0 / s; r.rhi = 1.0 / r.hi; r.r2cs = 1.0 / (2.0 * c * s);
     r.lt45 = g.lt45 ? 1 : 0; r.tsn = g.tsn; r.tcs = g.tcs; r.ttn = g.ttn;
+    // Footprints with an interior at least kRunsMinInterior pixels wide walk rows as runs (aai_rotated_runs_kernel);
+    // the threshold is from profiles/r01_rotated_runs.txt.  Only without replication (scale 1: rows are straight lines).
+    r.runs = (mode == AAI_MODE_AREA && g.scale == 1 && 2.0 * (h - r.k) >= kRunsMinInterior) ? 1 : 0;
     return r;
 }
 

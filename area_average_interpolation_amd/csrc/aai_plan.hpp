@@ -48,6 +48,9 @@ inline void dst_centre(const Geometry &g, double dx, double dy, double &px, doub
     py = -u * g.sn + v * g.cs + g.isoY;
 }
 
+// Interior width (virtual pixels, L - cos - sin) from which the area kernel walks rows as runs.
+constexpr double kRunsMinInterior = 4.0;
+
 // Fills the uniform block of the per-output-pixel kernels (K2-K5) from the geometry.
 RotLaunch make_rot_launch(const Geometry &g, int mode, int policy);
 

@@ -44,6 +44,7 @@ struct RotLaunch {
     double lo, hi;                  // min(c,s), max(c,s)
     double rc, rs, rhi, r2cs;       // 1/c, 1/s, 1/hi, 1/(2 c s)
     // the reference's edge-line parametrisation (Source.cpp:229-240), for the strict replay only
+    int runs;                       // area mode: walk each source row as boundary / interior / boundary runs (large footprints)
     int lt45;                       // reduced angle < 45 degrees
     double tsn, tcs, ttn;           // tmpSin, tmpCos, tmpTan (tan snapped to 0 below DBL_EPSILON)
 };
@@ -286,6 +287,42 @@ AAI_HD int64_t virt_offset(const RotLaunch &r, int X, int Y, int64_t rowStride)
         sy = (int)((sy + 0.5) * r.invScale);
     }
     return (int64_t)(sy - r.srcRow0) * rowStride + sx;
+}
+
+// With scale == 1 the virtual lattice IS the source image seen through a quarter-turn: walking X along virtual
+// row Y walks the source in a straight line.  offset(X, Y) = base + X * step.
+AAI_HD void virt_row(const RotLaunch &r, int Y, int64_t rowStride, int64_t &base, int64_t &step)
+{
+    switch (r.quadrant) {
+    default:
+    case 0: base = (int64_t)(Y - r.srcRow0) * rowStride;                  step = 1;          break;
+    case 1: base = (int64_t)(r.mW - 1 - r.srcRow0) * rowStride + Y;      step = -rowStride; break;
+    case 2: base = (int64_t)(r.mH - 1 - Y - r.srcRow0) * rowStride + (r.mW - 1); step = -1; break;
+    case 3: base = (int64_t)(-r.srcRow0) * rowStride + (r.mH - 1 - Y);   step = rowStride;  break;
+    }
+}
+
+// Runs of one virtual row Y inside the window columns [x0, x1] of the dst square centred at (px, py):
+//   [t0, t1]  pixels the square can touch -- every pixel outside it is PAIR_OUTSIDE for classify_pair;
+//   [i0, i1]  pixels wholly inside the square -- every one of them is PAIR_INSIDE (area exactly 1);
+// i0 > i1 when the row has no interior pixel, t0 > t1 when it has none at all.  The pixel's half extent along both
+// dst axes is k, so "touchable" is |a|, |b| < h + k and "inside" is |a|, |b| <= h - k, each an interval of
+// X - px; twice the knife guard is taken off both so that rounding in the bounds (~1e-12) can never contradict
+// classify_pair, which decides the pixels left in the two boundary runs exactly as before.
+AAI_HD void row_runs(const RotLaunch &r, double px, double py, int Y, int x0, int x1, int &t0, int &t1, int &i0, int &i1)
+{
+    const double g2 = 2.0 * AAI_KNIFE_GUARD;
+    const double ey = Y - py, es = ey * r.s, ec = ey * r.c;
+    const double ht = r.h + r.k + g2, hi = r.h - r.k - g2;
+    const double lot = fmax((es - ht) * r.rc, (-ec - ht) * r.rs), hit = fmin((es + ht) * r.rc, (-ec + ht) * r.rs);
+    // clamp in double before converting: near-axis rotations make the unconstrained bounds astronomically large
+    const double ta = fmax(ceil(px + lot), (double)x0), tb = fmin(floor(px + hit), (double)x1);
+    if (!(ta <= tb)) { t0 = 0; t1 = -1; i0 = 0; i1 = -1; return; }
+    t0 = (int)ta; t1 = (int)tb;
+    const double loi = fmax((es - hi) * r.rc, (-ec - hi) * r.rs), hii = fmin((es + hi) * r.rc, (-ec + hi) * r.rs);
+    const double ia = fmax(ceil(px + loi), ta), ib = fmin(floor(px + hii), tb);
+    if (hi > 0.0 && ia <= ib) { i0 = (int)ia; i1 = (int)ib; }
+    else { i0 = t1 + 1; i1 = t1; }          // empty interior: the left boundary run covers [t0, t1]
 }
 
 AAI_HD void pixel_centre(const RotLaunch &r, int dx, int dy, double &px, double &py)

@@ -25,6 +25,9 @@
 // general clip runs ~6 times per pixel, dense across the wave, instead of once per window position.
 #include "aai_rotated_kernel.hpp"
 
+#include <cstdlib>
+#include <cstring>
+
 namespace aai {
 
 namespace {
@@ -53,6 +56,98 @@ __global__ __launch_bounds__(kRotBlock) void aai_knife_scan_kernel(RotLaunch r, 
         waveFlags[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * (kRotBlock / 64) + wave] = any != 0ull ? 1u : 0u;
         if (any != 0ull) atomicAdd(counter, 1u);
     }
+}
+
+// ---- K2 for large footprints: rows as runs ------------------------------------------------------------------
+// Production pass of the area mode when the dst square has a wide interior (RotLaunch::runs, heavy down-sampling at
+// an angle).  Same lane-per-dst-pixel tiling and the same per-pair arithmetic as aai_rotated_kernel, but each source
+// row of the window is split by row_runs() into [boundary | interior | boundary]: interior pixels have area exactly
+// 1 and are just summed (independent loads, nothing to classify), pixels outside the touched interval are never
+// visited, and only the ~6 L boundary pixels go through classify_pair.  aai_rotated_kernel visits all
+// (1.26 L + 1)^2 window positions and waits for one dependent load per overlapping position, which at L >= 6 leaves
+// it latency-bound (profiles/r01_rotated_envelope.txt).  Sums are reassociated (interior first), a difference of
+// ~1e-16 relative.  The knife-edge fix-up pass is unchanged: flagged waves are redone by the strict kernel.
+template <typename T>
+__global__ __launch_bounds__(kRotBlock) void aai_rotated_runs_kernel(RotLaunch r, const T *__restrict__ src, ImageView sv,
+                                                                   float *__restrict__ dst, ImageView dv)
+{
+    __shared__ unsigned short pending[kRotListCap][kRotBlock];
+
+    const int tid = threadIdx.x;
+    const int dx = blockIdx.x * 16 + (tid & 15);
+    const int dy = r.dyBase + blockIdx.y * 16 + (tid >> 4);
+    if (!(dx < r.dW && dy < r.dyEnd)) return;          // no barrier below
+    const T *img = src + (int64_t)blockIdx.z * sv.imageStride;
+    float *out = dst + (int64_t)blockIdx.z * dv.imageStride + (int64_t)(dy - r.dyBase) * dv.rowStride + dx;
+
+    double px, py;
+    pixel_centre(r, dx, dy, px, py);
+    const double hb = r.h * (r.c + r.s);
+    const int x0 = max(0, (int)floor(px - hb + 0.5 - AAI_KNIFE_GUARD)), x1 = min(r.mW - 1, (int)ceil(px + hb - 0.5 + AAI_KNIFE_GUARD));
+    const int y0 = max(0, (int)floor(py - hb + 0.5 - AAI_KNIFE_GUARD)), y1 = min(r.mH - 1, (int)ceil(py + hb - 0.5 + AAI_KNIFE_GUARD));
+
+    double sumA = 0.0, sumVA = 0.0;
+    int nPend = 0;
+    const bool packable = (x1 - x0) < 256 && (y1 - y0) < 128;
+    for (int Y = y0; Y <= y1; ++Y) {
+        int t0, t1, i0, i1;
+        row_runs(r, px, py, Y, x0, x1, t0, t1, i0, i1);
+        if (t0 > t1) continue;
+        int64_t base, step;
+        virt_row(r, Y, sv.rowStride, base, step);
+        const T *row = img + base;
+        const double ey = Y - py;
+        // one boundary pixel: the body of aai_rotated_kernel's first pass
+        auto boundary = [&](int X) {
+            const double ex = X - px;
+            const double a = ex * r.c - ey * r.s, b = ex * r.s + ey * r.c;
+            double d = 0.0;
+            bool edgy = false, edgy2 = false;
+            const int cls = classify_pair<false>(r, a, b, d, edgy);
+            if (cls == PAIR_OUTSIDE) return;
+            double area;
+            if (cls == PAIR_INSIDE) area = 1.0;
+            else if (cls == PAIR_GENERAL) {
+                if (packable && nPend < kRotListCap) {
+                    pending[nPend++][tid] = (unsigned short)(((Y - y0) << 8) | (X - x0));
+                    return;
+                }
+                area = wedge_pair_area<false>(r, px - (X - 0.5), py - (Y - 0.5), a < 0.0, b < 0.0, r.policy, edgy2);
+            } else area = single_cut_area<false>(r, d, cls == PAIR_CUT_LR, r.policy, edgy2);
+            if (area != 0.0) {
+                sumA += area;
+                sumVA += area * (double)row[(int64_t)X * step];
+            }
+        };
+        for (int X = t0; X < i0; ++X) boundary(X);
+        if (i0 <= i1) {
+            // interior run: four independent loads in flight
+            double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+            int X = i0;
+            for (; X + 3 <= i1; X += 4) {
+                const T *p = row + (int64_t)X * step;
+                const T v0 = p[0], v1 = p[step], v2 = p[2 * step], v3 = p[3 * step];
+                s0 += (double)v0; s1 += (double)v1; s2 += (double)v2; s3 += (double)v3;
+            }
+            for (; X <= i1; ++X) s0 += (double)row[(int64_t)X * step];
+            sumVA += (s0 + s1) + (s2 + s3);
+            sumA += (double)(i1 - i0 + 1);
+            for (X = i1 + 1; X <= t1; ++X) boundary(X);
+        }
+    }
+    for (int i = 0; i < nPend; ++i) {
+        const unsigned short code = pending[i][tid];
+        const int X = x0 + (code & 255), Y = y0 + (code >> 8);
+        bool edgy = false;
+        const double ex = X - px, ey = Y - py;
+        const bool nearLeft = ex * r.c - ey * r.s < 0.0, nearTop = ex * r.s + ey * r.c < 0.0;
+        const double area = wedge_pair_area<false>(r, px - (X - 0.5), py - (Y - 0.5), nearLeft, nearTop, r.policy, edgy);
+        if (area != 0.0) {
+            sumA += area;
+            sumVA += area * (double)img[virt_offset(r, X, Y, sv.rowStride)];
+        }
+    }
+    *out = DBL_EPSILON < fabs(sumA) ? (float)(sumVA / sumA) : 0.f;   // Source.cpp:577
 }
 
 // ---- K4/K5 -------------------------------------------------------------------------------------------
@@ -159,8 +254,16 @@ static hipError_t launch_rotated_typed(const RotLaunch &r, const T *src, int src
         if (kernelName) *kernelName = "aai_rotated_kernel<fast>";
         hipLaunchKernelGGL((aai_rotated_kernel<AAI_MODE_FAST, false, T>), grid, dim3(kRotBlock), 0, stream, r, src, sv, dst, dv, waveFlags);
     } else {
-        if (kernelName) *kernelName = "aai_rotated_kernel<area>";
-        hipLaunchKernelGGL((aai_rotated_kernel<AAI_MODE_AREA, false, T>), grid, dim3(kRotBlock), 0, stream, r, src, sv, dst, dv, waveFlags);
+        int runs = r.runs;
+        if (const char *env = getenv("AAI_ROT_TUNE"))             // experiments: AAI_ROT_TUNE="runs=0|1"
+            if (const char *p = strstr(env, "runs=")) runs = (atoi(p + 5) != 0 && r.scale == 1) ? 1 : 0;
+        if (runs) {
+            if (kernelName) *kernelName = "aai_rotated_runs_kernel<area>";
+            hipLaunchKernelGGL((aai_rotated_runs_kernel<T>), grid, dim3(kRotBlock), 0, stream, r, src, sv, dst, dv);
+        } else {
+            if (kernelName) *kernelName = "aai_rotated_kernel<area>";
+            hipLaunchKernelGGL((aai_rotated_kernel<AAI_MODE_AREA, false, T>), grid, dim3(kRotBlock), 0, stream, r, src, sv, dst, dv, waveFlags);
+        }
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;

@@ -91,6 +91,8 @@ def hostemu(aai):
 
     lib.aai_emu_axis_invariants.restype = ctypes.c_int
     lib.aai_emu_axis_invariants.argtypes = [ctypes.POINTER(L.Request)]
+    lib.aai_emu_uses_runs.restype = ctypes.c_int
+    lib.aai_emu_uses_runs.argtypes = [ctypes.POINTER(L.Request)]
     lib.aai_emu_force_general.restype = None
     lib.aai_emu_force_general.argtypes = [ctypes.c_int]
     lib.aai_emu_set_strict.restype = None
@@ -132,3 +134,12 @@ def rel_err(got, gold, floor=1e-3):
 
 
 TOL = 1e-5   # BASELINE.json north_star: outputs within 1e-5 relative of the reference CPU path
+
+
+RUNS_CASES = [  # (W, H, srcRes, dstRes, angle, iso offset): footprints wide enough for the rows-as-runs kernel
+    (96, 80, 5.0, 1.0, 17.5, (0.0, 0.0)), (96, 96, 6.0, 1.0, 0.5, (0.3, -0.2)), (120, 90, 8.0, 1.0, 33.3, (0.0, 0.0)),
+    (128, 128, 12.0, 1.0, 17.5, (1.5, 2.5)), (100, 140, 7.5, 1.0, 117.5, (0.0, 0.0)), (140, 100, 6.5, 1.0, 200.25, (-3.0, 4.0)),
+    (96, 96, 9.0, 1.0, 305.0, (0.0, 0.0)), (128, 96, 16.0, 1.0, 45.0, (0.0, 0.0)), (96, 128, 8.0, 1.0, 30.0, (0.0, 0.0)),
+    (128, 128, 8.0, 1.0, 60.0, (0.5, 0.5)), (90, 90, 5.0, 1.0, 1e-6, (0.0, 0.0)), (90, 90, 5.0, 1.0, 89.999999, (0.0, 0.0)),
+    (64, 64, 40.0, 1.0, 17.5, (0.0, 0.0)), (200, 40, 6.0, 1.0, 12.0, (0.0, 0.0)),
+]

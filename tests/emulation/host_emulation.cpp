@@ -129,36 +129,59 @@ static void emu_rotated(const Geometry &g, const aai_request &rq, const float *i
                 *out = count > 0 ? (float)(acc / count) : 0.f;
             } else {
                 double sumA = 0, sumVA = 0;
-                for (int Y = y0; Y <= y1; ++Y)
-                    for (int X = x0; X <= x1; ++X) {
-                        const double ex = X - px, ey = Y - py;
-                        const double a = ex * r.c - ey * r.s, b = ex * r.s + ey * r.c;
-                        double d = 0;
-                        bool edgy = false, edgy2 = false;
-                        const int cls = classify_pair<true>(r, a, b, d, edgy);
-                        if (cls == PAIR_OUTSIDE) continue;
-                        double area;
-                        if (cls == PAIR_INSIDE) area = 1.0;
-                        else if (g_forceGeneral) area = pair_area<true>(r, px - (X - 0.5), py - (Y - 0.5), r.policy, edgy2);   // four-edge form
-                        else if (cls == PAIR_GENERAL) area = wedge_pair_area<true>(r, px - (X - 0.5), py - (Y - 0.5), a < 0.0, b < 0.0, r.policy, edgy2);
-                        else area = single_cut_area<true>(r, d, cls == PAIR_CUT_LR, r.policy, edgy2);
-                        // A pair-level knife flag in a pixel the per-pixel test let through is harmless as long as
-                        // the strict replay would not have changed the area (e.g. a pixel corner on the EXTENSION
-                        // of an edge line beyond the vertex); anything else is a gap in the per-pixel test.
-                        if ((edgy || edgy2) && !flagged) {
-                            SVec tv[4];
-                            strict_vertices(r, dx, dy, tv);
-                            if (std::fabs(strict_pair_area(tv, X, Y, r.policy) - area) > 1e-9) ++g_missedPairs;
-                        }
-                        if ((edgy || edgy2) && flagged) {
-                            ++knifeHere;
-                            if (g_strict) {
-                                if (!haveVertices) { strict_vertices(r, dx, dy, sv4); haveVertices = true; }
-                                area = strict_pair_area(sv4, X, Y, r.policy);
-                            }
-                        }
-                        if (area != 0.0) { sumA += area; sumVA += area * (double)img[virt_offset(r, X, Y, srcStride)]; }
+                // one (dst, src) pair: class, area, knife accounting -- shared by the two loop structures below
+                auto pair = [&](int X, int Y) {
+                    const double ex = X - px, ey = Y - py;
+                    const double a = ex * r.c - ey * r.s, b = ex * r.s + ey * r.c;
+                    double d = 0;
+                    bool edgy = false, edgy2 = false;
+                    const int cls = classify_pair<true>(r, a, b, d, edgy);
+                    if (cls == PAIR_OUTSIDE) return;
+                    double area;
+                    if (cls == PAIR_INSIDE) area = 1.0;
+                    else if (g_forceGeneral) area = pair_area<true>(r, px - (X - 0.5), py - (Y - 0.5), r.policy, edgy2);   // four-edge form
+                    else if (cls == PAIR_GENERAL) area = wedge_pair_area<true>(r, px - (X - 0.5), py - (Y - 0.5), a < 0.0, b < 0.0, r.policy, edgy2);
+                    else area = single_cut_area<true>(r, d, cls == PAIR_CUT_LR, r.policy, edgy2);
+                    // A pair-level knife flag in a pixel the per-pixel test let through is harmless as long as
+                    // the strict replay would not have changed the area (e.g. a pixel corner on the EXTENSION
+                    // of an edge line beyond the vertex); anything else is a gap in the per-pixel test.
+                    if ((edgy || edgy2) && !flagged) {
+                        SVec tv[4];
+                        strict_vertices(r, dx, dy, tv);
+                        if (std::fabs(strict_pair_area(tv, X, Y, r.policy) - area) > 1e-9) ++g_missedPairs;
                     }
+                    if ((edgy || edgy2) && flagged) {
+                        ++knifeHere;
+                        if (g_strict) {
+                            if (!haveVertices) { strict_vertices(r, dx, dy, sv4); haveVertices = true; }
+                            area = strict_pair_area(sv4, X, Y, r.policy);
+                        }
+                    }
+                    if (area != 0.0) { sumA += area; sumVA += area * (double)img[virt_offset(r, X, Y, srcStride)]; }
+                };
+                if (r.runs && !(flagged && g_strict)) {
+                    // production pass for large footprints (aai_rotated_runs_kernel): boundary | interior | boundary
+                    for (int Y = y0; Y <= y1; ++Y) {
+                        int t0, t1, i0, i1;
+                        row_runs(r, px, py, Y, x0, x1, t0, t1, i0, i1);
+                        if (t0 > t1) continue;
+                        int64_t base, step;
+                        virt_row(r, Y, srcStride, base, step);
+                        for (int X = t0; X < i0; ++X) pair(X, Y);
+                        if (i0 <= i1) {
+                            double sum = 0;
+                            for (int X = i0; X <= i1; ++X) {
+                                if (base + (int64_t)X * step != virt_offset(r, X, Y, srcStride)) ++g_missedPairs;   // virt_row must agree with virt_offset
+                                sum += (double)img[base + (int64_t)X * step];
+                            }
+                            sumVA += sum; sumA += (double)(i1 - i0 + 1);
+                            for (int X = i1 + 1; X <= t1; ++X) pair(X, Y);
+                        }
+                    }
+                } else {
+                    for (int Y = y0; Y <= y1; ++Y)
+                        for (int X = x0; X <= x1; ++X) pair(X, Y);
+                }
                 *out = DBL_EPSILON < std::fabs(sumA) ? (float)(sumVA / sumA) : 0.f;
             }
             g_knifePairs += knifeHere;
@@ -182,6 +205,15 @@ int aai_emu_resample(const aai_request *rq, const float *src, float *dst, int *d
     if (axis) emu_axis(g, rq->mode, src, g.W, dst, g.dW);
     else emu_rotated(g, *rq, src, g.W, dst, g.dW);
     return AAI_OK;
+}
+
+// 1 when the area mode of this request takes the rows-as-runs production kernel (RotLaunch::runs)
+int aai_emu_uses_runs(const aai_request *rq)
+{
+    Geometry g;
+    std::string msg;
+    if (make_geometry(*rq, g, msg) != AAI_OK || g.axisAligned) return 0;
+    return make_rot_launch(g, rq->mode, rq->policy).runs;
 }
 
 void aai_emu_force_general(int on) { g_forceGeneral = on; }

@@ -10,7 +10,7 @@ import ctypes
 import numpy as np
 import pytest
 
-from conftest import KNIFE_EDGE, KNIFE_EDGE_CASES, TOL, load_full, rel_err
+from conftest import KNIFE_EDGE, KNIFE_EDGE_CASES, RUNS_CASES, TOL, load_full, rel_err
 
 pytestmark = pytest.mark.gpu
 
@@ -144,6 +144,32 @@ def test_axis_kernel_code_paths_against_oracle(gpu, po):
                 if dst.size:
                     assert rel_err(dst, gold.dst).max() <= TOL, (W, H, sr, dr, ang, mode, gpu.last_kernel())
                 assert np.array_equal(gold.dst == 0, dst == 0), (W, H, sr, dr, ang, mode)
+
+
+def test_rows_as_runs_kernel_against_oracle(gpu, po):
+    """Large footprints (heavy down-sampling at an angle) take aai_rotated_runs_kernel: boundary / interior / boundary
+    runs per source row.  Same cases as the CPU replay test, plus 8- and 16-bit sources and a batch."""
+    from area_average_interpolation_amd import _lib as L
+    rng = np.random.default_rng(78)
+    for k, (W, H, sr, dr, ang, off) in enumerate(RUNS_CASES):
+        iso = ((W - 1) / 2 + off[0], (H - 1) / 2 + off[1])
+        src = rng.random((H, W)).astype(np.float32)
+        for policy in (0, 1):
+            gold = po.oracle_run(po.MODE_EXACT, src.astype(np.float64), sr, dr, iso, ang, policy=policy)
+            rc, msg, dst, giso, lay = gpu.resample_host(src, sr, dr, iso, ang, mode=1, policy=policy)
+            assert rc == 0, msg
+            assert "aai_rotated_runs_kernel" in gpu.last_kernel(), (k, gpu.last_kernel())
+            assert dst.shape == gold.dst.shape and tuple(giso) == gold.dst_iso
+            assert rel_err(dst, gold.dst).max() <= TOL, (k, policy, W, H, sr, ang)
+            assert np.array_equal(gold.dst == 0, dst == 0), (k, policy)
+        if k % 3 == 0:
+            for dt, top in ((np.uint8, 256), (np.uint16, 65536)):
+                isrc = rng.integers(0, top, size=(H, W)).astype(dt)
+                gold = po.oracle_run(po.MODE_EXACT, isrc.astype(np.float64), sr, dr, iso, ang)
+                rc, msg, dst, giso, lay = gpu.resample_host(isrc, sr, dr, iso, ang, mode=1)
+                assert rc == 0, msg
+                assert (np.abs(dst - gold.dst) / np.maximum(np.abs(gold.dst), 1e-3 * top)).max() <= TOL, (k, dt)
+                assert np.array_equal(gold.dst == 0, dst == 0), (k, dt)
 
 
 def test_near_axis_rotations_against_oracle(gpu, po):

@@ -9,7 +9,7 @@ import subprocess
 import numpy as np
 import pytest
 
-from conftest import GOLDEN, KNIFE_EDGE, KNIFE_EDGE_CASES, ROOT, TOL, load_full, rel_err
+from conftest import GOLDEN, KNIFE_EDGE, KNIFE_EDGE_CASES, ROOT, RUNS_CASES, TOL, load_full, rel_err
 
 
 # ---- ABI surface ---------------------------------------------------------------------------------------
@@ -191,6 +191,29 @@ def test_host_emulation_quadrants_agree_with_oracle(aai, hostemu, po):
             out, axis = hostemu.resample(aai.make_request(W, H, sr, dr, iso, ang, mode=mode), src)
             assert axis and out.shape == gold.shape
             assert rel_err(out, gold).max() <= TOL, (k, mode, W, H, sr, dr, ang, iso)
+
+
+def test_rows_as_runs_path_matches_oracle(aai, hostemu, po):
+    """Large footprints walk each source row as boundary / interior / boundary runs (csrc/aai_rot_math.hpp: row_runs,
+    aai_rotated_runs_kernel): same answers as the oracle, exact zeros exact, both policies, all quadrants, including
+    knife-edge angles (flagged pixels still go through the strict replay)."""
+    rng = np.random.default_rng(77)
+    for k, (W, H, sr, dr, ang, off) in enumerate(RUNS_CASES):
+        iso = ((W - 1) / 2 + off[0], (H - 1) / 2 + off[1])
+        src = rng.random((H, W)).astype(np.float32)
+        for policy in (0, 1):
+            rq = aai.make_request(W, H, sr, dr, iso, ang, policy=policy)
+            assert hostemu.aai_emu_uses_runs(rq) == 1, (k, "geometry does not take the runs path")
+            gold = po.oracle_run(1, src.astype(np.float64), sr, dr, iso, ang, policy=policy).dst
+            out, axis = hostemu.resample(rq, src)
+            assert not axis and out.shape == gold.shape
+            assert rel_err(out, gold).max() <= TOL, (k, policy, W, H, sr, ang)
+            assert np.array_equal(gold == 0, out == 0), (k, policy)
+            assert hostemu.aai_emu_missed_knife_pairs() == 0, (k, policy)
+    # small footprints, up-sampling and the fast mode keep the per-position loop
+    assert hostemu.aai_emu_uses_runs(aai.make_request(64, 64, 3.0, 1.0, (31.5, 31.5), 17.5)) == 0
+    assert hostemu.aai_emu_uses_runs(aai.make_request(64, 64, 1.0, 4.0, (31.5, 31.5), 45.0)) == 0
+    assert hostemu.aai_emu_uses_runs(aai.make_request(64, 64, 8.0, 1.0, (31.5, 31.5), 17.5, mode=2)) == 0
 
 
 def test_single_cut_closed_form_equals_general_clip(aai, hostemu):
