@@ -137,9 +137,9 @@ TOL = 1e-5   # BASELINE.json north_star: outputs within 1e-5 relative of the ref
 
 
 RUNS_CASES = [  # (W, H, srcRes, dstRes, angle, iso offset): footprints wide enough for the rows-as-runs kernel
-    (96, 80, 5.0, 1.0, 17.5, (0.0, 0.0)), (96, 96, 6.0, 1.0, 0.5, (0.3, -0.2)), (120, 90, 8.0, 1.0, 33.3, (0.0, 0.0)),
+    (96, 80, 5.5, 1.0, 17.5, (0.0, 0.0)), (96, 96, 6.0, 1.0, 0.5, (0.3, -0.2)), (120, 90, 8.0, 1.0, 33.3, (0.0, 0.0)),
     (128, 128, 12.0, 1.0, 17.5, (1.5, 2.5)), (100, 140, 7.5, 1.0, 117.5, (0.0, 0.0)), (140, 100, 6.5, 1.0, 200.25, (-3.0, 4.0)),
     (96, 96, 9.0, 1.0, 305.0, (0.0, 0.0)), (128, 96, 16.0, 1.0, 45.0, (0.0, 0.0)), (96, 128, 8.0, 1.0, 30.0, (0.0, 0.0)),
-    (128, 128, 8.0, 1.0, 60.0, (0.5, 0.5)), (90, 90, 5.0, 1.0, 1e-6, (0.0, 0.0)), (90, 90, 5.0, 1.0, 89.999999, (0.0, 0.0)),
+    (128, 128, 8.0, 1.0, 60.0, (0.5, 0.5)), (90, 90, 5.5, 1.0, 1e-6, (0.0, 0.0)), (90, 90, 5.5, 1.0, 89.999999, (0.0, 0.0)),
     (64, 64, 40.0, 1.0, 17.5, (0.0, 0.0)), (200, 40, 6.0, 1.0, 12.0, (0.0, 0.0)),
 ]
