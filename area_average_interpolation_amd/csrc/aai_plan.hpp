@@ -49,7 +49,7 @@ inline void dst_centre(const Geometry &g, double dx, double dy, double &px, doub
 }
 
 // Interior width (virtual pixels, L - cos - sin) from which the area kernel walks rows as runs.
-constexpr double kRunsMinInterior = 4.0;
+constexpr double kRunsMinInterior = 3.25;
 
 // Fills the uniform block of the per-output-pixel kernels (K2-K5) from the geometry.
 RotLaunch make_rot_launch(const Geometry &g, int mode, int policy);

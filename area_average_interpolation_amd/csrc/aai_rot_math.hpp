@@ -289,40 +289,60 @@ AAI_HD int64_t virt_offset(const RotLaunch &r, int X, int Y, int64_t rowStride)
     return (int64_t)(sy - r.srcRow0) * rowStride + sx;
 }
 
-// With scale == 1 the virtual lattice IS the source image seen through a quarter-turn: walking X along virtual
-// row Y walks the source in a straight line.  offset(X, Y) = base + X * step.
-AAI_HD void virt_row(const RotLaunch &r, int Y, int64_t rowStride, int64_t &base, int64_t &step)
+// With scale == 1 the virtual lattice IS the source image seen through a quarter-turn.  A "line" is the set of virtual
+// pixels that share one SOURCE row: virtual row Y = u in quadrants 0 and 2 (inner coordinate w = X), virtual column
+// X = u in quadrants 1 and 3 (w = Y).  virt_line gives the element offset of that source row and whether w runs
+// against source x; element w of the line is source column (rev ? n - 1 - w : w), n = mW (rows) or mH (columns) = W.
+AAI_HD bool virt_lines_are_columns(const RotLaunch &r) { return (r.quadrant & 1) != 0; }
+AAI_HD int64_t virt_line(const RotLaunch &r, int u, int64_t rowStride, bool &rev)
 {
+    int sy;
     switch (r.quadrant) {
     default:
-    case 0: base = (int64_t)(Y - r.srcRow0) * rowStride;                  step = 1;          break;
-    case 1: base = (int64_t)(r.mW - 1 - r.srcRow0) * rowStride + Y;      step = -rowStride; break;
-    case 2: base = (int64_t)(r.mH - 1 - Y - r.srcRow0) * rowStride + (r.mW - 1); step = -1; break;
-    case 3: base = (int64_t)(-r.srcRow0) * rowStride + (r.mH - 1 - Y);   step = rowStride;  break;
+    case 0: sy = u;            rev = false; break;
+    case 1: sy = r.mW - 1 - u; rev = false; break;      // (X, Y) -> source (Y, mW-1-X)
+    case 2: sy = r.mH - 1 - u; rev = true;  break;      // (X, Y) -> source (mW-1-X, mH-1-Y)
+    case 3: sy = u;            rev = true;  break;      // (X, Y) -> source (mH-1-Y, X)
     }
+    return (int64_t)(sy - r.srcRow0) * rowStride;
 }
 
-// Runs of one virtual row Y inside the window columns [x0, x1] of the dst square centred at (px, py):
+// Runs of one line inside the window range [w0, w1] of the dst square centred at (px, py); pIn is the centre's inner
+// coordinate and fixedRel the line's outer coordinate relative to the centre (rows: px and Y - py; columns: py and
+// X - px):
 //   [t0, t1]  pixels the square can touch -- every pixel outside it is PAIR_OUTSIDE for classify_pair;
 //   [i0, i1]  pixels wholly inside the square -- every one of them is PAIR_INSIDE (area exactly 1);
-// i0 > i1 when the row has no interior pixel, t0 > t1 when it has none at all.  The pixel's half extent along both
-// dst axes is k, so "touchable" is |a|, |b| < h + k and "inside" is |a|, |b| <= h - k, each an interval of
-// X - px; twice the knife guard is taken off both so that rounding in the bounds (~1e-12) can never contradict
-// classify_pair, which decides the pixels left in the two boundary runs exactly as before.
-AAI_HD void row_runs(const RotLaunch &r, double px, double py, int Y, int x0, int x1, int &t0, int &t1, int &i0, int &i1)
+// i0 > i1 when the line has no interior pixel, t0 > t1 when it has none at all.  The pixel's half extent along both
+// dst axes is k, so "touchable" is |a|, |b| < h + k and "inside" is |a|, |b| <= h - k with a = ex c - ey s,
+// b = ex s + ey c: two intervals of the inner coordinate.  Twice the knife guard is taken off both so that rounding in
+// the bounds (~1e-12) can never contradict classify_pair, which decides the pixels left in the two boundary runs
+// exactly as before.
+AAI_HD void line_runs(const RotLaunch &r, bool columns, double pIn, double fixedRel, int w0, int w1, int &t0, int &t1, int &i0, int &i1)
 {
     const double g2 = 2.0 * AAI_KNIFE_GUARD;
-    const double ey = Y - py, es = ey * r.s, ec = ey * r.c;
+    // rows:    ex in ((ey s -+ H) / c) and ((-ey c -+ H) / s);   columns: ey in ((ex c -+ H) / s) and ((-ex s -+ H) / c)
+    const double e1 = fixedRel * (columns ? r.c : r.s), e2 = fixedRel * (columns ? r.s : r.c);
+    const double q1 = columns ? r.rs : r.rc, q2 = columns ? r.rc : r.rs;
     const double ht = r.h + r.k + g2, hi = r.h - r.k - g2;
-    const double lot = fmax((es - ht) * r.rc, (-ec - ht) * r.rs), hit = fmin((es + ht) * r.rc, (-ec + ht) * r.rs);
+    const double lot = fmax((e1 - ht) * q1, (-e2 - ht) * q2), hit = fmin((e1 + ht) * q1, (-e2 + ht) * q2);
     // clamp in double before converting: near-axis rotations make the unconstrained bounds astronomically large
-    const double ta = fmax(ceil(px + lot), (double)x0), tb = fmin(floor(px + hit), (double)x1);
+    const double ta = fmax(ceil(pIn + lot), (double)w0), tb = fmin(floor(pIn + hit), (double)w1);
     if (!(ta <= tb)) { t0 = 0; t1 = -1; i0 = 0; i1 = -1; return; }
     t0 = (int)ta; t1 = (int)tb;
-    const double loi = fmax((es - hi) * r.rc, (-ec - hi) * r.rs), hii = fmin((es + hi) * r.rc, (-ec + hi) * r.rs);
-    const double ia = fmax(ceil(px + loi), ta), ib = fmin(floor(px + hii), tb);
+    const double loi = fmax((e1 - hi) * q1, (-e2 - hi) * q2), hii = fmin((e1 + hi) * q1, (-e2 + hi) * q2);
+    const double ia = fmax(ceil(pIn + loi), ta), ib = fmin(floor(pIn + hii), tb);
     if (hi > 0.0 && ia <= ib) { i0 = (int)ia; i1 = (int)ib; }
-    else { i0 = t1 + 1; i1 = t1; }          // empty interior: the left boundary run covers [t0, t1]
+    else { i0 = t1 + 1; i1 = t1; }          // empty interior
+}
+
+// Fast mode: the pixel centres of one line (see virt_line) inside the closed dst square form one interval of the inner
+// coordinate relative to the centre, [lo, hi] (two pairs of parallel edges = two interval constraints).
+AAI_HD void centre_interval(const RotLaunch &r, bool columns, double fixedRel, double &lo, double &hi)
+{
+    const double e1 = fixedRel * (columns ? r.c : r.s), e2 = fixedRel * (columns ? r.s : r.c);
+    const double q1 = columns ? r.rs : r.rc, q2 = columns ? r.rc : r.rs;
+    lo = fmax((e1 - r.h) * q1, (-e2 - r.h) * q2);
+    hi = fmin((e1 + r.h) * q1, (-e2 + r.h) * q2);
 }
 
 AAI_HD void pixel_centre(const RotLaunch &r, int dx, int dy, double &px, double &py)

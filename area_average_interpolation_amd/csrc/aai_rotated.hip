@@ -61,7 +61,7 @@ __global__ __launch_bounds__(kRotBlock) void aai_knife_scan_kernel(RotLaunch r, 
 // ---- K2 for large footprints: rows as runs ------------------------------------------------------------------
 // Production pass of the area mode when the dst square has a wide interior (RotLaunch::runs, heavy down-sampling at
 // an angle).  Same lane-per-dst-pixel tiling and the same per-pair arithmetic as aai_rotated_kernel, but each source
-// row of the window is split by row_runs() into [boundary | interior | boundary]: interior pixels have area exactly
+// row of the window is split by line_runs() into [boundary | interior | boundary]: interior pixels have area exactly
 // 1 and are just summed (independent loads, nothing to classify), pixels outside the touched interval are never
 // visited, and only the ~6 L boundary pixels go through classify_pair.  aai_rotated_kernel visits all
 // (1.26 L + 1)^2 window positions and waits for one dependent load per overlapping position, which at L >= 6 leaves
@@ -89,17 +89,22 @@ __global__ __launch_bounds__(kRotBlock) void aai_rotated_runs_kernel(RotLaunch r
     double sumA = 0.0, sumVA = 0.0;
     int nPend = 0;
     const bool packable = (x1 - x0) < 256 && (y1 - y0) < 128;
-    for (int Y = y0; Y <= y1; ++Y) {
+    // lines = virtual rows (quadrants 0, 2) or virtual columns (quadrants 1, 3): whichever is a SOURCE row, so that
+    // a lane walks contiguous memory
+    const bool cols = virt_lines_are_columns(r);
+    const int u0 = cols ? x0 : y0, u1 = cols ? x1 : y1, w0 = cols ? y0 : x0, w1 = cols ? y1 : x1;
+    const int nIn = cols ? r.mH : r.mW;
+    const double pIn = cols ? py : px, pOut = cols ? px : py;
+    for (int u = u0; u <= u1; ++u) {
         int t0, t1, i0, i1;
-        row_runs(r, px, py, Y, x0, x1, t0, t1, i0, i1);
+        line_runs(r, cols, pIn, u - pOut, w0, w1, t0, t1, i0, i1);
         if (t0 > t1) continue;
-        int64_t base, step;
-        virt_row(r, Y, sv.rowStride, base, step);
-        const T *row = img + base;
-        const double ey = Y - py;
+        bool rev;
+        const T *srow = img + virt_line(r, u, sv.rowStride, rev);
         // one boundary pixel: the body of aai_rotated_kernel's first pass
-        auto boundary = [&](int X) {
-            const double ex = X - px;
+        auto boundary = [&](int w, float v) {
+            const int X = cols ? u : w, Y = cols ? w : u;
+            const double ex = X - px, ey = Y - py;
             const double a = ex * r.c - ey * r.s, b = ex * r.s + ey * r.c;
             double d = 0.0;
             bool edgy = false, edgy2 = false;
@@ -116,24 +121,37 @@ __global__ __launch_bounds__(kRotBlock) void aai_rotated_runs_kernel(RotLaunch r
             } else area = single_cut_area<false>(r, d, cls == PAIR_CUT_LR, r.policy, edgy2);
             if (area != 0.0) {
                 sumA += area;
-                sumVA += area * (double)row[(int64_t)X * step];
+                sumVA += area * (double)v;
             }
         };
-        for (int X = t0; X < i0; ++X) boundary(X);
-        if (i0 <= i1) {
-            // interior run: four independent loads in flight
-            double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
-            int X = i0;
-            for (; X + 3 <= i1; X += 4) {
-                const T *p = row + (int64_t)X * step;
-                const T v0 = p[0], v1 = p[step], v2 = p[2 * step], v3 = p[3 * step];
-                s0 += (double)v0; s1 += (double)v1; s2 += (double)v2; s3 += (double)v3;
+        double s0 = 0.0, s1 = 0.0;
+        if (nIn >= 4) {
+            // Fetch the touched segment four source columns at a time (one dword-aligned 16-byte load per lane instead
+            // of four 4-byte loads: neighbouring lanes are L source pixels apart, so every load instruction touches
+            // ~64 cache lines and their number is what bounds this kernel), then deal with the four positions from
+            // registers.
+            const int sa = rev ? nIn - 1 - t1 : t0, sb = rev ? nIn - 1 - t0 : t1;        // source columns, ascending
+            for (int c0 = sa; c0 <= sb; c0 += 4) {
+                const int cc = min(c0, nIn - 4);               // keep the vector inside the row; elements left of c0 were done
+                float v[4];
+                load4(srow + cc, v);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int sx = cc + j;
+                    if (sx < c0 || sx > sb) continue;
+                    const int w = rev ? nIn - 1 - sx : sx;
+                    if (w >= i0 && w <= i1) { if (j & 1) s1 += (double)v[j]; else s0 += (double)v[j]; }
+                    else boundary(w, v[j]);
+                }
             }
-            for (; X <= i1; ++X) s0 += (double)row[(int64_t)X * step];
-            sumVA += (s0 + s1) + (s2 + s3);
-            sumA += (double)(i1 - i0 + 1);
-            for (X = i1 + 1; X <= t1; ++X) boundary(X);
+        } else {
+            for (int w = t0; w <= t1; ++w) {
+                const float v = (float)srow[rev ? nIn - 1 - w : w];
+                if (w >= i0 && w <= i1) s0 += (double)v;
+                else boundary(w, v);
+            }
         }
+        if (i0 <= i1) { sumVA += s0 + s1; sumA += (double)(i1 - i0 + 1); }
     }
     for (int i = 0; i < nPend; ++i) {
         const unsigned short code = pending[i][tid];

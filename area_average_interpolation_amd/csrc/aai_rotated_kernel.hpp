@@ -13,6 +13,19 @@ namespace aai {
 constexpr int kRotListCap = 24;    // queued vertex-region pairs per lane (overflow is processed in line)
 constexpr int kRotBlock = 256;     // 16 x 16 dst pixels; a wave covers 16 x 4
 
+// four consecutive source elements as fp32; p only needs element alignment
+__device__ __forceinline__ void load4(const float *p, float v[4])
+{
+    typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+    const f4u q = *reinterpret_cast<const f4u *>(p);
+    v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
+}
+template <typename T>
+__device__ __forceinline__ void load4(const T *p, float v[4])
+{
+    v[0] = (float)p[0]; v[1] = (float)p[1]; v[2] = (float)p[2]; v[3] = (float)p[3];
+}
+
 // STRICT = false: the production pass.  Every pair is answered by the fast path.
 // STRICT = true: the fix-up pass over the same grid, launched only when the plan's knife-edge scan
 //   (aai_knife_scan_kernel, run once per geometry) found flagged waves.  Waves whose flag is clear exit at
@@ -64,6 +77,37 @@ __global__ __launch_bounds__(kRotBlock) void aai_rotated_kernel(RotLaunch r, con
             // flags and the fix-up pass (the per-pixel loop below) redoes.
             int count = 0;
             double acc = 0.0;
+            if (r.scale == 1 && min(r.mW, r.mH) >= 4) {
+                // Without replication a "line" of virtual pixels is a source row (virt_line): walk the lines that way
+                // round -- rows in quadrants 0/2, columns in 1/3 -- and fetch each interval four source columns at a
+                // time (one dword-aligned 16-byte load per lane): neighbouring lanes are L source pixels apart, so
+                // it is the number of load instructions, each touching ~64 cache lines, that bounds large footprints.
+                const bool cols = virt_lines_are_columns(r);
+                const int u0 = cols ? x0 : y0, u1 = cols ? x1 : y1;
+                const int nIn = cols ? r.mH : r.mW;
+                const double pIn = cols ? py : px, pOut = cols ? px : py;
+                double acc1 = 0.0;
+                for (int u = u0; u <= u1; ++u) {
+                    double lo, hi;
+                    centre_interval(r, cols, u - pOut, lo, hi);
+                    const double da = fmax(ceil(pIn + lo), 0.0), db = fmin(floor(pIn + hi), (double)(nIn - 1));
+                    if (!(da <= db)) continue;
+                    const int wa = (int)da, wb = (int)db;
+                    bool rev;
+                    const T *srow = img + virt_line(r, u, sv.rowStride, rev);
+                    const int sa = rev ? nIn - 1 - wb : wa, sb = rev ? nIn - 1 - wa : wb;      // source columns, ascending
+                    for (int c0 = sa; c0 <= sb; c0 += 4) {
+                        const int cc = min(c0, nIn - 4);       // keep the vector inside the row; elements left of c0 were done
+                        float v[4];
+                        load4(srow + cc, v);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            if (cc + j >= c0 && cc + j <= sb) { if (j & 1) acc1 += (double)v[j]; else acc += (double)v[j]; }
+                    }
+                    count += wb - wa + 1;
+                }
+                acc += acc1;
+            } else
             for (int Y = y0; Y <= y1; ++Y) {
                 const double ey = Y - py;
                 const double es = ey * r.s, ec = ey * r.c;

@@ -87,17 +87,29 @@ static void emu_rotated(const Geometry &g, const aai_request &rq, const float *i
             // the production pass flags whole dst pixels; only flagged ones reach the strict replay
             const bool flagged = pixel_on_knife_edge(r, px, py, rq.mode != AAI_MODE_FAST);
             if (rq.mode == AAI_MODE_FAST && !flagged) {
-                // production pass: one interval of centres per source row (see aai_rotated_kernel)
+                // production pass: one interval of centres per line (see aai_rotated_kernel): lines are source rows when
+                // there is no replication (virtual rows in quadrants 0/2, virtual columns in 1/3), else virtual rows
                 int count = 0; double acc = 0;
-                for (int Y = y0; Y <= y1; ++Y) {
-                    const double ey = Y - py, es = ey * r.s, ec = ey * r.c;
-                    const double lo = std::fmax((es - r.h) * r.rc, (-r.h - ec) * r.rs);
-                    const double hi = std::fmin((es + r.h) * r.rc, (r.h - ec) * r.rs);
-                    const double da = std::fmax(std::ceil(px + lo), 0.0), db = std::fmin(std::floor(px + hi), (double)(r.mW - 1));
+                const bool lines = r.scale == 1 && std::min(r.mW, r.mH) >= 4;
+                const bool cols = lines && virt_lines_are_columns(r);
+                const int u0 = cols ? x0 : y0, u1 = cols ? x1 : y1;
+                const int nIn = cols ? r.mH : r.mW;
+                for (int u = u0; u <= u1; ++u) {
+                    double lo, hi;
+                    centre_interval(r, cols, u - (cols ? px : py), lo, hi);
+                    const double pIn = cols ? py : px;
+                    const double da = std::fmax(std::ceil(pIn + lo), 0.0), db = std::fmin(std::floor(pIn + hi), (double)(nIn - 1));
                     if (!(da <= db)) continue;
-                    const int xa = (int)da, xb = (int)db;
-                    for (int X = xa; X <= xb; ++X) acc += (double)img[virt_offset(r, X, Y, srcStride)];
-                    count += xb - xa + 1;
+                    const int wa = (int)da, wb = (int)db;
+                    bool rev = false;
+                    const int64_t line = lines ? virt_line(r, u, srcStride, rev) : 0;
+                    for (int w = wa; w <= wb; ++w) {
+                        const int X = cols ? u : w, Y = cols ? w : u;
+                        const int64_t off = virt_offset(r, X, Y, srcStride);
+                        if (lines && off != line + (rev ? nIn - 1 - w : w)) ++g_missedPairs;       // virt_line must agree with virt_offset
+                        acc += (double)img[off];
+                    }
+                    count += wb - wa + 1;
                 }
                 *out = count > 0 ? (float)(acc / count) : 0.f;
             } else if (rq.mode == AAI_MODE_FAST) {
@@ -161,22 +173,24 @@ static void emu_rotated(const Geometry &g, const aai_request &rq, const float *i
                 };
                 if (r.runs && !(flagged && g_strict)) {
                     // production pass for large footprints (aai_rotated_runs_kernel): boundary | interior | boundary
-                    for (int Y = y0; Y <= y1; ++Y) {
+                    const bool cols = virt_lines_are_columns(r);
+                    const int u0 = cols ? x0 : y0, u1 = cols ? x1 : y1, w0 = cols ? y0 : x0, w1 = cols ? y1 : x1;
+                    const int nIn = cols ? r.mH : r.mW;
+                    for (int u = u0; u <= u1; ++u) {
                         int t0, t1, i0, i1;
-                        row_runs(r, px, py, Y, x0, x1, t0, t1, i0, i1);
+                        line_runs(r, cols, cols ? py : px, u - (cols ? px : py), w0, w1, t0, t1, i0, i1);
                         if (t0 > t1) continue;
-                        int64_t base, step;
-                        virt_row(r, Y, srcStride, base, step);
-                        for (int X = t0; X < i0; ++X) pair(X, Y);
-                        if (i0 <= i1) {
-                            double sum = 0;
-                            for (int X = i0; X <= i1; ++X) {
-                                if (base + (int64_t)X * step != virt_offset(r, X, Y, srcStride)) ++g_missedPairs;   // virt_row must agree with virt_offset
-                                sum += (double)img[base + (int64_t)X * step];
-                            }
-                            sumVA += sum; sumA += (double)(i1 - i0 + 1);
-                            for (int X = i1 + 1; X <= t1; ++X) pair(X, Y);
+                        bool rev;
+                        const int64_t line = virt_line(r, u, srcStride, rev);
+                        double sum = 0;
+                        for (int w = t0; w <= t1; ++w) {
+                            const int X = cols ? u : w, Y = cols ? w : u;
+                            const int64_t off = line + (rev ? nIn - 1 - w : w);
+                            if (off != virt_offset(r, X, Y, srcStride)) ++g_missedPairs;   // virt_line must agree with virt_offset
+                            if (w >= i0 && w <= i1) sum += (double)img[off];
+                            else pair(X, Y);
                         }
+                        if (i0 <= i1) { sumVA += sum; sumA += (double)(i1 - i0 + 1); }
                     }
                 } else {
                     for (int Y = y0; Y <= y1; ++Y)

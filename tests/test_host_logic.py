@@ -212,7 +212,7 @@ def test_rows_as_runs_path_matches_oracle(aai, hostemu, po):
             assert hostemu.aai_emu_missed_knife_pairs() == 0, (k, policy)
     # small footprints, up-sampling and the fast mode keep the per-position loop
     assert hostemu.aai_emu_uses_runs(aai.make_request(64, 64, 3.0, 1.0, (31.5, 31.5), 17.5)) == 0
-    assert hostemu.aai_emu_uses_runs(aai.make_request(64, 64, 5.0, 1.0, (31.5, 31.5), 17.5)) == 0      # interior 3.75 < kRunsMinInterior
+    assert hostemu.aai_emu_uses_runs(aai.make_request(64, 64, 4.0, 1.0, (31.5, 31.5), 17.5)) == 0      # interior 2.75 < kRunsMinInterior
     assert hostemu.aai_emu_uses_runs(aai.make_request(64, 64, 1.0, 4.0, (31.5, 31.5), 45.0)) == 0
     assert hostemu.aai_emu_uses_runs(aai.make_request(64, 64, 8.0, 1.0, (31.5, 31.5), 17.5, mode=2)) == 0
 
