@@ -117,6 +117,64 @@ def resample_host(src, src_resolution, dst_resolution, src_isocenter, rotation_a
     return rc, "", dst, (out_lay.dst_iso_x, out_lay.dst_iso_y), out_lay
 
 
+_NP_DTYPES = {np.dtype(np.float32): L.DTYPE_F32, np.dtype(np.uint8): L.DTYPE_U8, np.dtype(np.uint16): L.DTYPE_U16}
+
+
+class PinnedArray:
+    """A numpy array in page-locked host memory (aai_host_alloc = hipHostMalloc), so that the pipelined host-batch
+    entry copies asynchronously.  Use `.array`; the memory is released by close() / the context manager / GC."""
+
+    def __init__(self, shape, dtype):
+        lib = L.load()
+        self._ptr = ctypes.c_void_p()
+        n = int(np.prod(shape)) * np.dtype(dtype).itemsize
+        rc = lib.aai_host_alloc(ctypes.byref(self._ptr), n)
+        if rc != L.OK:
+            raise AaiError(rc, last_error())
+        buf = (ctypes.c_char * max(n, 1)).from_address(self._ptr.value)
+        self.array = np.frombuffer(buf, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
+
+    def close(self):
+        if self._ptr is not None and self._ptr.value:
+            self.array = None
+            L.load().aai_host_free(self._ptr)
+            self._ptr = None
+
+    __del__ = close
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+
+def resample_batch_host(srcs, src_resolution, dst_resolution, src_isocenter, rotation_angle,
+                        mode=L.MODE_AREA, policy=L.POLICY_REFERENCE, out=None):
+    """Pipelined host-batch path (aai_resample_batch_host): srcs is [B, H, W] float32 / uint8 / uint16 (C-contiguous),
+    the result [B, dH, dW] float32 (written into `out` when given, e.g. a PinnedArray's array).
+    Returns (code, message, dst or None, Layout or None)."""
+    lib = L.load()
+    a = np.ascontiguousarray(srcs)
+    if a.ndim != 3 or a.dtype not in _NP_DTYPES:
+        raise ValueError("srcs must be a [B, H, W] array of float32, uint8 or uint16")
+    B, H, W = a.shape
+    rq = make_request(W, H, src_resolution, dst_resolution, src_isocenter, rotation_angle, mode, policy)
+    rc, msg, lay = query(rq)
+    if rc != L.OK:
+        return rc, msg, None, None
+    shape = (B, lay.dst_height, lay.dst_width)
+    dst = np.empty(shape, dtype=np.float32) if out is None else out
+    if dst.shape != shape or dst.dtype != np.float32 or not dst.flags.c_contiguous:
+        raise ValueError("out must be a C-contiguous float32 array of shape %r" % (shape,))
+    out_lay = L.Layout()
+    rc = lib.aai_resample_batch_host(ctypes.byref(rq), B, a.ctypes.data, _NP_DTYPES[a.dtype], W, W * H,
+                                     dst.ctypes.data, max(lay.dst_width, 1), lay.dst_width * lay.dst_height, ctypes.byref(out_lay))
+    if rc != L.OK:
+        return rc, last_error(), None, None
+    return rc, "", dst, out_lay
+
+
 def resample_device(request, src_ptr, src_stride, dst_ptr, dst_stride, stream=0, batch=None,
                     src_image_stride=0, dst_image_stride=0, src_dtype=L.DTYPE_F32):
     """Device-resident path: raw device pointers (ints) and a hipStream_t handle (int, 0 = default).

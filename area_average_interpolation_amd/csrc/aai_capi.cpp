@@ -488,6 +488,143 @@ int aai_resample_host(const aai_request *req, const void *src, int32_t src_dtype
     return AAI_OK;
 }
 
+int aai_host_alloc(void **ptr, uint64_t bytes)
+{
+    if (!ptr) return fail(AAI_ERR_BAD_ARGUMENT, "Null pointer.");
+    int rc = require_device();
+    if (rc != AAI_OK) return rc;
+    AAI_HIP(hipHostMalloc(ptr, bytes ? (size_t)bytes : 1, hipHostMallocDefault));
+    g_lastError.clear();
+    return AAI_OK;
+}
+
+int aai_host_free(void *ptr)
+{
+    if (!ptr) return AAI_OK;
+    AAI_HIP(hipHostFree(ptr));
+    return AAI_OK;
+}
+
+namespace {
+
+// Device slots of the pipelined host-batch entry, kept between calls (allocating and freeing ~100 MB buffers costs
+// about as much as moving one 8-bit image over PCIe).  One pool per process; calls are serialised on its mutex.
+constexpr int kSlots = 3;
+struct SlotPool {
+    int device = -1;
+    size_t srcBytes = 0, dstBytes = 0;
+    hipStream_t streams[kSlots] = {nullptr, nullptr, nullptr};
+    void *dSrc[kSlots] = {nullptr, nullptr, nullptr};
+    float *dDst[kSlots] = {nullptr, nullptr, nullptr};
+    void release()
+    {
+        for (int s = 0; s < kSlots; ++s) {
+            if (streams[s]) { (void)hipStreamSynchronize(streams[s]); (void)hipStreamDestroy(streams[s]); streams[s] = nullptr; }
+            if (dSrc[s]) { (void)hipFree(dSrc[s]); dSrc[s] = nullptr; }
+            if (dDst[s]) { (void)hipFree(dDst[s]); dDst[s] = nullptr; }
+        }
+        srcBytes = dstBytes = 0; device = -1;
+    }
+    hipError_t reserve(size_t needSrc, size_t needDst)
+    {
+        int dev = -1;
+        hipError_t e = hipGetDevice(&dev);
+        if (e != hipSuccess) return e;
+        if (dev == device && needSrc <= srcBytes && needDst <= dstBytes) return hipSuccess;
+        release();
+        for (int s = 0; s < kSlots && e == hipSuccess; ++s) {
+            e = hipStreamCreateWithFlags(&streams[s], hipStreamNonBlocking);
+            if (e == hipSuccess) e = hipMalloc(&dSrc[s], needSrc);
+            if (e == hipSuccess) e = hipMalloc((void **)&dDst[s], needDst);
+        }
+        if (e != hipSuccess) { release(); return e; }
+        device = dev; srcBytes = needSrc; dstBytes = needDst;
+        return hipSuccess;
+    }
+};
+std::mutex g_slotMutex;
+SlotPool g_slots;
+
+// page-locked (hipHostMalloc / hipHostRegister) memory copies asynchronously; anything else is staged by the runtime
+bool is_page_locked(const void *p)
+{
+    hipPointerAttribute_t attr{};
+    if (hipPointerGetAttributes(&attr, p) != hipSuccess) { (void)hipGetLastError(); return false; }
+    return attr.type == hipMemoryTypeHost;
+}
+
+}  // namespace
+
+int aai_resample_batch_host(const aai_request *req, int32_t batch, const void *src, int32_t src_dtype,
+                            int64_t src_stride, int64_t src_image_stride,
+                            float *dst, int64_t dst_stride, int64_t dst_image_stride, aai_layout *layout)
+{
+    int rc = check_request(req);
+    if (rc != AAI_OK) return rc;
+    const size_t esz = src_dtype == AAI_DTYPE_F32 ? 4 : src_dtype == AAI_DTYPE_U8 ? 1 : src_dtype == AAI_DTYPE_U16 ? 2 : 0;
+    if (!esz) return fail(AAI_ERR_BAD_ARGUMENT, "Unknown source element type.");
+    if (batch < 0) return fail(AAI_ERR_BAD_ARGUMENT, "Negative batch.");
+    aai::Geometry g;
+    std::string msg;
+    rc = aai::make_geometry(*req, g, msg);
+    if (rc != AAI_OK) return fail(rc, msg);
+    if (batch > 0 && (!src || !dst)) return fail(AAI_ERR_BAD_ARGUMENT, "Null image pointer.");
+    if (src_stride < g.W) return fail(AAI_ERR_BAD_ARGUMENT, "Source stride smaller than the image width.");
+    if (dst_stride < g.dW) return fail(AAI_ERR_BAD_ARGUMENT, "Destination stride smaller than the output width.");
+    rc = require_device();
+    if (rc != AAI_OK) return rc;
+
+    const size_t nDst = (size_t)g.dW * g.dH;
+    if (batch > 0 && nDst) {
+        std::lock_guard<std::mutex> lock(g_slotMutex);
+        SlotPool &p = g_slots;
+        AAI_HIP(p.reserve(esz * (size_t)g.W * g.H + 16, sizeof(float) * nDst));
+        // Pageable buffers: the runtime's blocking copy (pinned bounce buffers, double-buffered) is its fastest path
+        // and the asynchronous one much slower, so only page-locked buffers are copied asynchronously.
+        const bool asyncUp = is_page_locked(src), asyncDown = is_page_locked(dst);
+        const char *srcBytes = static_cast<const char *>(src);
+        hipError_t e = hipSuccess;
+        for (int b = 0; b < batch && e == hipSuccess; ++b) {
+            const int s = b % kSlots;
+            hipStream_t st = p.streams[s];
+            // stream order protects the slot: this upload waits for the download of image b - kSlots.  Dense images
+            // go as one linear copy (the 2-D path copies row by row and is several times slower).
+            const char *hSrc = srcBytes + esz * (size_t)b * src_image_stride;
+            float *hDst = dst + (size_t)b * dst_image_stride;
+            if (!asyncUp) e = hipStreamSynchronize(st);          // a blocking copy does not wait for the slot's stream
+            if (e != hipSuccess) break;
+            if (src_stride == g.W) {
+                e = asyncUp ? hipMemcpyAsync(p.dSrc[s], hSrc, esz * (size_t)g.W * g.H, hipMemcpyHostToDevice, st)
+                            : hipMemcpy(p.dSrc[s], hSrc, esz * (size_t)g.W * g.H, hipMemcpyHostToDevice);
+            } else {
+                e = asyncUp ? hipMemcpy2DAsync(p.dSrc[s], esz * g.W, hSrc, esz * src_stride, esz * g.W, g.H, hipMemcpyHostToDevice, st)
+                            : hipMemcpy2D(p.dSrc[s], esz * g.W, hSrc, esz * src_stride, esz * g.W, g.H, hipMemcpyHostToDevice);
+            }
+            if (e != hipSuccess) break;
+            rc = enqueue(*req, 1, p.dSrc[s], src_dtype, g.W, 0, p.dDst[s], g.dW, 0, st);
+            if (rc != AAI_OK) break;
+            if (!asyncDown) e = hipStreamSynchronize(st);
+            if (e != hipSuccess) break;
+            if (dst_stride == g.dW) {
+                e = asyncDown ? hipMemcpyAsync(hDst, p.dDst[s], sizeof(float) * nDst, hipMemcpyDeviceToHost, st)
+                              : hipMemcpy(hDst, p.dDst[s], sizeof(float) * nDst, hipMemcpyDeviceToHost);
+            } else {
+                e = asyncDown ? hipMemcpy2DAsync(hDst, sizeof(float) * dst_stride, p.dDst[s], sizeof(float) * g.dW, sizeof(float) * g.dW, g.dH, hipMemcpyDeviceToHost, st)
+                              : hipMemcpy2D(hDst, sizeof(float) * dst_stride, p.dDst[s], sizeof(float) * g.dW, sizeof(float) * g.dW, g.dH, hipMemcpyDeviceToHost);
+            }
+        }
+        for (int s = 0; s < kSlots; ++s) {
+            const hipError_t e2 = hipStreamSynchronize(p.streams[s]);
+            if (e == hipSuccess) e = e2;
+        }
+        if (rc != AAI_OK) return rc;
+        if (e != hipSuccess) return hip_fail(e, "aai_resample_batch_host");
+    }
+    if (layout) fill_layout(g, resolved_kernel(*req, g), layout);
+    g_lastError.clear();
+    return AAI_OK;
+}
+
 int aai_resample_f32(const aai_request *req, const float *src, int64_t src_stride, float *dst, int64_t dst_stride, aai_layout *layout)
 {
     return resample_host<float>(req, src, src_stride, dst, dst_stride, layout);

@@ -153,6 +153,19 @@ int aai_resample_batch_device(const aai_request *req, int32_t batch, const void 
 int aai_resample_host(const aai_request *req, const void *src, int32_t src_dtype, int64_t src_stride,
                       float *dst, int64_t dst_stride, aai_layout *layout);
 
+/* ---- host batches, pipelined ("pinned-memory streaming pipeline") ----------------------------
+ * `batch` images in HOST memory (image b at src + b*src_image_stride elements, written to dst + b*dst_image_stride):
+ * the images go through three device slots, each with its own HIP stream (upload -> kernel -> download in stream
+ * order), so the upload of image b+1 and the download of image b-1 overlap the kernel of image b and each other.  The
+ * copies are truly asynchronous only from page-locked memory: allocate the buffers with aai_host_alloc (hipHostMalloc)
+ * or register them yourself; pageable buffers work too, at the runtime's staged-copy rate.  Replaces a loop over the
+ * call at Source.cpp:1565 / 1569 for callers that hold many images. */
+int aai_host_alloc(void **ptr, uint64_t bytes);
+int aai_host_free(void *ptr);
+int aai_resample_batch_host(const aai_request *req, int32_t batch, const void *src, int32_t src_dtype,
+                            int64_t src_stride, int64_t src_image_stride,
+                            float *dst, int64_t dst_stride, int64_t dst_image_stride, aai_layout *layout);
+
 /* ---- row bands of one image -------------------------------------------------------
  * dst rows [dst_row0, dst_row1) only: for sharding ONE image over several GPUs (each rank computes a band, no
  * collective: a band only reads its own source footprint) or for images larger than device memory.

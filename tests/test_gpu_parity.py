@@ -366,6 +366,38 @@ def test_batch_equals_singles_and_strides(gpu):
     assert torch.equal(b2[3], _device_run(gpu, rq2, src[3]))
 
 
+def test_pipelined_host_batch_equals_single_calls(gpu):
+    """aai_resample_batch_host (three device slots, one stream each) from pageable and from page-locked
+    buffers, all source types, more images than slots: bit-identical to one aai_resample_host call per image."""
+    rng = np.random.default_rng(31)
+    for (W, H, sr, dr, ang, mode, dt) in [(301, 211, 4.0, 1.0, 0.0, 1, np.float32), (128, 96, 3.0, 1.0, 17.5, 1, np.uint8),
+                                          (96, 128, 7.0, 1.0, 200.0, 1, np.uint16), (150, 90, 2.0, 1.0, 33.0, 2, np.float32),
+                                          (64, 64, 1.0, 2.0, 45.0, 3, np.float32)]:
+        B = 7
+        iso = ((W - 1) / 2, (H - 1) / 2)
+        if dt == np.float32:
+            srcs = rng.random((B, H, W)).astype(np.float32)
+        else:
+            srcs = rng.integers(0, np.iinfo(dt).max + 1, size=(B, H, W)).astype(dt)
+        singles = [gpu.resample_host(srcs[b], sr, dr, iso, ang, mode=mode)[2] for b in range(B)]
+        rc, msg, dst, lay = gpu.resample_batch_host(srcs, sr, dr, iso, ang, mode=mode)
+        assert rc == 0, msg
+        assert dst.shape == (B,) + singles[0].shape
+        for b in range(B):
+            assert np.array_equal(dst[b], singles[b]), (W, H, ang, mode, dt, b)
+        with gpu.PinnedArray(srcs.shape, srcs.dtype) as ps, gpu.PinnedArray(dst.shape, np.float32) as pd:
+            ps.array[...] = srcs
+            pd.array[...] = -1.0
+            rc, msg, dst2, lay = gpu.resample_batch_host(ps.array, sr, dr, iso, ang, mode=mode, out=pd.array)
+            assert rc == 0, msg
+            assert np.array_equal(dst2, dst)
+    # argument errors come before any device work; an empty batch is a no-op
+    rc, msg, dst, lay = gpu.resample_batch_host(np.zeros((0, 8, 8), np.float32), 2.0, 1.0, (3.5, 3.5), 0.0)
+    assert rc == 0 and dst.shape[0] == 0
+    rc, msg, dst, lay = gpu.resample_batch_host(np.zeros((2, 8, 8), np.float32), 2.0, 0.0, (3.5, 3.5), 0.0)
+    assert rc != 0 and "resolution" in msg
+
+
 def test_row_bands_equal_full_image(gpu):
     """dst row bands computed from buffers holding only their source footprint are
     bit-identical to the same rows of the full-image call -- every kernel family, all quadrants."""

@@ -61,6 +61,10 @@ def test_compute_entry_points_fail_loudly_without_a_gpu(aai):
     assert rc == L.ERR_NO_DEVICE and dst is None and "no CPU fallback" in msg
     with pytest.raises(aai.AaiError):
         aai.AreaAverageInterpolation().areaAverageInterpolation(np.ones((4, 4)), 1, 1, (0, 0), 0)
+    rc, msg, dst, lay = aai.resample_batch_host(np.ones((2, 4, 4), np.uint8), 1, 1, (0, 0), 0)
+    assert rc == L.ERR_NO_DEVICE and dst is None and "no CPU fallback" in msg
+    with pytest.raises(aai.AaiError):
+        aai.PinnedArray((4, 4), np.float32)
 
 
 # ---- validation and geometry -----------------------------------------------------------------------------
