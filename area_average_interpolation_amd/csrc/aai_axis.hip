@@ -233,10 +233,71 @@ __global__ __launch_bounds__(kWaves * 64) void aai_axis_kernel(AxisLaunch a, con
                 hi.x = fwd ? acc[4] : acc[3]; hi.y = fwd ? acc[5] : acc[2]; hi.z = fwd ? acc[6] : acc[1]; hi.w = fwd ? acc[7] : acc[0];
                 *reinterpret_cast<f4u *>(p) = lo;
                 *reinterpret_cast<f4u *>(p + 4) = hi;
+            } else if (kb0 + 4 == rowEnd) {
+                // four dst columns (four output rows per workgroup): one 16-byte store
+                const bool fwd = a.outStrideB == 1;
+                float *p = orow + (int64_t)(fwd ? kb0 : kb0 + 3) * a.outStrideB;
+                f4 v;
+                v.x = fwd ? acc[0] : acc[3]; v.y = fwd ? acc[1] : acc[2]; v.z = fwd ? acc[2] : acc[1]; v.w = fwd ? acc[3] : acc[0];
+                *reinterpret_cast<f4u *>(p) = v;
+            } else if (kb0 + 2 == rowEnd) {
+                typedef float f2u __attribute__((ext_vector_type(2), aligned(4)));
+                const bool fwd = a.outStrideB == 1;
+                float *p = orow + (int64_t)(fwd ? kb0 : kb0 + 1) * a.outStrideB;
+                f2u v;
+                v.x = fwd ? acc[0] : acc[1]; v.y = fwd ? acc[1] : acc[0];
+                *reinterpret_cast<f2u *>(p) = v;
             } else {
 #pragma unroll
                 for (int j = 0; j < 8; ++j)
                     if (kb0 + j < rowEnd) orow[(int64_t)(kb0 + j) * a.outStrideB] = acc[j];
+            }
+        }
+    } else if (nOut <= 256 && (a.outStrideB == 1 || a.outStrideB == -1) && rowStep == 1) {
+        // Quadrants 1 and 3 at ratios below 4 (65..256 outputs per strip): up to four outputs per lane, interleaved
+        // across the wave (k = k0 + lane + 64 q, so that neighbouring lanes read neighbouring windows of the LDS line),
+        // each holding FOUR consecutive dst columns in registers = one 16-byte store per output and chunk instead of
+        // four 4-byte stores a dst row pitch apart.
+        const int kl = st.k0 + lane;
+        const int nq = (nOut + 63) >> 6;                         // wave-uniform: 2..4
+        const Win c0 = load_win(laneTab, kl < st.k1 ? kl : st.k0), c1 = load_win(laneTab, kl + 64 < st.k1 ? kl + 64 : st.k0);
+        const Win c2 = load_win(laneTab, kl + 128 < st.k1 ? kl + 128 : st.k0), c3 = load_win(laneTab, kl + 192 < st.k1 ? kl + 192 : st.k0);
+        const bool fwd = a.outStrideB == 1;
+        for (int kb0 = rowStart; kb0 < rowEnd; kb0 += 4) {
+            float acc[4][4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc[q][j] = 0.f;
+                if (kb0 + j < rowEnd) {          // wave-uniform
+                    const Win e = load_win(rowTab, kb0 + j);
+                    const Cols v = vertical_pass<NT, T>(img, sv.rowStride, colc, e);
+                    __builtin_amdgcn_wave_barrier();
+                    park(line, lane, shift, v);
+                    __builtin_amdgcn_wave_barrier();
+                    acc[0][j] = horizontal_pass(line, c0.s0 - st.x0, c0.s1 - c0.s0, c0.wF, c0.wM, c0.wL);
+                    acc[1][j] = horizontal_pass(line, c1.s0 - st.x0, c1.s1 - c1.s0, c1.wF, c1.wM, c1.wL);
+                    if (nq > 2) acc[2][j] = horizontal_pass(line, c2.s0 - st.x0, c2.s1 - c2.s0, c2.wF, c2.wM, c2.wL);
+                    if (nq > 3) acc[3][j] = horizontal_pass(line, c3.s0 - st.x0, c3.s1 - c3.s0, c3.wF, c3.wM, c3.wL);
+                }
+            }
+            const bool full = kb0 + 4 <= rowEnd;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int k = kl + 64 * q;
+                if (k >= st.k1) continue;
+                float *orow = out + (int64_t)k * a.outStrideA;
+                if (full) {
+                    // ascending dst columns: kb0..kb0+3 when outStrideB = +1, reversed when -1
+                    f4 v;
+                    v.x = fwd ? acc[q][0] : acc[q][3]; v.y = fwd ? acc[q][1] : acc[q][2];
+                    v.z = fwd ? acc[q][2] : acc[q][1]; v.w = fwd ? acc[q][3] : acc[q][0];
+                    *reinterpret_cast<f4u *>(orow + (int64_t)(fwd ? kb0 : kb0 + 3) * a.outStrideB) = v;
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if (kb0 + j < rowEnd) orow[(int64_t)(kb0 + j) * a.outStrideB] = acc[q][j];
+                }
             }
         }
     } else if (nOut <= 64) {
@@ -365,8 +426,14 @@ static hipError_t launch_axis_typed(const AxisLaunch &a, const T *src, ImageView
         const int64_t stripBlocks = (int64_t)((a.nStrips + kWaves - 1) / kWaves) * batch;
         while (rows < want && stripBlocks * ((a.nB + 2 * rows - 1) / (2 * rows)) >= 2048) rows *= 2;
     }
-    if (a.outStrideA != 1 && a.outStrideA != -1) rows = 8;      // transposed quadrants: eight dst columns per lane and store
-    if (a.maxOutputsPerStrip > 128 && a.maxOutputsPerStrip <= 256) rows = 32;      // ratios below 2: write-heavy
+    if (a.outStrideA != 1 && a.outStrideA != -1) {
+        // transposed quadrants: 2, 4 or 8 dst columns per lane and store; about 16 source rows per workgroup is the
+        // sweet spot between DRAM page locality and store width (8192^2 at 90 degrees: 4:1 5.9 TB/s at 4 rows vs 5.2 at
+        // 8; 8:1 6.0 at 2 vs 4.8 at 8; profiles/r01_axis_transposed.txt)
+        rows = a.maxRowSpan >= 8 ? 2 : (a.maxRowSpan >= 3 ? 4 : 8);
+        if (a.maxOutputsPerStrip > 64) rows = a.maxRowSpan >= 2 ? 4 : 16;     // the four-column path (ratios below 4)
+    }
+    if ((a.outStrideA == 1 || a.outStrideA == -1) && a.maxOutputsPerStrip > 128 && a.maxOutputsPerStrip <= 256) rows = 32;      // ratios below 2: write-heavy
     if (const char *env = getenv("AAI_AXIS_TUNE")) {
         auto get = [&](const char *key, int &v) {
             const char *p = strstr(env, key);
