@@ -13,7 +13,9 @@ for ang in (0, 90, 180, 270):
 cases += [(8192, 8192, 8192.0, 2731.0, 0, aai.MODE_AREA), (8192, 8192, 2.0, 1.0, 0, aai.MODE_AREA), (8192, 8192, 3.0, 1.0, 0, aai.MODE_AREA),
           (8192, 8192, 8.0, 1.0, 0, aai.MODE_AREA), (8192, 8192, 16.0, 1.0, 0, aai.MODE_AREA), (8192, 8192, 1.0, 1.0, 0, aai.MODE_AREA),
           (4096, 4096, 1.0, 2.0, 0, aai.MODE_AREA), (4096, 4096, 1.0, 4.0, 0, aai.MODE_AREA), (8192, 8192, 4.0, 1.0, 0, aai.MODE_FAST),
-          (8000, 6000, 5.0, 2.0, 90, aai.MODE_AREA), (8191, 8193, 4.0, 1.0, 0, aai.MODE_AREA)]
+          (8000, 6000, 5.0, 2.0, 90, aai.MODE_AREA), (8191, 8193, 4.0, 1.0, 0, aai.MODE_AREA),
+          (8192, 8192, 8.0, 1.0, 90, aai.MODE_AREA), (8192, 8192, 3.0, 1.0, 270, aai.MODE_AREA), (8192, 8192, 2.0, 1.0, 90, aai.MODE_AREA),
+          (8192, 8192, 1.0, 1.0, 270, aai.MODE_AREA), (4096, 4096, 1.0, 2.0, 90, aai.MODE_AREA), (8191, 8193, 4.0, 1.0, 90, aai.MODE_AREA)]
 for (W, H, sr, dr, ang, mode) in cases:
     rq = aai.make_request(W, H, sr, dr, ((W - 1) / 2, (H - 1) / 2), ang, mode=mode)
     rc, msg, lay = aai.query(rq)
