@@ -299,7 +299,8 @@ def _device_run(gpu, rq, src, batch=None):
     return dst
 
 
-@pytest.mark.parametrize("cfg", [(8192, 8192, 4.0, 1.0, 0.0), (8192, 8192, 8192.0, 2731.0, 17.5)])
+@pytest.mark.parametrize("cfg", [(8192, 8192, 4.0, 1.0, 0.0), (8192, 8192, 8192.0, 2731.0, 17.5),
+                                 (8192, 8192, 8.0, 1.0, 107.5), (8192, 8192, 4.0, 1.0, 270.0)])      # + rows-as-runs kernel, transposed K1
 def test_full_size_constant_and_linearity(gpu, cfg):
     """Constant image -> the same constant wherever the dst pixel touches the image, exact 0 elsewhere
     (Source.cpp:577); and resample(a*x + b*y) == a*resample(x) + b*resample(y) (weights do not depend on data)."""
