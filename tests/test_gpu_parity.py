@@ -407,7 +407,10 @@ def test_row_bands_equal_full_image(gpu):
     rng = np.random.default_rng(29)
     cases = [(1024, 768, 4, 1, 0.0, 1), (1024, 768, 4, 1, 180.0, 1), (700, 900, 3, 1, 90.0, 1), (700, 900, 3, 1, 270.0, 2),
              (640, 480, 3, 1, 17.5, 1), (640, 480, 3, 1, 200.0, 2), (200, 160, 1, 3, 45.0, 1), (300, 200, 1, 2, 30.0, 4),
-             (300, 200, 2, 1, 0.0, 3), (512, 512, 8192, 2731, 0.0, 1)]
+             (300, 200, 2, 1, 0.0, 3), (512, 512, 8192, 2731, 0.0, 1),
+             # large footprints: rows-as-runs area kernel and the line-walking fast kernel, in every quadrant
+             (900, 700, 6, 1, 17.5, 1), (900, 700, 6, 1, 107.5, 1), (700, 900, 8, 1, 200.0, 1), (700, 900, 7, 1, 300.0, 1),
+             (900, 700, 6, 1, 107.5, 2), (700, 900, 8, 1, 300.0, 2)]
     for (W, H, sr, dr, ang, mode) in cases:
         rq = gpu.make_request(W, H, sr, dr, ((W - 1) / 2, (H - 1) / 2), ang, mode=mode)
         rc, msg, lay = gpu.query(rq)
