@@ -358,6 +358,67 @@ __global__ __launch_bounds__(kWaves * 64) void aai_axis_kernel(AxisLaunch a, con
     }
 }
 
+// Quadrants 1 and 3 (rotation by 90 / 270 degrees) at ratios below 2, i.e. more than 128 outputs per strip: the lane axis
+// runs along dst y, so the outputs a wave produces for one output row kb are one dst COLUMN -- 64+ stores a dst row
+// pitch apart.  Measured (profiles/r01_axis_transposed.txt): even 16-byte stores per lane leave 1:1 at 1.7 TB/s,
+// whatever the grid order, because every store instruction writes into 64 different lines.  Here a wave gathers
+// kTileCols consecutive output rows (= dst columns) of its strip in an LDS tile and then stores the tile with lanes
+// running along dst x: 64 contiguous bytes per dst row and store.
+constexpr int kTileCols = 16;
+constexpr int kTilePitch = kTileCols + 1;              // odd pitch: the transposed reads hit 64 different banks
+constexpr int kTileWaveFloats = 64 * VEC + 8 + 256 * kTilePitch;
+
+template <bool NT, typename T>
+__global__ __launch_bounds__(kWaves * 64) void aai_axis_tile_kernel(AxisLaunch a, const AxisEntry *__restrict__ laneTab,
+                                                                     const AxisEntry *__restrict__ rowTab, const AxisStrip *__restrict__ strips,
+                                                                     const T *__restrict__ src, ImageView sv,
+                                                                     float *__restrict__ dst, ImageView dv)
+{
+    __shared__ __attribute__((aligned(16))) float smem[kWaves * kTileWaveFloats];     // 72 KiB: two workgroups per CU
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int strip = blockIdx.x * kWaves + wave;
+    if (strip >= a.nStrips) return;   // waves are independent: no s_barrier anywhere
+
+    typedef int i4s __attribute__((ext_vector_type(4)));
+    const i4s stq = reinterpret_cast<const i4s *>(strips)[strip];
+    struct { int k0, k1, x0; } st = {stq.x, stq.y, stq.z};
+    const T *img = src + (int64_t)blockIdx.z * sv.imageStride;
+    float *out = dst + (int64_t)blockIdx.z * dv.imageStride + a.outBase;
+    float *line = smem + wave * kTileWaveFloats;
+    float *tile = line + 64 * VEC + 8;
+    const int col = st.x0 + VEC * lane;
+    const int colc = min(col, a.srcW - VEC);
+    const int shift = col - colc;
+    const int nOut = st.k1 - st.k0;                              // <= 256
+    const int nq = (nOut + 63) >> 6;                             // wave-uniform
+    const int kb0 = blockIdx.y * kTileCols;
+    const int nCols = min(kTileCols, a.nB - kb0);
+
+    const int kl = st.k0 + lane;
+    const Win c0 = load_win(laneTab, kl < st.k1 ? kl : st.k0), c1 = load_win(laneTab, kl + 64 < st.k1 ? kl + 64 : st.k0);
+    const Win c2 = load_win(laneTab, kl + 128 < st.k1 ? kl + 128 : st.k0), c3 = load_win(laneTab, kl + 192 < st.k1 ? kl + 192 : st.k0);
+    for (int j = 0; j < nCols; ++j) {
+        const Win e = load_win(rowTab, kb0 + j);
+        const Cols v = vertical_pass<NT, T>(img, sv.rowStride, colc, e);
+        __builtin_amdgcn_wave_barrier();
+        park(line, lane, shift, v);
+        __builtin_amdgcn_wave_barrier();
+        // outputs interleaved across the wave (k = k0 + lane + 64 q): neighbouring lanes read neighbouring windows
+        tile[lane * kTilePitch + j] = horizontal_pass(line, c0.s0 - st.x0, c0.s1 - c0.s0, c0.wF, c0.wM, c0.wL);
+        if (nq > 1) tile[(lane + 64) * kTilePitch + j] = horizontal_pass(line, c1.s0 - st.x0, c1.s1 - c1.s0, c1.wF, c1.wM, c1.wL);
+        if (nq > 2) tile[(lane + 128) * kTilePitch + j] = horizontal_pass(line, c2.s0 - st.x0, c2.s1 - c2.s0, c2.wF, c2.wM, c2.wL);
+        if (nq > 3) tile[(lane + 192) * kTilePitch + j] = horizontal_pass(line, c3.s0 - st.x0, c3.s1 - c3.s0, c3.wF, c3.wM, c3.wL);
+    }
+    __builtin_amdgcn_wave_barrier();
+    // store: four dst rows x 16 dst columns per instruction
+    const int jr = lane & (kTileCols - 1), rr = lane >> 4;
+    if (jr < nCols)
+        for (int r = rr; r < nOut; r += 64 / kTileCols)
+            out[(int64_t)(st.k0 + r) * a.outStrideA + (int64_t)(kb0 + jr) * a.outStrideB] = tile[r * kTilePitch + jr];
+}
+
 // Fallback for footprints wider than one strip (down-sampling by more than ~250:1): one thread per output
 // pixel walks its whole window.  Correct, not fast; such ratios leave almost no output to write.
 template <typename T>
@@ -441,6 +502,20 @@ static hipError_t launch_axis_typed(const AxisLaunch &a, const T *src, ImageView
         };
         get("nt=", nt); get("rows=", rows); get("interleave=", interleave); get("gy=", gy);
         if (rows < 1) rows = 1;
+    }
+    // (measured, profiles/r01_axis_transposed.txt: wins below 2:1 -- 1:1 1.8 -> 2.3 TB/s, x4 up-sampling 1.2 -> 1.6 --
+    // and loses 5-14 % to the four-column register path between 2:1 and 4:1)
+    int tile = (a.outStrideA != 1 && a.outStrideA != -1) && (a.outStrideB == 1 || a.outStrideB == -1) && a.maxOutputsPerStrip > 128 &&
+               a.maxOutputsPerStrip <= 256;
+    if (const char *env = getenv("AAI_AXIS_TUNE"))
+        if (const char *p = strstr(env, "tile=")) tile = tile && atoi(p + 5) != 0;
+    if (tile && (a.nB + kTileCols - 1) / kTileCols <= 65535) {
+        // transposed quadrants at ratios below 4: LDS tile, stores along dst x (see aai_axis_tile_kernel)
+        dim3 grid((a.nStrips + kWaves - 1) / kWaves, (a.nB + kTileCols - 1) / kTileCols, batch), block(kWaves * 64);
+        if (kernelName) *kernelName = "aai_axis_tile_kernel";
+        if (nt) hipLaunchKernelGGL((aai_axis_tile_kernel<true, T>), grid, block, 0, stream, a, a.laneTab, a.rowTab, a.strips, src, sv, dst, dv);
+        else hipLaunchKernelGGL((aai_axis_tile_kernel<false, T>), grid, block, 0, stream, a, a.laneTab, a.rowTab, a.strips, src, sv, dst, dv);
+        return hipGetLastError();
     }
     const int blocksX = (a.nStrips + kWaves - 1) / kWaves;
     int blocksY = (a.nB + rows - 1) / rows;

@@ -131,6 +131,7 @@ def test_axis_kernel_code_paths_against_oracle(gpu, po):
         (3000, 12, 700, 1, L.KERNEL_AXIS_WIDE), (3, 50, 2, 1, L.KERNEL_AXIS_WIDE), (1, 1, 1, 1, L.KERNEL_AXIS_WIDE),
         (2, 300, 1, 1, L.KERNEL_AXIS_WIDE), (4, 4, 2, 1, L.KERNEL_AXIS), (5, 700, 3, 1, L.KERNEL_AXIS),
     ]
+    seen = set()
     for (W, H, sr, dr, kern) in cases:
         for ang in (0, 90, 180, 270):
             iso = ((W - 1) / 2, (H - 1) / 2) if ang in (0, 180) else (float(rng.uniform(0, W)), float(rng.uniform(0, H)))
@@ -139,11 +140,14 @@ def test_axis_kernel_code_paths_against_oracle(gpu, po):
                 gold = po.oracle_run(omode, src.astype(np.float64), sr, dr, iso, ang)
                 dst, giso, lay = _host(gpu, src, dict(src_res=float(sr), dst_res=float(dr), iso=iso, angle=float(ang)), mode)
                 assert dst.shape == gold.dst.shape and tuple(giso) == gold.dst_iso
+                seen.add(gpu.last_kernel())
                 if ang in (0, 180):
                     assert lay.kernel == kern, (W, H, sr, dr, ang, lay.kernel)
                 if dst.size:
                     assert rel_err(dst, gold.dst).max() <= TOL, (W, H, sr, dr, ang, mode, gpu.last_kernel())
                 assert np.array_equal(gold.dst == 0, dst == 0), (W, H, sr, dr, ang, mode)
+    # the transposed quadrants at ratios below 2 go through the LDS-tile kernel
+    assert {"aai_axis_kernel", "aai_axis_wide_kernel", "aai_axis_tile_kernel"} <= seen, seen
 
 
 def test_rows_as_runs_kernel_against_oracle(gpu, po):
