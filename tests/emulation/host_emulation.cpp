@@ -230,6 +230,44 @@ int aai_emu_uses_runs(const aai_request *rq)
     return make_rot_launch(g, rq->mode, rq->policy).runs;
 }
 
+// Property behind the rows-as-runs kernel: for every dst pixel and every line of its window, line_runs' interior
+// pixels are PAIR_INSIDE for classify_pair and the pixels outside its touched interval are PAIR_OUTSIDE -- along rows
+// and along columns.  Returns the number of violations (0 expected), -1 on a bad request.
+long aai_emu_check_line_runs(const aai_request *rq)
+{
+    Geometry g;
+    std::string msg;
+    if (make_geometry(*rq, g, msg) != AAI_OK || g.axisAligned) return -1;
+    const RotLaunch r = make_rot_launch(g, AAI_MODE_AREA, rq->policy);
+    long bad = 0;
+    for (int dy = 0; dy < r.dH; ++dy)
+        for (int dx = 0; dx < r.dW; ++dx) {
+            double px, py;
+            pixel_centre(r, dx, dy, px, py);
+            const double hb = r.h * (r.c + r.s);
+            const int x0 = std::max(0, (int)std::floor(px - hb + 0.5 - AAI_KNIFE_GUARD)), x1 = std::min(r.mW - 1, (int)std::ceil(px + hb - 0.5 + AAI_KNIFE_GUARD));
+            const int y0 = std::max(0, (int)std::floor(py - hb + 0.5 - AAI_KNIFE_GUARD)), y1 = std::min(r.mH - 1, (int)std::ceil(py + hb - 0.5 + AAI_KNIFE_GUARD));
+            for (int cols = 0; cols < 2; ++cols) {
+                const int u0 = cols ? x0 : y0, u1 = cols ? x1 : y1, w0 = cols ? y0 : x0, w1 = cols ? y1 : x1;
+                for (int u = u0; u <= u1; ++u) {
+                    int t0, t1, i0, i1;
+                    line_runs(r, cols != 0, cols ? py : px, u - (cols ? px : py), w0, w1, t0, t1, i0, i1);
+                    for (int w = w0; w <= w1; ++w) {
+                        const int X = cols ? u : w, Y = cols ? w : u;
+                        const double ex = X - px, ey = Y - py;
+                        double d = 0;
+                        bool edgy = false;
+                        const int cls = classify_pair<false>(r, ex * r.c - ey * r.s, ex * r.s + ey * r.c, d, edgy);
+                        const bool touched = t0 <= t1 && w >= t0 && w <= t1, interior = touched && i0 <= i1 && w >= i0 && w <= i1;
+                        if (interior && cls != PAIR_INSIDE) ++bad;
+                        if (!touched && cls != PAIR_OUTSIDE) ++bad;
+                    }
+                }
+            }
+        }
+    return bad;
+}
+
 void aai_emu_force_general(int on) { g_forceGeneral = on; }
 void aai_emu_set_strict(int on) { g_strict = on; }
 void aai_emu_knife_stats(long *pairs, long *pixels) { *pairs = g_knifePairs; *pixels = g_knifePixels; }

@@ -324,3 +324,26 @@ def test_planner_invariants_fuzzed(aai, hostemu):
         assert hostemu.aai_emu_axis_invariants(ctypes.byref(rq)) == 0, (W, H, sr, dr, quadrant, mode, fx, fy)
 
     check()
+
+
+def test_line_runs_never_contradict_the_pair_classifier(aai, hostemu):
+    """The rows-as-runs kernel skips classify_pair for a line's interior pixels (area 1) and never visits pixels
+    outside the touched interval: check, over fuzzed geometries (hypothesis) and the structured knife-edge angles, that
+    classify_pair would indeed have said INSIDE / OUTSIDE for every such pixel, along rows and along columns
+    (csrc/aai_rot_math.hpp: line_runs)."""
+    from hypothesis import given, settings, strategies as st
+
+    @settings(max_examples=120, deadline=None)
+    @given(W=st.integers(8, 90), H=st.integers(8, 90), ratio=st.floats(1.2, 24.0), ang=st.floats(-360.0, 720.0),
+           fx=st.floats(-0.1, 1.1), fy=st.floats(-0.1, 1.1), policy=st.sampled_from([0, 1]))
+    def check(W, H, ratio, ang, fx, fy, policy):
+        rq = aai.make_request(W, H, ratio, 1.0, (fx * (W - 1), fy * (H - 1)), ang, policy=policy)
+        bad = hostemu.aai_emu_check_line_runs(ctypes.byref(rq))
+        assert bad <= 0, (W, H, ratio, ang, fx, fy, bad)          # -1: axis-aligned, nothing to check
+
+    check()
+    for ang in (30.0, 45.0, 60.0, 26.565051177077990, 36.869897645844020, 1e-6, 89.999999, 135.0, 210.0, 300.0):
+        for ratio in (2.0, 4.0, 5.0, 8.0, 2.0 * 2 ** 0.5, 12.0):
+            for iso in ((31.5, 31.5), (32.0, 32.0), (31.75, 30.25)):
+                rq = aai.make_request(64, 64, ratio, 1.0, iso, ang)
+                assert hostemu.aai_emu_check_line_runs(ctypes.byref(rq)) == 0, (ang, ratio, iso)
