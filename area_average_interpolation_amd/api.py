@@ -125,6 +125,7 @@ class PinnedArray:
     entry copies asynchronously.  Use `.array`; the memory is released by close() / the context manager / GC."""
 
     def __init__(self, shape, dtype):
+        self._ptr = None
         lib = L.load()
         self._ptr = ctypes.c_void_p()
         n = int(np.prod(shape)) * np.dtype(dtype).itemsize
@@ -135,10 +136,14 @@ class PinnedArray:
         self.array = np.frombuffer(buf, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
 
     def close(self):
-        if self._ptr is not None and self._ptr.value:
+        ptr = getattr(self, "_ptr", None)
+        if ptr is not None and ptr.value:
             self.array = None
-            L.load().aai_host_free(self._ptr)
             self._ptr = None
+            try:
+                L.load().aai_host_free(ptr)
+            except Exception:           # interpreter shutdown: the runtime may already be gone
+                pass
 
     __del__ = close
 
