@@ -8,6 +8,7 @@
 
 #include <cmath>
 #include <cstring>
+#include <algorithm>
 #include <list>
 #include <mutex>
 #include <string>
@@ -177,6 +178,15 @@ int get_plan(const aai_request &rq, int band0, int band1, Plan **out)
     return AAI_OK;
 }
 
+constexpr int kMaxGridZ = 65535;
+
+// element offset into a typed source buffer
+const void *src_at(const void *base, int srcType, int64_t elements)
+{
+    const int64_t esz = srcType == aai::SRC_U8 ? 1 : srcType == aai::SRC_U16 ? 2 : 4;
+    return static_cast<const char *>(base) + elements * esz;
+}
+
 int enqueue(const aai_request &rq, int batch, const void *dSrc, int srcType, int64_t srcStride, int64_t srcImageStride,
             float *dDst, int64_t dstStride, int64_t dstImageStride, hipStream_t stream, int band0 = -1, int band1 = -1)
 {
@@ -208,11 +218,17 @@ int enqueue(const aai_request &rq, int batch, const void *dSrc, int srcType, int
         a.outStrideA = t.flipA ? -sa : sa;
         a.outStrideB = t.flipB ? -sb : sb;
         a.outBase = (t.flipA ? (int64_t)(t.nA - 1) * sa : 0) + (t.flipB ? (int64_t)(t.nB - 1) * sb : 0);
-        e = aai::launch_axis(a, dSrc, srcType, sv, dDst, dv, batch, stream, &name);
+        e = hipSuccess;
+        for (int b0 = 0; b0 < batch && e == hipSuccess; b0 += kMaxGridZ)       // grid.z carries the batch
+            e = aai::launch_axis(a, src_at(dSrc, srcType, (int64_t)b0 * srcImageStride), srcType, sv, dDst + (int64_t)b0 * dstImageStride, dv,
+                                 std::min(batch - b0, kMaxGridZ), stream, &name);
     } else {
         aai::RotLaunch r = aai::make_rot_launch(g, rq.mode, rq.policy);
         if (band0 >= 0) { r.dyBase = band0; r.dyEnd = band1; r.srcRow0 = p->srcRow0; }
-        e = aai::launch_rotated(r, dSrc, srcType, sv, dDst, dv, batch, p->dFlags, stream, &name);
+        e = hipSuccess;
+        for (int b0 = 0; b0 < batch && e == hipSuccess; b0 += kMaxGridZ)
+            e = aai::launch_rotated(r, src_at(dSrc, srcType, (int64_t)b0 * srcImageStride), srcType, sv, dDst + (int64_t)b0 * dstImageStride, dv,
+                                    std::min(batch - b0, kMaxGridZ), p->dFlags, stream, &name);
     }
     g_lastKernel = name;
     if (e != hipSuccess) return hip_fail(e, name);
@@ -362,7 +378,7 @@ static int resample_batch_device_typed(const aai_request *req, int32_t batch, co
     int rc = check_request(req);
     if (rc != AAI_OK) return rc;
     if (src_dtype != AAI_DTYPE_F32 && src_dtype != AAI_DTYPE_U8 && src_dtype != AAI_DTYPE_U16) return fail(AAI_ERR_BAD_ARGUMENT, "Unknown source element type.");
-    if (batch < 0 || batch > 65535) return fail(AAI_ERR_BAD_ARGUMENT, "Batch must be in [0, 65535].");
+    if (batch < 0) return fail(AAI_ERR_BAD_ARGUMENT, "Negative batch.");      // any size: enqueue() splits batches beyond the grid.z limit
     // argument errors are reported before the device is touched, like the reference reports them first
     {
         aai::Geometry g;

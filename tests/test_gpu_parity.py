@@ -369,6 +369,14 @@ def test_batch_equals_singles_and_strides(gpu):
     rq2 = gpu.make_request(W, H, 3, 1, ((W - 1) / 2, (H - 1) / 2), 33.0)
     b2 = _device_run(gpu, rq2, src, batch=B)
     assert torch.equal(b2[3], _device_run(gpu, rq2, src[3]))
+    # more images than one launch's grid.z can carry (65,535): the entry splits the batch
+    big = 70000
+    tiny = torch.rand((big, 8, 8), dtype=torch.float32, device="cuda")
+    for ang in (0.0, 30.0):
+        rq3 = gpu.make_request(8, 8, 2, 1, (3.5, 3.5), ang)
+        b3 = _device_run(gpu, rq3, tiny, batch=big)
+        for b in (0, 65534, 65535, 65536, big - 1):
+            assert torch.equal(b3[b], _device_run(gpu, rq3, tiny[b])), (ang, b)
 
 
 def test_pipelined_host_batch_equals_single_calls(gpu):
