@@ -197,14 +197,14 @@ __global__ __launch_bounds__(kBlock) void aai_sample_kernel(RotLaunch r, const T
     double X, Y;
     pixel_centre(r, dx, dy, X, Y);
     // continuous virtual coordinates -> continuous original-image coordinates (pixel centres at integers)
-    const double sc = (double)r.scale;
+    const double is = r.invScale;      // a multiplication instead of two fp64 divisions per pixel
     double sx, sy;
     switch (r.quadrant) {
     default:
-    case 0: sx = (X + 0.5) / sc - 0.5;             sy = (Y + 0.5) / sc - 0.5;             break;
-    case 1: sx = (Y + 0.5) / sc - 0.5;             sy = (r.mW - 1 - X + 0.5) / sc - 0.5;  break;
-    case 2: sx = (r.mW - 1 - X + 0.5) / sc - 0.5;  sy = (r.mH - 1 - Y + 0.5) / sc - 0.5;  break;
-    case 3: sx = (r.mH - 1 - Y + 0.5) / sc - 0.5;  sy = (X + 0.5) / sc - 0.5;             break;
+    case 0: sx = (X + 0.5) * is - 0.5;             sy = (Y + 0.5) * is - 0.5;             break;
+    case 1: sx = (Y + 0.5) * is - 0.5;             sy = (r.mW - 1 - X + 0.5) * is - 0.5;  break;
+    case 2: sx = (r.mW - 1 - X + 0.5) * is - 0.5;  sy = (r.mH - 1 - Y + 0.5) * is - 0.5;  break;
+    case 3: sx = (r.mH - 1 - Y + 0.5) * is - 0.5;  sy = (X + 0.5) * is - 0.5;             break;
     }
     float v = 0.f;
     if (!(sx < -0.5 || sx > r.W - 0.5 || sy < -0.5 || sy > r.H - 0.5)) {
