@@ -65,6 +65,8 @@ SYMBOLS = {
     "aai_resample_batch_device_f32": (ctypes.c_int, [_RQ, ctypes.c_int32, _P, _I64, _I64, _P, _I64, _I64, _P]),
     "aai_resample_batch_device": (ctypes.c_int, [_RQ, ctypes.c_int32, _P, ctypes.c_int32, _I64, _I64, _P, _I64, _I64, _P]),
     "aai_resample_host": (ctypes.c_int, [_RQ, _P, ctypes.c_int32, _I64, _P, _I64, _LY]),
+    "aai_resample_interleaved_device": (ctypes.c_int, [_RQ, ctypes.c_int32, ctypes.c_int32, _P, ctypes.c_int32, _I64, _I64, _P, _I64, _I64, _P]),
+    "aai_resample_interleaved_host": (ctypes.c_int, [_RQ, ctypes.c_int32, _P, ctypes.c_int32, _I64, _P, _I64, _LY]),
     "aai_host_alloc": (ctypes.c_int, [ctypes.POINTER(ctypes.c_void_p), ctypes.c_uint64]),
     "aai_host_free": (ctypes.c_int, [_P]),
     "aai_resample_batch_host": (ctypes.c_int, [_RQ, ctypes.c_int32, _P, ctypes.c_int32, _I64, _I64, _P, _I64, _I64, _LY]),

@@ -180,6 +180,38 @@ def resample_batch_host(srcs, src_resolution, dst_resolution, src_isocenter, rot
     return rc, "", dst, out_lay
 
 
+def resample_interleaved_host(src, src_resolution, dst_resolution, src_isocenter, rotation_angle,
+                              mode=L.MODE_AREA, policy=L.POLICY_REFERENCE):
+    """Interleaved channels from host memory (aai_resample_interleaved_host): src is [H, W, C] float32 / uint8 / uint16
+    with C in 1..4, the result [dH, dW, C] float32.  Returns (code, message, dst or None, Layout or None)."""
+    lib = L.load()
+    a = np.ascontiguousarray(src)
+    if a.ndim != 3 or a.dtype not in _NP_DTYPES:
+        raise ValueError("src must be an [H, W, C] array of float32, uint8 or uint16")
+    H, W, C = a.shape
+    rq = make_request(W, H, src_resolution, dst_resolution, src_isocenter, rotation_angle, mode, policy)
+    rc, msg, lay = query(rq)
+    if rc != L.OK:
+        return rc, msg, None, None
+    dst = np.empty((lay.dst_height, lay.dst_width, C), dtype=np.float32)
+    out_lay = L.Layout()
+    rc = lib.aai_resample_interleaved_host(ctypes.byref(rq), C, a.ctypes.data, _NP_DTYPES[a.dtype], W * C,
+                                           dst.ctypes.data, max(lay.dst_width * C, 1), ctypes.byref(out_lay))
+    if rc != L.OK:
+        return rc, last_error(), None, None
+    return rc, "", dst, out_lay
+
+
+def resample_interleaved_device(request, channels, src_ptr, src_stride, dst_ptr, dst_stride, stream=0, batch=1,
+                                src_image_stride=0, dst_image_stride=0, src_dtype=L.DTYPE_F32):
+    """Device-resident interleaved images (aai_resample_interleaved_device); strides in elements."""
+    lib = L.load()
+    rc = lib.aai_resample_interleaved_device(ctypes.byref(request), int(batch), int(channels), src_ptr, int(src_dtype), src_stride,
+                                             src_image_stride, dst_ptr, dst_stride, dst_image_stride, stream)
+    if rc != L.OK:
+        raise AaiError(rc, last_error())
+
+
 def resample_device(request, src_ptr, src_stride, dst_ptr, dst_stride, stream=0, batch=None,
                     src_image_stride=0, dst_image_stride=0, src_dtype=L.DTYPE_F32):
     """Device-resident path: raw device pointers (ints) and a hipStream_t handle (int, 0 = default).

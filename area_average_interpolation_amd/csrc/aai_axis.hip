@@ -151,13 +151,14 @@ __device__ __forceinline__ void park(float *line, int lane, int shift, const Col
 }
 
 // Horizontal pass for one output pixel from the wave's LDS line (indices relative to the strip origin).
-__device__ __forceinline__ float horizontal_pass(const float *line, int off, int span, float wF, float wM, float wL)
+// `step` = distance between taps in elements (1, or the channel count of an interleaved source).
+__device__ __forceinline__ float horizontal_pass(const float *line, int off, int span, float wF, float wM, float wL, int step = 1)
 {
     float s = wF * line[off];
     if (span > 0) {
         float mid = 0.f;
-        for (int i = 1; i < span; ++i) mid += line[off + i];
-        s += wM * mid + wL * line[off + span];
+        for (int i = 1; i < span; ++i) mid += line[off + i * step];
+        s += wM * mid + wL * line[off + span * step];
     }
     return s;
 }
@@ -171,7 +172,8 @@ __device__ __forceinline__ float horizontal_pass(const float *line, int off, int
 // time, whereas tall workgroups open 2048 independent streams 32 KiB apart.  A software-pipelined variant
 // (two output rows in flight per wave) bought 2 % at 2+ rows per workgroup and nothing at 1, so the kernel
 // keeps the simple form: 4 source rows (4 KiB per wave) in flight, latency covered by 8 waves per SIMD.
-template <bool NT, typename T>
+// CH: interleaved channels (AxisLaunch::tapStep / outChan); false compiles the single-channel kernel unchanged.
+template <bool NT, typename T, bool CH>
 __global__ __launch_bounds__(kWaves * 64) void aai_axis_kernel(AxisLaunch a, const AxisEntry *__restrict__ laneTab,
                                                                 const AxisEntry *__restrict__ rowTab, const AxisStrip *__restrict__ strips,
                                                                 const T *__restrict__ src, ImageView sv,
@@ -199,8 +201,14 @@ __global__ __launch_bounds__(kWaves * 64) void aai_axis_kernel(AxisLaunch a, con
     const int rowStep = interleave ? (int)gridDim.y : 1;
     const int rowEnd = interleave ? a.nB : min(rowStart + rowsPerBlock, a.nB);
     const int nOut = st.k1 - st.k0;
+    // interleaved channels: taps `step` elements apart, dst element of lane entry ka split into (pixel, channel)
+    const int step = CH ? a.tapStep : 1;
+    auto taps = [&](const Win &c) { return CH ? (c.s1 - c.s0) / step : c.s1 - c.s0; };        // number of taps - 1
+    auto out_off = [&](int ka) -> int64_t {
+        return CH ? (int64_t)(ka / a.outChan) * a.outStrideA + ka % a.outChan : (int64_t)ka * a.outStrideA;
+    };
 
-    if (nOut <= 64 && (a.outStrideB == 1 || a.outStrideB == -1) && rowStep == 1) {
+    if (!CH && nOut <= 64 && (a.outStrideB == 1 || a.outStrideB == -1) && rowStep == 1) {
         // Quadrants 1 and 3 (pre-rotation by 90 / 270 degrees): the lane axis runs along dst y, so the output
         // rows of this workgroup are CONSECUTIVE DST COLUMNS of each lane's dst row.  Keep eight of them in
         // registers and write them as two 16-byte stores per lane instead of eight 4-byte stores a row pitch
@@ -253,7 +261,7 @@ __global__ __launch_bounds__(kWaves * 64) void aai_axis_kernel(AxisLaunch a, con
                     if (kb0 + j < rowEnd) orow[(int64_t)(kb0 + j) * a.outStrideB] = acc[j];
             }
         }
-    } else if (nOut <= 256 && (a.outStrideB == 1 || a.outStrideB == -1) && rowStep == 1) {
+    } else if (!CH && nOut <= 256 && (a.outStrideB == 1 || a.outStrideB == -1) && rowStep == 1) {
         // Quadrants 1 and 3 at ratios below 4 (65..256 outputs per strip): up to four outputs per lane, interleaved
         // across the wave (k = k0 + lane + 64 q, so that neighbouring lanes read neighbouring windows of the LDS line),
         // each holding FOUR consecutive dst columns in registers = one 16-byte store per output and chunk instead of
@@ -305,15 +313,15 @@ __global__ __launch_bounds__(kWaves * 64) void aai_axis_kernel(AxisLaunch a, con
         // its window description stays in registers for all rows.
         const bool live = lane < nOut;
         const Win c = load_win(laneTab, live ? st.k0 + lane : st.k0);
-        const int off = c.s0 - st.x0, span = c.s1 - c.s0;
-        const int64_t outCol = (int64_t)(st.k0 + lane) * a.outStrideA;
+        const int off = c.s0 - st.x0, span = taps(c);
+        const int64_t outCol = out_off(st.k0 + lane);
         for (int kb = rowStart; kb < rowEnd; kb += rowStep) {
             const Win e = load_win(rowTab, kb);
             const Cols v = vertical_pass<NT, T>(img, sv.rowStride, colc, e);
             __builtin_amdgcn_wave_barrier();
             park(line, lane, shift, v);
             __builtin_amdgcn_wave_barrier();
-            if (live) out[outCol + (int64_t)kb * a.outStrideB] = horizontal_pass(line, off, span, c.wF, c.wM, c.wL);
+            if (live) out[outCol + (int64_t)kb * a.outStrideB] = horizontal_pass(line, off, span, c.wF, c.wM, c.wL, step);
         }
     } else if (nOut <= 256 && a.outStrideA == 1) {
         // Ratios between 1 and 4 (65..256 outputs per strip) with dst x along the lanes: four consecutive
@@ -329,11 +337,11 @@ __global__ __launch_bounds__(kWaves * 64) void aai_axis_kernel(AxisLaunch a, con
             park(line, lane, shift, v);
             __builtin_amdgcn_wave_barrier();
             f4 r;
-            r.x = horizontal_pass(line, c0.s0 - st.x0, c0.s1 - c0.s0, c0.wF, c0.wM, c0.wL);
-            r.y = horizontal_pass(line, c1.s0 - st.x0, c1.s1 - c1.s0, c1.wF, c1.wM, c1.wL);
-            r.z = horizontal_pass(line, c2.s0 - st.x0, c2.s1 - c2.s0, c2.wF, c2.wM, c2.wL);
-            r.w = horizontal_pass(line, c3.s0 - st.x0, c3.s1 - c3.s0, c3.wF, c3.wM, c3.wL);
-            float *o = out + kq + (int64_t)kb * a.outStrideB;
+            r.x = horizontal_pass(line, c0.s0 - st.x0, taps(c0), c0.wF, c0.wM, c0.wL, step);
+            r.y = horizontal_pass(line, c1.s0 - st.x0, taps(c1), c1.wF, c1.wM, c1.wL, step);
+            r.z = horizontal_pass(line, c2.s0 - st.x0, taps(c2), c2.wF, c2.wM, c2.wL, step);
+            r.w = horizontal_pass(line, c3.s0 - st.x0, taps(c3), c3.wF, c3.wM, c3.wL, step);
+            float *o = out + kq + (int64_t)kb * a.outStrideB;           // outStrideA == 1: lane order = dst element order
             if (nq == 4) *reinterpret_cast<f4u *>(o) = r;
             else {
                 if (nq > 0) o[0] = r.x;
@@ -351,8 +359,8 @@ __global__ __launch_bounds__(kWaves * 64) void aai_axis_kernel(AxisLaunch a, con
             __builtin_amdgcn_wave_barrier();
             for (int k = st.k0 + lane; k < st.k1; k += 64) {
                 const Win c = load_win(laneTab, k);
-                out[(int64_t)k * a.outStrideA + (int64_t)kb * a.outStrideB] =
-                    horizontal_pass(line, c.s0 - st.x0, c.s1 - c.s0, c.wF, c.wM, c.wL);
+                out[out_off(k) + (int64_t)kb * a.outStrideB] =
+                    horizontal_pass(line, c.s0 - st.x0, taps(c), c.wF, c.wM, c.wL, step);
             }
         }
     }
@@ -430,15 +438,17 @@ __global__ __launch_bounds__(256) void aai_axis_wide_kernel(AxisLaunch a, const 
     if (ka >= a.nA || kb >= a.nB) return;
     const Win c = load_win(a.laneTab, ka), e = load_win(a.rowTab, kb);
     const T *img = src + (int64_t)blockIdx.z * sv.imageStride;
+    const int step = a.tapStep > 1 ? a.tapStep : 1;              // interleaved channels: taps `step` elements apart
+    const int oc = a.outChan > 1 ? a.outChan : 1;
     float acc = 0.f;
     for (int y = e.s0; y <= e.s1; ++y) {
         const T *row = img + (int64_t)y * sv.rowStride;
         float h = 0.f;
-        for (int x = c.s0; x <= c.s1; ++x)
+        for (int x = c.s0; x <= c.s1; x += step)
             h += row_weight(c, x) * (float)row[x];
         acc += row_weight(e, y) * h;
     }
-    dst[(int64_t)blockIdx.z * dv.imageStride + a.outBase + (int64_t)ka * a.outStrideA + (int64_t)kb * a.outStrideB] = acc;
+    dst[(int64_t)blockIdx.z * dv.imageStride + a.outBase + (int64_t)(ka / oc) * a.outStrideA + ka % oc + (int64_t)kb * a.outStrideB] = acc;
 }
 
 }  // namespace
@@ -487,14 +497,14 @@ static hipError_t launch_axis_typed(const AxisLaunch &a, const T *src, ImageView
         const int64_t stripBlocks = (int64_t)((a.nStrips + kWaves - 1) / kWaves) * batch;
         while (rows < want && stripBlocks * ((a.nB + 2 * rows - 1) / (2 * rows)) >= 2048) rows *= 2;
     }
-    if (a.outStrideA != 1 && a.outStrideA != -1) {
+    if (a.transposed) {
         // transposed quadrants: 2, 4 or 8 dst columns per lane and store; about 16 source rows per workgroup is the
         // sweet spot between DRAM page locality and store width (8192^2 at 90 degrees: 4:1 5.9 TB/s at 4 rows vs 5.2 at
         // 8; 8:1 6.0 at 2 vs 4.8 at 8; profiles/r01_axis_transposed.txt)
         rows = a.maxRowSpan >= 8 ? 2 : (a.maxRowSpan >= 3 ? 4 : 8);
         if (a.maxOutputsPerStrip > 64) rows = a.maxRowSpan >= 2 ? 4 : 16;     // the four-column path (ratios below 4)
     }
-    if ((a.outStrideA == 1 || a.outStrideA == -1) && a.maxOutputsPerStrip > 128 && a.maxOutputsPerStrip <= 256) rows = 32;      // ratios below 2: write-heavy
+    if (!a.transposed && a.maxOutputsPerStrip > 128 && a.maxOutputsPerStrip <= 256) rows = 32;      // ratios below 2: write-heavy
     if (const char *env = getenv("AAI_AXIS_TUNE")) {
         auto get = [&](const char *key, int &v) {
             const char *p = strstr(env, key);
@@ -505,7 +515,7 @@ static hipError_t launch_axis_typed(const AxisLaunch &a, const T *src, ImageView
     }
     // (measured, profiles/r01_axis_transposed.txt: wins below 2:1 -- 1:1 1.8 -> 2.3 TB/s, x4 up-sampling 1.2 -> 1.6 --
     // and loses 5-14 % to the four-column register path between 2:1 and 4:1)
-    int tile = (a.outStrideA != 1 && a.outStrideA != -1) && (a.outStrideB == 1 || a.outStrideB == -1) && a.maxOutputsPerStrip > 128 &&
+    int tile = a.transposed && a.tapStep <= 1 && (a.outStrideB == 1 || a.outStrideB == -1) && a.maxOutputsPerStrip > 128 &&
                a.maxOutputsPerStrip <= 256;
     if (const char *env = getenv("AAI_AXIS_TUNE"))
         if (const char *p = strstr(env, "tile=")) tile = tile && atoi(p + 5) != 0;
@@ -523,8 +533,13 @@ static hipError_t launch_axis_typed(const AxisLaunch &a, const T *src, ImageView
     while (blocksY > 65535) { rows *= 2; blocksY = (a.nB + rows - 1) / rows; }
     dim3 grid(blocksX, blocksY, batch), block(kWaves * 64);
     if (kernelName) *kernelName = "aai_axis_kernel";
-    if (nt) hipLaunchKernelGGL((aai_axis_kernel<true, T>), grid, block, 0, stream, a, a.laneTab, a.rowTab, a.strips, src, sv, dst, dv, rows, interleave);
-    else hipLaunchKernelGGL((aai_axis_kernel<false, T>), grid, block, 0, stream, a, a.laneTab, a.rowTab, a.strips, src, sv, dst, dv, rows, interleave);
+    if (a.tapStep > 1) {
+        if (nt) hipLaunchKernelGGL((aai_axis_kernel<true, T, true>), grid, block, 0, stream, a, a.laneTab, a.rowTab, a.strips, src, sv, dst, dv, rows, interleave);
+        else hipLaunchKernelGGL((aai_axis_kernel<false, T, true>), grid, block, 0, stream, a, a.laneTab, a.rowTab, a.strips, src, sv, dst, dv, rows, interleave);
+    } else {
+        if (nt) hipLaunchKernelGGL((aai_axis_kernel<true, T, false>), grid, block, 0, stream, a, a.laneTab, a.rowTab, a.strips, src, sv, dst, dv, rows, interleave);
+        else hipLaunchKernelGGL((aai_axis_kernel<false, T, false>), grid, block, 0, stream, a, a.laneTab, a.rowTab, a.strips, src, sv, dst, dv, rows, interleave);
+    }
     return hipGetLastError();
 }
 

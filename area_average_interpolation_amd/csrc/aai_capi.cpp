@@ -6,7 +6,9 @@
 // linked or loaded here.
 #include <hip/hip_runtime.h>
 
+#include <climits>
 #include <cmath>
+#include <cstdint>
 #include <cstring>
 #include <algorithm>
 #include <list>
@@ -46,6 +48,7 @@ int hip_fail(hipError_t e, const char *what)
 struct Plan {
     aai_request key{};
     int band0 = -1, band1 = -1;      // dst row band this plan serves (-1: the whole image)
+    int channels = 1;                // interleaved channels the K1 tables were built for
     int srcRow0 = 0, srcRow1 = 0;     // source rows the band reads; the source pointer addresses row srcRow0
     int device = -1;
     aai::Geometry g;
@@ -117,12 +120,12 @@ void fill_layout(const aai::Geometry &g, int kernel, aai_layout *out)
 
 // Finds or builds the plan for (request, current device).  Returns a pointer valid until evicted; callers
 // hold g_planMutex for the duration of the launch (launches only enqueue, so this is short).
-int get_plan(const aai_request &rq, int band0, int band1, Plan **out)
+int get_plan(const aai_request &rq, int band0, int band1, int channels, Plan **out)
 {
     int dev = -1;
     AAI_HIP(hipGetDevice(&dev));
     for (auto it = g_plans.begin(); it != g_plans.end(); ++it) {
-        if (it->device == dev && it->band0 == band0 && it->band1 == band1 && same_request(it->key, rq)) {
+        if (it->device == dev && it->band0 == band0 && it->band1 == band1 && it->channels == channels && same_request(it->key, rq)) {
             g_plans.splice(g_plans.begin(), g_plans, it);
             *out = &g_plans.front();
             return AAI_OK;
@@ -135,10 +138,10 @@ int get_plan(const aai_request &rq, int band0, int band1, Plan **out)
 
     g_plans.emplace_front();
     Plan &p = g_plans.front();
-    p.key = rq; p.band0 = band0; p.band1 = band1; p.device = dev; p.g = g; p.kernel = pick_kernel(rq, g);
+    p.key = rq; p.band0 = band0; p.band1 = band1; p.channels = channels; p.device = dev; p.g = g; p.kernel = pick_kernel(rq, g);
     p.srcRow0 = 0; p.srcRow1 = g.H;
     if (p.kernel == AAI_KERNEL_AXIS) {
-        aai::build_axis_tables(g, rq.mode, p.tabs);
+        aai::build_axis_tables(g, rq.mode, p.tabs, channels);
         if (band0 >= 0) aai::restrict_axis_tables_to_band(g, p.tabs, band0, band1, p.srcRow0, p.srcRow1);
         if (p.tabs.wide) p.kernel = AAI_KERNEL_AXIS_WIDE;
         auto upload = [&](const void *h, size_t bytes, void **d) -> hipError_t {
@@ -188,15 +191,17 @@ const void *src_at(const void *base, int srcType, int64_t elements)
 }
 
 int enqueue(const aai_request &rq, int batch, const void *dSrc, int srcType, int64_t srcStride, int64_t srcImageStride,
-            float *dDst, int64_t dstStride, int64_t dstImageStride, hipStream_t stream, int band0 = -1, int band1 = -1)
+            float *dDst, int64_t dstStride, int64_t dstImageStride, hipStream_t stream, int band0 = -1, int band1 = -1,
+            int channels = 1)
 {
     std::lock_guard<std::mutex> lock(g_planMutex);
     Plan *p = nullptr;
-    int rc = get_plan(rq, band0, band1, &p);
+    int rc = get_plan(rq, band0, band1, channels, &p);
     if (rc != AAI_OK) return rc;
     const aai::Geometry &g = p->g;
-    if (srcStride < g.W) return fail(AAI_ERR_BAD_ARGUMENT, "Source stride smaller than the image width.");
-    if (dstStride < g.dW) return fail(AAI_ERR_BAD_ARGUMENT, "Destination stride smaller than the output width.");
+    // strides are in elements; an interleaved pixel takes `channels` of them
+    if (srcStride < (int64_t)g.W * channels) return fail(AAI_ERR_BAD_ARGUMENT, "Source stride smaller than the image width.");
+    if (dstStride < (int64_t)g.dW * channels) return fail(AAI_ERR_BAD_ARGUMENT, "Destination stride smaller than the output width.");
     if (g.dW == 0 || g.dH == 0 || batch == 0) return AAI_OK;
 
     aai::ImageView sv{srcStride, srcImageStride}, dv{dstStride, dstImageStride};
@@ -207,17 +212,22 @@ int enqueue(const aai_request &rq, int batch, const void *dSrc, int srcType, int
         aai::AxisLaunch a{};
         a.laneTab = p->dLane; a.rowTab = p->dRow; a.strips = p->dStrips;
         a.nA = t.nA; a.nB = t.nB; a.nStrips = (int)t.strips.size();
-        a.srcW = g.W; a.srcH = g.H;
+        a.srcW = g.W * channels; a.srcH = g.H;      // elements of a source row
         a.wide = t.wide ? 1 : 0;
         a.maxRowSpan = t.maxRowSpan;
         a.rowsShared = t.rowsShared ? 1 : 0;
         a.maxOutputsPerStrip = t.maxOutputsPerStrip;
         // (ka,kb) -> dst element: the lane axis is dst x unless the quadrant transposes; flips run an axis
         // backwards
-        const int64_t sa = t.transposed ? dstStride : 1, sb = t.transposed ? 1 : dstStride;
+        // (with interleaved channels a dst pixel is `channels` elements wide and lane entry ka = pixel * channels + channel)
+        const int nApix = t.nA / channels;
+        const int64_t sa = t.transposed ? dstStride : channels, sb = t.transposed ? channels : dstStride;
         a.outStrideA = t.flipA ? -sa : sa;
         a.outStrideB = t.flipB ? -sb : sb;
-        a.outBase = (t.flipA ? (int64_t)(t.nA - 1) * sa : 0) + (t.flipB ? (int64_t)(t.nB - 1) * sb : 0);
+        a.outBase = (t.flipA ? (int64_t)(nApix - 1) * sa : 0) + (t.flipB ? (int64_t)(t.nB - 1) * sb : 0);
+        a.transposed = t.transposed ? 1 : 0;
+        a.tapStep = channels; a.outChan = channels;
+        if (channels > 1 && !t.transposed && !t.flipA) { a.outStrideA = 1; a.outChan = 1; }     // lane order = dst element order
         e = hipSuccess;
         for (int b0 = 0; b0 < batch && e == hipSuccess; b0 += kMaxGridZ)       // grid.z carries the batch
             e = aai::launch_axis(a, src_at(dSrc, srcType, (int64_t)b0 * srcImageStride), srcType, sv, dDst + (int64_t)b0 * dstImageStride, dv,
@@ -225,6 +235,7 @@ int enqueue(const aai_request &rq, int batch, const void *dSrc, int srcType, int
     } else {
         aai::RotLaunch r = aai::make_rot_launch(g, rq.mode, rq.policy);
         if (band0 >= 0) { r.dyBase = band0; r.dyEnd = band1; r.srcRow0 = p->srcRow0; }
+        r.chan = channels;
         e = hipSuccess;
         for (int b0 = 0; b0 < batch && e == hipSuccess; b0 += kMaxGridZ)
             e = aai::launch_rotated(r, src_at(dSrc, srcType, (int64_t)b0 * srcImageStride), srcType, sv, dDst + (int64_t)b0 * dstImageStride, dv,
@@ -496,6 +507,72 @@ int aai_resample_host(const aai_request *req, const void *src, int32_t src_dtype
         if (rc != AAI_OK) { cleanup(); return rc; }
         AAI_HIP_C(hipStreamSynchronize(nullptr));
         AAI_HIP_C(hipMemcpy2D(dst, sizeof(float) * dst_stride, dDst, sizeof(float) * g.dW, sizeof(float) * g.dW, g.dH, hipMemcpyDeviceToHost));
+    }
+    cleanup();
+#undef AAI_HIP_C
+    if (layout) fill_layout(g, resolved_kernel(*req, g), layout);
+    g_lastError.clear();
+    return AAI_OK;
+}
+
+int aai_resample_interleaved_device(const aai_request *req, int32_t batch, int32_t channels,
+                                    const void *d_src, int32_t src_dtype, int64_t src_stride, int64_t src_image_stride,
+                                    float *d_dst, int64_t dst_stride, int64_t dst_image_stride, void *stream)
+{
+    int rc = check_request(req);
+    if (rc != AAI_OK) return rc;
+    if (channels < 1 || channels > 4) return fail(AAI_ERR_BAD_ARGUMENT, "Channels must be 1..4.");
+    if (batch < 0) return fail(AAI_ERR_BAD_ARGUMENT, "Negative batch.");
+    if (src_dtype != AAI_DTYPE_F32 && src_dtype != AAI_DTYPE_U8 && src_dtype != AAI_DTYPE_U16) return fail(AAI_ERR_BAD_ARGUMENT, "Unknown source element type.");
+    aai::Geometry g;
+    std::string msg;
+    rc = aai::make_geometry(*req, g, msg);
+    if (rc != AAI_OK) return fail(rc, msg);
+    if ((int64_t)g.W * channels > INT32_MAX / 2 || (int64_t)g.dW * channels > INT32_MAX / 2) return fail(AAI_ERR_TOO_LARGE, "Image too large.");
+    if (batch > 0 && g.dW > 0 && g.dH > 0 && (!d_src || !d_dst)) return fail(AAI_ERR_BAD_ARGUMENT, "Null image pointer.");
+    rc = require_device();
+    if (rc != AAI_OK) return rc;
+    rc = enqueue(*req, batch, d_src, src_dtype, src_stride, src_image_stride, d_dst, dst_stride, dst_image_stride, (hipStream_t)stream, -1, -1, channels);
+    if (rc == AAI_OK) g_lastError.clear();
+    return rc;
+}
+
+int aai_resample_interleaved_host(const aai_request *req, int32_t channels, const void *src, int32_t src_dtype, int64_t src_stride,
+                                  float *dst, int64_t dst_stride, aai_layout *layout)
+{
+    int rc = check_request(req);
+    if (rc != AAI_OK) return rc;
+    if (channels < 1 || channels > 4) return fail(AAI_ERR_BAD_ARGUMENT, "Channels must be 1..4.");
+    const size_t esz = src_dtype == AAI_DTYPE_F32 ? 4 : src_dtype == AAI_DTYPE_U8 ? 1 : src_dtype == AAI_DTYPE_U16 ? 2 : 0;
+    if (!esz) return fail(AAI_ERR_BAD_ARGUMENT, "Unknown source element type.");
+    aai::Geometry g;
+    std::string msg;
+    rc = aai::make_geometry(*req, g, msg);
+    if (rc != AAI_OK) return fail(rc, msg);
+    if (!src || !dst) return fail(AAI_ERR_BAD_ARGUMENT, "Null image pointer.");
+    const int64_t rowIn = (int64_t)g.W * channels, rowOut = (int64_t)g.dW * channels;      // elements per dense row
+    if (rowIn > INT32_MAX / 2 || rowOut > INT32_MAX / 2) return fail(AAI_ERR_TOO_LARGE, "Image too large.");
+    if (src_stride < rowIn) return fail(AAI_ERR_BAD_ARGUMENT, "Source stride smaller than the image width.");
+    if (dst_stride < rowOut) return fail(AAI_ERR_BAD_ARGUMENT, "Destination stride smaller than the output width.");
+    rc = require_device();
+    if (rc != AAI_OK) return rc;
+    void *dSrc = nullptr;
+    float *dDst = nullptr;
+    const size_t nDst = (size_t)rowOut * g.dH;
+    auto cleanup = [&]() { if (dSrc) (void)hipFree(dSrc); if (dDst) (void)hipFree(dDst); };
+#define AAI_HIP_C(call)                                                        \
+    do {                                                                       \
+        hipError_t e__ = (call);                                               \
+        if (e__ != hipSuccess) { cleanup(); return hip_fail(e__, #call); }     \
+    } while (0)
+    AAI_HIP_C(hipMalloc(&dSrc, esz * (size_t)rowIn * g.H + 16));
+    AAI_HIP_C(hipMemcpy2D(dSrc, esz * rowIn, src, esz * src_stride, esz * rowIn, g.H, hipMemcpyHostToDevice));
+    if (nDst) {
+        AAI_HIP_C(hipMalloc((void **)&dDst, sizeof(float) * nDst));
+        rc = enqueue(*req, 1, dSrc, src_dtype, rowIn, 0, dDst, rowOut, 0, nullptr, -1, -1, channels);
+        if (rc != AAI_OK) { cleanup(); return rc; }
+        AAI_HIP_C(hipStreamSynchronize(nullptr));
+        AAI_HIP_C(hipMemcpy2D(dst, sizeof(float) * dst_stride, dDst, sizeof(float) * rowOut, sizeof(float) * rowOut, g.dH, hipMemcpyDeviceToHost));
     }
     cleanup();
 #undef AAI_HIP_C

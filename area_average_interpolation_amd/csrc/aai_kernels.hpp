@@ -30,6 +30,11 @@ struct AxisLaunch {
     int maxRowSpan;             // largest number of source rows any output row needs
     int rowsShared;             // consecutive output rows share a source row
     int maxOutputsPerStrip;
+    // interleaved channels (1 = none): lane entries are (pixel, channel) pairs over the source row's ELEMENTS; the taps of
+    // one entry are tapStep elements apart; dst element = outBase + (ka / outChan)*outStrideA + ka % outChan + kb*outStrideB
+    // (outChan = 1 when the lane order is already the dst element order: not transposed, not flipped)
+    int tapStep, outChan;
+    int transposed;             // the lane axis runs along dst y (quadrants 1 and 3)
 };
 hipError_t launch_axis(const AxisLaunch &a, const void *src, int srcType, ImageView sv, float *dst, ImageView dv,
                        int batch, hipStream_t stream, const char **kernelName);

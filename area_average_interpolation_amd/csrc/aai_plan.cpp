@@ -124,7 +124,7 @@ RotLaunch make_rot_launch(const Geometry &g, int mode, int policy)
     r.reach = g.side * std::sqrt(2.0) / 2 + 1;
     r.dW = g.dW; r.dH = g.dH; r.mW = g.mW; r.mH = g.mH; r.W = g.W; r.H = g.H;
     r.scale = g.scale; r.quadrant = g.quadrant; r.mode = mode; r.policy = policy;
-    r.dyBase = 0; r.dyEnd = g.dH; r.srcRow0 = 0;
+    r.dyBase = 0; r.dyEnd = g.dH; r.srcRow0 = 0; r.chan = 1;
     r.invScale = 1.0 / g.scale;
     const double c = g.cs, s = g.sn, h = 0.5 * g.side;
     r.c = c; r.s = s; r.h = h;
@@ -271,6 +271,40 @@ AxisEntry fold(const VirtRange &vr, int m, int scale, bool reversed, double othe
 
 }  // namespace
 
+// Greedy strips: consecutive lane-axis outputs whose windows fit in STRIP_COLS source columns (elements of a source
+// row: with interleaved channels a pixel takes `channels` of them).
+static void build_axis_strips(AxisTables &t, int srcRowElements)
+{
+    t.strips.clear();
+    t.maxOutputsPerStrip = 0;
+    t.wide = srcRowElements < 4;      // the strip kernel loads whole 4-column vectors
+    const int n = (int)t.lane.size();
+    int k = 0;
+    while (k < n) {
+        AxisStrip s{};
+        s.k0 = k; s.x0 = t.lane[k].s0;
+        int x0 = s.x0;
+        int kk = k;
+        while (kk < n) {
+            // windows are ascending, but parked empties may sit lower; keep x0 = min.  Ascending windows make the
+            // last one the binding constraint for the (possibly lowered) origin.
+            const int lo2 = std::min(x0, t.lane[kk].s0);
+            const int hi2 = t.lane[kk].s1;
+            if (hi2 - lo2 + 1 > STRIP_COLS) break;
+            // at most 256 outputs per strip: the kernel then keeps four window descriptions per lane in
+            // registers and stores 16 bytes per lane (up-sampling would otherwise put >1000 outputs in a strip)
+            if (kk - k >= 256) break;
+            x0 = lo2;
+            ++kk;
+        }
+        if (kk == k) { t.wide = true; kk = k + 1; }   // a single window wider than a strip
+        s.x0 = x0; s.k1 = kk;
+        t.maxOutputsPerStrip = std::max(t.maxOutputsPerStrip, s.k1 - s.k0);
+        t.strips.push_back(s);
+        k = kk;
+    }
+}
+
 // Derived data of a (possibly band-restricted) pair of tables: parked empties, row statistics, strips.
 static void finalize_axis_tables(const Geometry &g, AxisTables &t)
 {
@@ -288,39 +322,10 @@ static void finalize_axis_tables(const Geometry &g, AxisTables &t)
     for (size_t i = 0; i + 1 < t.row.size(); ++i)
         if (t.row[i].wMid + t.row[i].wFirst > 0.f && t.row[i + 1].wMid + t.row[i + 1].wFirst > 0.f && t.row[i].s1 >= t.row[i + 1].s0) { t.rowsShared = true; break; }
 
-    // Greedy strips: consecutive lane-axis outputs whose windows fit in STRIP_COLS source columns.
-    t.strips.clear();
-    t.maxOutputsPerStrip = 0;
-    t.wide = g.W < 4;      // the strip kernel loads whole 4-column vectors
-    int k = 0;
-    while (k < t.nA) {
-        AxisStrip s{};
-        s.k0 = k; s.x0 = t.lane[k].s0;
-        int x0 = s.x0;
-        int kk = k;
-        while (kk < t.nA) {
-            const int lo2 = std::min(x0, t.lane[kk].s0);
-            const int hi2 = t.lane[kk].s1;
-            // windows are ascending, but parked empties may sit lower; keep x0 = min
-            int need = hi2 - lo2 + 1;
-            // also every earlier window must still fit from the (possibly lowered) origin: ascending
-            // windows make the last one the binding constraint
-            if (need > STRIP_COLS) break;
-            // at most 256 outputs per strip: the kernel then keeps four window descriptions per lane in
-            // registers and stores 16 bytes per lane (up-sampling would otherwise put >1000 outputs in a strip)
-            if (kk - k >= 256) break;
-            x0 = lo2;
-            ++kk;
-        }
-        if (kk == k) { t.wide = true; kk = k + 1; }   // a single window wider than a strip
-        s.x0 = x0; s.k1 = kk;
-        t.maxOutputsPerStrip = std::max(t.maxOutputsPerStrip, s.k1 - s.k0);
-        t.strips.push_back(s);
-        k = kk;
-    }
+    build_axis_strips(t, g.W);
 }
 
-void build_axis_tables(const Geometry &g, int mode, AxisTables &t)
+void build_axis_tables(const Geometry &g, int mode, AxisTables &t, int channels)
 {
     // Which virtual axis reads which source axis (Source.cpp:164-167):
     //   q0: X -> src x (+), Y -> src y (+)      q1: X -> src y (-), Y -> src x (+)
@@ -357,6 +362,24 @@ void build_axis_tables(const Geometry &g, int mode, AxisTables &t)
     t.nA = (int)t.lane.size(); t.nB = (int)t.row.size();
 
     finalize_axis_tables(g, t);
+    t.channels = 1;
+    if (channels > 1) {
+        // Interleaved channels: the source row is W * channels elements wide and the lane
+        // axis runs over its elements.  Entry (p, ch) = pixel entry p moved to the elements of channel ch: taps
+        // `channels` elements apart (AxisLaunch::tapStep), same weights.  Windows stay ascending, so strips work as before.
+        std::vector<AxisEntry> wideLane;
+        wideLane.reserve(t.lane.size() * channels);
+        for (const AxisEntry &e : t.lane)
+            for (int ch = 0; ch < channels; ++ch) {
+                AxisEntry x = e;
+                x.s0 = e.s0 * channels + ch; x.s1 = e.s1 * channels + ch;
+                wideLane.push_back(x);
+            }
+        t.lane.swap(wideLane);
+        t.nA = (int)t.lane.size();
+        t.channels = channels;
+        build_axis_strips(t, g.W * channels);
+    }
 }
 
 // Keep only the dst rows [row0,row1) (row bands of one image on different GPUs, or an

@@ -85,10 +85,11 @@ struct AxisTables {
     int maxRowSpan = 0;              // largest s1-s0+1 over the row table
     bool rowsShared = false;         // consecutive output rows read a common source row (windows not pixel-aligned)
     int maxOutputsPerStrip = 0;
+    int channels = 1;                // interleaved channels: the lane table has nA = pixels * channels entries, taps `channels` apart
 };
 
 // mode: AAI_MODE_AREA (overlap lengths) or AAI_MODE_FAST (centre counts).  Only for g.axisAligned.
-void build_axis_tables(const Geometry &g, int mode, AxisTables &t);
+void build_axis_tables(const Geometry &g, int mode, AxisTables &t, int channels = 1);
 void restrict_axis_tables_to_band(const Geometry &g, AxisTables &t, int row0, int row1, int &srcRow0, int &srcRow1);
 
 // Source rows [srcRow0, srcRow1) that dst rows [row0,row1) of a rotated-lattice request can touch (conservative).

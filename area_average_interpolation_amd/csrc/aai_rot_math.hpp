@@ -45,6 +45,7 @@ struct RotLaunch {
     double rc, rs, rhi, r2cs;       // 1/c, 1/s, 1/hi, 1/(2 c s)
     // the reference's edge-line parametrisation (Source.cpp:229-240), for the strict replay only
     int runs;                       // area mode: walk each source row as boundary / interior / boundary runs (large footprints)
+    int chan;                       // interleaved channels per pixel (1 = a plain image): element = pixel offset * chan + channel
     int lt45;                       // reduced angle < 45 degrees
     double tsn, tcs, ttn;           // tmpSin, tmpCos, tmpTan (tan snapped to 0 below DBL_EPSILON)
 };
@@ -272,7 +273,8 @@ AAI_HD double wedge_pair_area(const RotLaunch &f, double lx, double ly, bool nea
 }
 
 // virtual pixel (X,Y) -> element offset in the original image (Source.cpp:164-167)
-AAI_HD int64_t virt_offset(const RotLaunch &r, int X, int Y, int64_t rowStride)
+// (pitch = elements per pixel: the channel count of an interleaved image; rowStride is in elements either way)
+AAI_HD int64_t virt_offset(const RotLaunch &r, int X, int Y, int64_t rowStride, int pitch = 1)
 {
     int sx, sy;
     switch (r.quadrant) {
@@ -286,7 +288,7 @@ AAI_HD int64_t virt_offset(const RotLaunch &r, int X, int Y, int64_t rowStride)
         sx = (int)((sx + 0.5) * r.invScale);
         sy = (int)((sy + 0.5) * r.invScale);
     }
-    return (int64_t)(sy - r.srcRow0) * rowStride + sx;
+    return (int64_t)(sy - r.srcRow0) * rowStride + (int64_t)sx * pitch;
 }
 
 // With scale == 1 the virtual lattice IS the source image seen through a quarter-turn.  A "line" is the set of virtual

@@ -169,12 +169,13 @@ __global__ __launch_bounds__(kRotBlock) void aai_rotated_runs_kernel(RotLaunch r
 }
 
 // ---- K4/K5 -------------------------------------------------------------------------------------------
+// img already points at the channel; pitch = elements per pixel
 template <typename T>
-__device__ __forceinline__ float tap(const T *img, int64_t rowStride, int W, int H, int x, int y, int srcRow0 = 0)
+__device__ __forceinline__ float tap(const T *img, int64_t rowStride, int W, int H, int x, int y, int srcRow0 = 0, int pitch = 1)
 {
     x = min(max(x, 0), W - 1);
     y = min(max(y, 0), H - 1);
-    return (float)img[(int64_t)(y - srcRow0) * rowStride + x];
+    return (float)img[(int64_t)(y - srcRow0) * rowStride + (int64_t)x * pitch];
 }
 
 __device__ __forceinline__ void keys(float t, float w[4])
@@ -206,31 +207,39 @@ __global__ __launch_bounds__(kBlock) void aai_sample_kernel(RotLaunch r, const T
     case 2: sx = (r.mW - 1 - X + 0.5) * is - 0.5;  sy = (r.mH - 1 - Y + 0.5) * is - 0.5;  break;
     case 3: sx = (r.mH - 1 - Y + 0.5) * is - 0.5;  sy = (X + 0.5) * is - 0.5;             break;
     }
-    float v = 0.f;
-    if (!(sx < -0.5 || sx > r.W - 0.5 || sy < -0.5 || sy > r.H - 0.5)) {
-        const double fx = floor(sx), fy = floor(sy);
-        const int ix = (int)fx, iy = (int)fy;
-        const float tx = (float)(sx - fx), ty = (float)(sy - fy);
+    const int chan = r.chan > 1 ? r.chan : 1;          // interleaved channels share the taps' positions and weights
+    float *out = dst + (int64_t)blockIdx.z * dv.imageStride + (int64_t)(dy - r.dyBase) * dv.rowStride + (int64_t)dx * chan;
+    if (sx < -0.5 || sx > r.W - 0.5 || sy < -0.5 || sy > r.H - 0.5) {
+        for (int c = 0; c < chan; ++c) out[c] = 0.f;
+        return;
+    }
+    const double fx = floor(sx), fy = floor(sy);
+    const int ix = (int)fx, iy = (int)fy;
+    const float tx = (float)(sx - fx), ty = (float)(sy - fy);
+    float wx[4], wy[4];
+    if (MODE != AAI_MODE_BILINEAR) { keys(tx, wx); keys(ty, wy); }
+    for (int c = 0; c < chan; ++c) {
+        const T *ch = img + c;
+        float v;
         if (MODE == AAI_MODE_BILINEAR) {
-            const float v00 = tap(img, sv.rowStride, r.W, r.H, ix, iy, r.srcRow0), v10 = tap(img, sv.rowStride, r.W, r.H, ix + 1, iy, r.srcRow0);
-            const float v01 = tap(img, sv.rowStride, r.W, r.H, ix, iy + 1, r.srcRow0), v11 = tap(img, sv.rowStride, r.W, r.H, ix + 1, iy + 1, r.srcRow0);
-            const float top = v00 + (v10 - v00) * tx, bot = v01 + (v11 - v01) * tx;
-            v = top + (bot - top) * ty;
+            const float v00 = tap(ch, sv.rowStride, r.W, r.H, ix, iy, r.srcRow0, chan), v10 = tap(ch, sv.rowStride, r.W, r.H, ix + 1, iy, r.srcRow0, chan);
+            const float v01 = tap(ch, sv.rowStride, r.W, r.H, ix, iy + 1, r.srcRow0, chan), v11 = tap(ch, sv.rowStride, r.W, r.H, ix + 1, iy + 1, r.srcRow0, chan);
+            // explicit fused multiply-adds: the same rounding whatever the compiler does with the channel loop
+            const float top = fmaf(v10 - v00, tx, v00), bot = fmaf(v11 - v01, tx, v01);
+            v = fmaf(bot - top, ty, top);
         } else {
-            float wx[4], wy[4];
-            keys(tx, wx); keys(ty, wy);
             float acc = 0.f;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 float row = 0.f;
 #pragma unroll
-                for (int i = 0; i < 4; ++i) row += wx[i] * tap(img, sv.rowStride, r.W, r.H, ix - 1 + i, iy - 1 + j, r.srcRow0);
-                acc += wy[j] * row;
+                for (int i = 0; i < 4; ++i) row = fmaf(wx[i], tap(ch, sv.rowStride, r.W, r.H, ix - 1 + i, iy - 1 + j, r.srcRow0, chan), row);
+                acc = fmaf(wy[j], row, acc);
             }
             v = acc;
         }
+        out[c] = v;
     }
-    dst[(int64_t)blockIdx.z * dv.imageStride + (int64_t)(dy - r.dyBase) * dv.rowStride + dx] = v;
 }
 
 }  // namespace
@@ -268,7 +277,16 @@ static hipError_t launch_rotated_typed(const RotLaunch &r, const T *src, int src
     dim3 grid((r.dW + 15) / 16, (r.dyEnd - r.dyBase + 15) / 16, batch);
     // production pass; then, only for geometries whose scan found knife edges (waveFlags != NULL), the fix-up
     // pass over the same grid
-    if (r.mode == AAI_MODE_FAST) {
+    if (r.chan > 1) {
+        // interleaved channels: the per-position kernels with the areas shared between the channels
+        if (r.mode == AAI_MODE_FAST) {
+            if (kernelName) *kernelName = "aai_rotated_kernel<fast, channels>";
+            hipLaunchKernelGGL((aai_rotated_kernel<AAI_MODE_FAST, false, T, true>), grid, dim3(kRotBlock), 0, stream, r, src, sv, dst, dv, waveFlags);
+        } else {
+            if (kernelName) *kernelName = "aai_rotated_kernel<area, channels>";
+            hipLaunchKernelGGL((aai_rotated_kernel<AAI_MODE_AREA, false, T, true>), grid, dim3(kRotBlock), 0, stream, r, src, sv, dst, dv, waveFlags);
+        }
+    } else if (r.mode == AAI_MODE_FAST) {
         if (kernelName) *kernelName = "aai_rotated_kernel<fast>";
         hipLaunchKernelGGL((aai_rotated_kernel<AAI_MODE_FAST, false, T>), grid, dim3(kRotBlock), 0, stream, r, src, sv, dst, dv, waveFlags);
     } else {

@@ -26,13 +26,38 @@ __device__ __forceinline__ void load4(const T *p, float v[4])
     v[0] = (float)p[0]; v[1] = (float)p[1]; v[2] = (float)p[2]; v[3] = (float)p[3];
 }
 
+// the `chan` (2..4) interleaved channels of one pixel as fp32: ONE load instruction for fp32 images (neighbouring lanes
+// are L source pixels apart, so the number of load instructions, each touching ~64 cache lines, is what the
+// multi-channel kernels are bound by: three 4-byte loads per pixel made RGB 2.4x slower than one channel)
+__device__ __forceinline__ void load_pixel(const float *p, int chan, float v[4])
+{
+    typedef float f2u __attribute__((ext_vector_type(2), aligned(4)));
+    typedef float f3u __attribute__((ext_vector_type(3), aligned(4)));
+    typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+    v[2] = 0.f; v[3] = 0.f;
+    if (chan == 3) { const f3u q = *reinterpret_cast<const f3u *>(p); v[0] = q.x; v[1] = q.y; v[2] = q.z; }
+    else if (chan == 4) { const f4u q = *reinterpret_cast<const f4u *>(p); v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w; }
+    else { const f2u q = *reinterpret_cast<const f2u *>(p); v[0] = q.x; v[1] = q.y; }
+}
+template <typename T>
+__device__ __forceinline__ void load_pixel(const T *p, int chan, float v[4])
+{
+    v[0] = (float)p[0]; v[1] = (float)p[1];
+    v[2] = chan > 2 ? (float)p[2] : 0.f;
+    v[3] = chan > 3 ? (float)p[3] : 0.f;
+}
+
 // STRICT = false: the production pass.  Every pair is answered by the fast path.
 // STRICT = true: the fix-up pass over the same grid, launched only when the plan's knife-edge scan
 //   (aai_knife_scan_kernel, run once per geometry) found flagged waves.  Waves whose flag is clear exit at
 //   once; flagged waves recompute their 64 pixels, replaying the reference's own arithmetic
 //   (aai_strict.hpp) for the knife-edge
 //   pairs.  In generic geometry -- every BASELINE configuration -- no flag is ever raised.
-template <int MODE, bool STRICT, typename T>
+// MULTI: interleaved channels (RotLaunch::chan = 2..4).  The geometry -- classification and overlap areas -- is computed
+// once per (dst, src) pair and applied to every channel; false compiles the single-channel kernel unchanged.
+constexpr int kMaxChan = 4;
+
+template <int MODE, bool STRICT, typename T, bool MULTI = false>
 __global__ __launch_bounds__(kRotBlock) void aai_rotated_kernel(RotLaunch r, const T *__restrict__ src, ImageView sv,
                                                               float *__restrict__ dst, ImageView dv,
                                                               const unsigned *__restrict__ waveFlags)
@@ -52,10 +77,31 @@ __global__ __launch_bounds__(kRotBlock) void aai_rotated_kernel(RotLaunch r, con
     // (Staging the tile's source footprint in LDS with coalesced loads was measured and rejected: cfg3 1452 ->
     // 1744 us, cfg3 fast 435 -> 560 us, cfg5 17.3 -> 21.4 ms.  The per-lane 4-byte loads hit L1/L2 and are not the
     // limiter; the extra pass, the barrier and the lost occupancy cost more.)
-    auto fetch = [&](int X, int Y) -> double { return (double)img[virt_offset(r, X, Y, sv.rowStride)]; };
+    const int chan = MULTI ? r.chan : 1;
+    // acc[c] += w * value of channel c at virtual pixel (X, Y)
+    auto add_pixel = [&](double (&acc)[MULTI ? kMaxChan : 1], double w, int X, int Y) {
+        const T *p = img + virt_offset(r, X, Y, sv.rowStride, chan);
+        if (!MULTI) acc[0] += w * (double)p[0];
+        else {
+            float v[kMaxChan];
+            load_pixel(p, chan, v);
+#pragma unroll
+            for (int c = 0; c < kMaxChan; ++c)
+                if (c < chan) acc[c] += w * (double)v[c];
+        }
+    };
+    // write acc[c] * scale (or 0 when the pixel got no weight) to the dst pixel's channels
+    auto store_pixel = [&](float *out, const double (&acc)[MULTI ? kMaxChan : 1], bool any, double denom) {
+        out[0] = any ? (float)(acc[0] / denom) : 0.f;
+        if (MULTI) {
+#pragma unroll
+            for (int c = 1; c < kMaxChan; ++c)
+                if (c < chan) out[c] = any ? (float)(acc[c] / denom) : 0.f;
+        }
+    };
 
     if (valid) {
-        float *out = dst + (int64_t)blockIdx.z * dv.imageStride + (int64_t)(dy - r.dyBase) * dv.rowStride + dx;
+        float *out = dst + (int64_t)blockIdx.z * dv.imageStride + (int64_t)(dy - r.dyBase) * dv.rowStride + (int64_t)dx * chan;
 
         double px, py;
         pixel_centre(r, dx, dy, px, py);
@@ -76,8 +122,23 @@ __global__ __launch_bounds__(kRotBlock) void aai_rotated_kernel(RotLaunch r, con
             // 2e-9 of an edge would make the integer bounds ambiguous -- exactly the pixels the knife-edge scan
             // flags and the fix-up pass (the per-pixel loop below) redoes.
             int count = 0;
-            double acc = 0.0;
-            if (r.scale == 1 && min(r.mW, r.mH) >= 4) {
+            double acc[MULTI ? kMaxChan : 1] = {};
+            if (MULTI && r.scale == 1) {
+                // lines = source rows (see below); one vector load per pixel brings all its channels
+                const bool cols = virt_lines_are_columns(r);
+                const int u0 = cols ? x0 : y0, u1 = cols ? x1 : y1;
+                const int nIn = cols ? r.mH : r.mW;
+                const double pIn = cols ? py : px, pOut = cols ? px : py;
+                for (int u = u0; u <= u1; ++u) {
+                    double lo, hi;
+                    centre_interval(r, cols, u - pOut, lo, hi);
+                    const double da = fmax(ceil(pIn + lo), 0.0), db = fmin(floor(pIn + hi), (double)(nIn - 1));
+                    if (!(da <= db)) continue;
+                    const int wa = (int)da, wb = (int)db;
+                    for (int w = wa; w <= wb; ++w) add_pixel(acc, 1.0, cols ? u : w, cols ? w : u);
+                    count += wb - wa + 1;
+                }
+            } else if (!MULTI && r.scale == 1 && min(r.mW, r.mH) >= 4) {
                 // Without replication a "line" of virtual pixels is a source row (virt_line): walk the lines that way
                 // round -- rows in quadrants 0/2, columns in 1/3 -- and fetch each interval four source columns at a
                 // time (one dword-aligned 16-byte load per lane): neighbouring lanes are L source pixels apart, so
@@ -102,11 +163,11 @@ __global__ __launch_bounds__(kRotBlock) void aai_rotated_kernel(RotLaunch r, con
                         load4(srow + cc, v);
 #pragma unroll
                         for (int j = 0; j < 4; ++j)
-                            if (cc + j >= c0 && cc + j <= sb) { if (j & 1) acc1 += (double)v[j]; else acc += (double)v[j]; }
+                            if (cc + j >= c0 && cc + j <= sb) { if (j & 1) acc1 += (double)v[j]; else acc[0] += (double)v[j]; }
                     }
                     count += wb - wa + 1;
                 }
-                acc += acc1;
+                acc[0] += acc1;
             } else
             for (int Y = y0; Y <= y1; ++Y) {
                 const double ey = Y - py;
@@ -117,15 +178,15 @@ __global__ __launch_bounds__(kRotBlock) void aai_rotated_kernel(RotLaunch r, con
                 const double da = fmax(ceil(px + lo), 0.0), db = fmin(floor(px + hi), (double)(r.mW - 1));
                 if (!(da <= db)) continue;
                 const int xa = (int)da, xb = (int)db;
-                for (int X = xa; X <= xb; ++X) acc += fetch(X, Y);
+                for (int X = xa; X <= xb; ++X) add_pixel(acc, 1.0, X, Y);
                 count += xb - xa + 1;
             }
-            *out = count > 0 ? (float)(acc / count) : 0.f;      // Source.cpp:905
+            store_pixel(out, acc, count > 0, (double)count);      // Source.cpp:905
         } else if (MODE == AAI_MODE_FAST) {
             // closed-square membership of the pixel centre with the reference's parameter slack
             const double lim = r.h + DBL_EPSILON * r.side;
             int count = 0;
-            double acc = 0.0;
+            double acc[MULTI ? kMaxChan : 1] = {};
             for (int Y = y0; Y <= y1; ++Y)
                 for (int X = x0; X <= x1; ++X) {
                     const double ex = X - px, ey = Y - py;
@@ -141,13 +202,14 @@ __global__ __launch_bounds__(kRotBlock) void aai_rotated_kernel(RotLaunch r, con
                             in = strict_centre_inside(pc, sv4);
                         }
                     }
-                    if (in) { ++count; acc += fetch(X, Y); }
+                    if (in) { ++count; add_pixel(acc, 1.0, X, Y); }
                 }
-            *out = count > 0 ? (float)(acc / count) : 0.f;      // Source.cpp:905
+            store_pixel(out, acc, count > 0, (double)count);      // Source.cpp:905
         } else {
             // Pass 1 over the window: pairs that are outside, inside, or cut by a single edge line are settled
             // on the spot (two dot products + a closed form); the rest -- pixels near a dst vertex -- are queued.
-            double sumA = 0.0, sumVA = 0.0;
+            double sumA = 0.0;
+            double sumVA[MULTI ? kMaxChan : 1] = {};
             int nPend = 0;
             const bool packable = (x1 - x0) < 256 && (y1 - y0) < 128;
             for (int Y = y0; Y <= y1; ++Y) {
@@ -175,7 +237,7 @@ __global__ __launch_bounds__(kRotBlock) void aai_rotated_kernel(RotLaunch r, con
                     }
                     if (area != 0.0) {
                         sumA += area;
-                        sumVA += area * fetch(X, Y);
+                        add_pixel(sumVA, area, X, Y);
                     }
                 }
             }
@@ -195,10 +257,10 @@ __global__ __launch_bounds__(kRotBlock) void aai_rotated_kernel(RotLaunch r, con
                 }
                 if (area != 0.0) {
                     sumA += area;
-                    sumVA += area * fetch(X, Y);
+                    add_pixel(sumVA, area, X, Y);
                 }
             }
-            *out = DBL_EPSILON < fabs(sumA) ? (float)(sumVA / sumA) : 0.f;   // Source.cpp:577
+            store_pixel(out, sumVA, DBL_EPSILON < fabs(sumA), sumA);   // Source.cpp:577
         }
     }
 }

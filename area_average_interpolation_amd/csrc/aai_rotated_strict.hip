@@ -12,6 +12,13 @@ template <typename T>
 static void fixup_typed(const RotLaunch &r, dim3 grid, const T *src, ImageView sv, float *dst, ImageView dv,
                         const unsigned *waveFlags, hipStream_t stream)
 {
+    if (r.chan > 1) {      // interleaved channels
+        if (r.mode == AAI_MODE_FAST)
+            hipLaunchKernelGGL((aai_rotated_kernel<AAI_MODE_FAST, true, T, true>), grid, dim3(kRotBlock), 0, stream, r, src, sv, dst, dv, waveFlags);
+        else
+            hipLaunchKernelGGL((aai_rotated_kernel<AAI_MODE_AREA, true, T, true>), grid, dim3(kRotBlock), 0, stream, r, src, sv, dst, dv, waveFlags);
+        return;
+    }
     if (r.mode == AAI_MODE_FAST)
         hipLaunchKernelGGL((aai_rotated_kernel<AAI_MODE_FAST, true, T>), grid, dim3(kRotBlock), 0, stream, r, src, sv, dst, dv, waveFlags);
     else

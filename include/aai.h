@@ -153,6 +153,19 @@ int aai_resample_batch_device(const aai_request *req, int32_t batch, const void 
 int aai_resample_host(const aai_request *req, const void *src, int32_t src_dtype, int64_t src_stride,
                       float *dst, int64_t dst_stride, aai_layout *layout);
 
+/* ---- interleaved channels --------------------------------------------------------------
+ * Images whose pixels hold `channels` (1..4) interleaved values, e.g. RGB scans: element (x, y, c) of image b is
+ * src[b*src_image_stride + y*src_stride + x*channels + c], and the output has the same layout (fp32).  Strides are in
+ * ELEMENTS (src_stride >= width*channels, dst_stride >= dst_width*channels).  Every channel gets exactly the result
+ * of the single-channel call on that channel alone; the rotated-lattice kernels compute the overlap areas once per
+ * pixel pair for all channels, the axis-aligned kernel reads every source byte once.  The reference only knows
+ * single-channel images (IMG, Source.cpp:31). */
+int aai_resample_interleaved_device(const aai_request *req, int32_t batch, int32_t channels,
+                                    const void *d_src, int32_t src_dtype, int64_t src_stride, int64_t src_image_stride,
+                                    float *d_dst, int64_t dst_stride, int64_t dst_image_stride, void *stream);
+int aai_resample_interleaved_host(const aai_request *req, int32_t channels, const void *src, int32_t src_dtype, int64_t src_stride,
+                                  float *dst, int64_t dst_stride, aai_layout *layout);
+
 /* ---- host batches, pipelined ("pinned-memory streaming pipeline") ----------------------------
  * `batch` images in HOST memory (image b at src + b*src_image_stride elements, written to dst + b*dst_image_stride):
  * the images go through three device slots, each with its own HIP stream (upload -> kernel -> download in stream

@@ -65,6 +65,69 @@ static void emu_axis(const Geometry &g, int mode, const float *src, int64_t srcS
     }
 }
 
+// Interleaved channels through the axis-aligned path (mirrors enqueue() in csrc/aai_capi.cpp and the CH = true kernel):
+// lane entries are (pixel, channel) pairs over the source row's elements, taps `C` elements apart.
+static int emu_axis_channels(const Geometry &g, int mode, int C, const float *src, float *dst)
+{
+    AxisTables t;
+    build_axis_tables(g, mode, t, C);
+    if (t.channels != C || t.nA != (t.transposed ? g.dH : g.dW) * C) return 1;
+    const int64_t srcStride = (int64_t)g.W * C, dstStride = (int64_t)g.dW * C;
+    const int nApix = t.nA / C;
+    const int64_t sa = t.transposed ? dstStride : C, sb = t.transposed ? C : dstStride;
+    int64_t strideA = t.flipA ? -sa : sa;
+    const int64_t strideB = t.flipB ? -sb : sb;
+    const int64_t base = (t.flipA ? (int64_t)(nApix - 1) * sa : 0) + (t.flipB ? (int64_t)(t.nB - 1) * sb : 0);
+    int outChan = C;
+    if (C > 1 && !t.transposed && !t.flipA) { strideA = 1; outChan = 1; }
+    auto out_off = [&](int ka) { return base + (int64_t)(ka / outChan) * strideA + ka % outChan; };
+    // strips: in order, <= 256 entries, windows inside (unless the per-pixel fallback serves the request)
+    int next = 0;
+    for (const auto &s : t.strips) {
+        if (s.k0 != next || s.k1 <= s.k0 || s.k1 - s.k0 > 256) return 2;
+        for (int k = s.k0; k < s.k1; ++k) {
+            if ((t.lane[k].s1 - t.lane[k].s0) % C != 0 || t.lane[k].s0 % C != k % C) return 3;
+            if (!t.wide && (t.lane[k].s0 < s.x0 || t.lane[k].s1 >= s.x0 + STRIP_COLS)) return 4;
+        }
+        next = s.k1;
+    }
+    if (next != t.nA) return 5;
+    std::vector<float> line(STRIP_COLS);
+    for (const AxisStrip &st : t.strips)
+        for (int kb = 0; kb < t.nB; ++kb) {
+            const AxisEntry &e = t.row[kb];
+            if (!t.wide)
+                for (int i = 0; i < STRIP_COLS; ++i) {
+                    const int col = st.x0 + i;
+                    float acc = 0.f;
+                    for (int y = e.s0; y <= e.s1; ++y) acc += row_w(e, y) * (col < g.W * C ? src[(int64_t)y * srcStride + col] : 0.f);
+                    line[i] = acc;
+                }
+            for (int k = st.k0; k < st.k1; ++k) {
+                const AxisEntry &c = t.lane[k];
+                float s;
+                if (t.wide) {
+                    s = 0.f;
+                    for (int y = e.s0; y <= e.s1; ++y) {
+                        float h = 0.f;
+                        for (int x = c.s0; x <= c.s1; x += C) h += row_w(c, x) * src[(int64_t)y * srcStride + x];
+                        s += row_w(e, y) * h;
+                    }
+                } else {
+                    const int off = c.s0 - st.x0, span = (c.s1 - c.s0) / C;
+                    s = c.wFirst * line[off];
+                    if (span > 0) {
+                        float mid = 0.f;
+                        for (int i = 1; i < span; ++i) mid += line[off + i * C];
+                        s += c.wMid * mid + c.wLast * line[off + span * C];
+                    }
+                }
+                dst[out_off(k) + (int64_t)kb * strideB] = s;
+            }
+        }
+    return 0;
+}
+
 static int g_forceGeneral = 0;   // test hook: route every cut pair through pair_area (cross-checks the closed form)
 static int g_strict = 1;         // test hook: 0 = production pass only, 1 = production + knife-edge fix-up pass
 static long g_knifePairs = 0, g_knifePixels = 0, g_missedPairs = 0;   // missed: pair-level knife in a pixel the per-pixel test did not flag
@@ -266,6 +329,18 @@ long aai_emu_check_line_runs(const aai_request *rq)
             }
         }
     return bad;
+}
+
+// Axis-aligned requests with C interleaved channels: src is [H][W][C], dst [dH][dW][C].  0 on success, > 0 = an
+// invariant of the channel tables failed, < 0 = bad request / not axis-aligned.
+int aai_emu_resample_channels(const aai_request *rq, int C, const float *src, float *dst)
+{
+    Geometry g;
+    std::string msg;
+    if (make_geometry(*rq, g, msg) != AAI_OK) return -1;
+    if (!g.axisAligned || (rq->mode != AAI_MODE_AREA && rq->mode != AAI_MODE_FAST)) return -2;
+    if (!g.dW || !g.dH) return 0;
+    return emu_axis_channels(g, rq->mode, C, src, dst);
 }
 
 void aai_emu_force_general(int on) { g_forceGeneral = on; }

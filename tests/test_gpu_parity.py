@@ -411,6 +411,67 @@ def test_pipelined_host_batch_equals_single_calls(gpu):
     assert rc != 0 and "resolution" in msg
 
 
+def test_interleaved_channels_equal_planar_calls(gpu, po):
+    """interleaved [H, W, C] images.  Every channel must equal the single-channel call on that
+    channel alone, bit for bit -- the axis-aligned kernel in all four quadrants and all its output paths, the rotated
+    area / fast kernels (incl. a knife-edge angle and the large-footprint regime), the samplers, 8-/16-bit sources --
+    and one case is checked against the oracle directly."""
+    rng = np.random.default_rng(41)
+    cases = [  # W, H, srcRes, dstRes, angle, mode
+        (517, 40, 4, 1, 0.0, 1), (517, 40, 4, 1, 180.0, 1), (300, 33, 3, 1, 90.0, 1), (301, 21, 2, 1, 270.0, 2),
+        (259, 17, 1, 1, 0.0, 1), (70, 50, 1, 2, 90.0, 1), (40, 30, 1, 4, 180.0, 1), (1030, 9, 8, 1, 0.0, 2),
+        (3000, 12, 700, 1, 0.0, 1), (3, 50, 2, 1, 0.0, 1), (5, 700, 3, 1, 270.0, 1),
+        (128, 96, 3, 1, 17.5, 1), (96, 128, 3, 1, 200.0, 2), (64, 64, 2, 1, 45.0, 1), (120, 90, 8, 1, 33.3, 1),
+        (96, 96, 6, 1, 107.5, 2), (64, 48, 1, 3, 30.0, 1), (80, 60, 2, 1, 17.5, 3), (80, 60, 1, 2, 300.0, 4),
+    ]
+    for k, (W, H, sr, dr, ang, mode) in enumerate(cases):
+        C = 1 + k % 4
+        dt = (np.float32, np.uint8, np.uint16)[k % 3] if mode in (1, 2) else np.float32
+        iso = ((W - 1) / 2, (H - 1) / 2) if k % 2 else (float(rng.uniform(0, W)), float(rng.uniform(0, H)))
+        if dt == np.float32:
+            src = rng.random((H, W, C)).astype(np.float32)
+        else:
+            src = rng.integers(0, np.iinfo(dt).max + 1, size=(H, W, C)).astype(dt)
+        rc, msg, dst, lay = gpu.resample_interleaved_host(src, sr, dr, iso, ang, mode=mode)
+        assert rc == 0, (k, msg)
+        assert dst.shape == (lay.dst_height, lay.dst_width, C)
+        for c in range(C):
+            rc, msg, planar, giso, _ = gpu.resample_host(np.ascontiguousarray(src[:, :, c]), sr, dr, iso, ang, mode=mode)
+            assert rc == 0, msg
+            if W * C >= 4 > W:
+                # the planar image is too narrow for the strip kernel (per-pixel fallback), the interleaved one is not:
+                # same weights, different summation order
+                assert rel_err(dst[:, :, c], planar, floor=1e-3 * float(src.max())).max() <= 1e-6, (k, c)
+            else:
+                assert np.array_equal(dst[:, :, c], planar), (k, W, H, sr, dr, ang, mode, C, c, dt, gpu.last_kernel())
+    # against the oracle itself
+    src = rng.random((90, 120, 3)).astype(np.float32)
+    rc, msg, dst, lay = gpu.resample_interleaved_host(src, 3.0, 1.0, (59.5, 44.5), 17.5)
+    assert rc == 0, msg
+    for c in range(3):
+        gold = po.oracle_run(po.MODE_EXACT, src[:, :, c].astype(np.float64), 3.0, 1.0, (59.5, 44.5), 17.5)
+        assert rel_err(dst[:, :, c], gold.dst).max() <= TOL and np.array_equal(gold.dst == 0, dst[:, :, c] == 0)
+    # device entry: batch of interleaved images with padded strides
+    import torch
+    B, W, H, C = 3, 200, 150, 3
+    rq = gpu.make_request(W, H, 4, 1, ((W - 1) / 2, (H - 1) / 2), 33.0)
+    rc, msg, lay = gpu.query(rq)
+    hsrc = rng.random((B, H, W + 5, C)).astype(np.float32)
+    dsrc = torch.from_numpy(hsrc).cuda()
+    ddst = torch.full((B, lay.dst_height, lay.dst_width + 2, C), -5.0, dtype=torch.float32, device="cuda")
+    gpu.resample_interleaved_device(rq, C, dsrc.data_ptr(), (W + 5) * C, ddst.data_ptr(), (lay.dst_width + 2) * C,
+                                    torch.cuda.current_stream().cuda_stream, batch=B, src_image_stride=H * (W + 5) * C,
+                                    dst_image_stride=lay.dst_height * (lay.dst_width + 2) * C)
+    torch.cuda.synchronize()
+    got = ddst.cpu().numpy()
+    for b in range(B):
+        rc, msg, ref, _ = gpu.resample_interleaved_host(np.ascontiguousarray(hsrc[b, :, :W, :]), 4, 1, ((W - 1) / 2, (H - 1) / 2), 33.0)
+        assert np.array_equal(got[b, :, :lay.dst_width, :], ref), b
+    assert float(got[:, :, lay.dst_width:, :].max()) == -5.0          # padding untouched
+    with pytest.raises(gpu.AaiError):
+        gpu.resample_interleaved_device(rq, 5, dsrc.data_ptr(), (W + 5) * C, ddst.data_ptr(), (lay.dst_width + 2) * C)
+
+
 def test_row_bands_equal_full_image(gpu):
     """dst row bands computed from buffers holding only their source footprint are
     bit-identical to the same rows of the full-image call -- every kernel family, all quadrants."""
