@@ -67,10 +67,12 @@ __global__ __launch_bounds__(kRotBlock) void aai_knife_scan_kernel(RotLaunch r, 
 // (1.26 L + 1)^2 window positions and waits for one dependent load per overlapping position, which at L >= 6 leaves
 // it latency-bound (profiles/r01_rotated_envelope.txt).  Sums are reassociated (interior first), a difference of
 // ~1e-16 relative.  The knife-edge fix-up pass is unchanged: flagged waves are redone by the strict kernel.
-template <typename T>
+// MULTI: interleaved channels -- the same runs, every pixel's channels fetched by one vector load (load_pixel).
+template <typename T, bool MULTI>
 __global__ __launch_bounds__(kRotBlock) void aai_rotated_runs_kernel(RotLaunch r, const T *__restrict__ src, ImageView sv,
                                                                    float *__restrict__ dst, ImageView dv)
 {
+    constexpr int NC = MULTI ? kMaxChan : 1;
     __shared__ unsigned short pending[kRotListCap][kRotBlock];
 
     const int tid = threadIdx.x;
@@ -78,7 +80,8 @@ __global__ __launch_bounds__(kRotBlock) void aai_rotated_runs_kernel(RotLaunch r
     const int dy = r.dyBase + blockIdx.y * 16 + (tid >> 4);
     if (!(dx < r.dW && dy < r.dyEnd)) return;          // no barrier below
     const T *img = src + (int64_t)blockIdx.z * sv.imageStride;
-    float *out = dst + (int64_t)blockIdx.z * dv.imageStride + (int64_t)(dy - r.dyBase) * dv.rowStride + dx;
+    const int chan = MULTI ? r.chan : 1;
+    float *out = dst + (int64_t)blockIdx.z * dv.imageStride + (int64_t)(dy - r.dyBase) * dv.rowStride + (int64_t)dx * chan;
 
     double px, py;
     pixel_centre(r, dx, dy, px, py);
@@ -86,7 +89,8 @@ __global__ __launch_bounds__(kRotBlock) void aai_rotated_runs_kernel(RotLaunch r
     const int x0 = max(0, (int)floor(px - hb + 0.5 - AAI_KNIFE_GUARD)), x1 = min(r.mW - 1, (int)ceil(px + hb - 0.5 + AAI_KNIFE_GUARD));
     const int y0 = max(0, (int)floor(py - hb + 0.5 - AAI_KNIFE_GUARD)), y1 = min(r.mH - 1, (int)ceil(py + hb - 0.5 + AAI_KNIFE_GUARD));
 
-    double sumA = 0.0, sumVA = 0.0;
+    double sumA = 0.0;
+    double sumVA[NC] = {};
     int nPend = 0;
     const bool packable = (x1 - x0) < 256 && (y1 - y0) < 128;
     // lines = virtual rows (quadrants 0, 2) or virtual columns (quadrants 1, 3): whichever is a SOURCE row, so that
@@ -102,7 +106,7 @@ __global__ __launch_bounds__(kRotBlock) void aai_rotated_runs_kernel(RotLaunch r
         bool rev;
         const T *srow = img + virt_line(r, u, sv.rowStride, rev);
         // one boundary pixel: the body of aai_rotated_kernel's first pass
-        auto boundary = [&](int w, float v) {
+        auto boundary = [&](int w, const float (&v)[NC]) {
             const int X = cols ? u : w, Y = cols ? w : u;
             const double ex = X - px, ey = Y - py;
             const double a = ex * r.c - ey * r.s, b = ex * r.s + ey * r.c;
@@ -121,10 +125,33 @@ __global__ __launch_bounds__(kRotBlock) void aai_rotated_runs_kernel(RotLaunch r
             } else area = single_cut_area<false>(r, d, cls == PAIR_CUT_LR, r.policy, edgy2);
             if (area != 0.0) {
                 sumA += area;
-                sumVA += area * (double)v;
+#pragma unroll
+                for (int c = 0; c < NC; ++c)
+                    if (c < chan) sumVA[c] += area * (double)v[c];
             }
         };
         double s0 = 0.0, s1 = 0.0;
+        if (MULTI) {
+            double sc[NC] = {};
+            for (int w = t0; w <= t1; ++w) {
+                float v[kMaxChan];
+                load_pixel(srow + (int64_t)(rev ? nIn - 1 - w : w) * chan, chan, v);
+                float vv[NC];
+#pragma unroll
+                for (int c = 0; c < NC; ++c) vv[c] = v[c];
+                if (w >= i0 && w <= i1) {
+#pragma unroll
+                    for (int c = 0; c < NC; ++c)
+                        if (c < chan) sc[c] += (double)vv[c];
+                } else boundary(w, vv);
+            }
+            if (i0 <= i1) {
+#pragma unroll
+                for (int c = 0; c < NC; ++c) sumVA[c] += sc[c];
+                sumA += (double)(i1 - i0 + 1);
+            }
+            continue;
+        }
         if (nIn >= 4) {
             // Fetch the touched segment four source columns at a time (one dword-aligned 16-byte load per lane instead
             // of four 4-byte loads: neighbouring lanes are L source pixels apart, so every load instruction touches
@@ -141,17 +168,17 @@ __global__ __launch_bounds__(kRotBlock) void aai_rotated_runs_kernel(RotLaunch r
                     if (sx < c0 || sx > sb) continue;
                     const int w = rev ? nIn - 1 - sx : sx;
                     if (w >= i0 && w <= i1) { if (j & 1) s1 += (double)v[j]; else s0 += (double)v[j]; }
-                    else boundary(w, v[j]);
+                    else { const float one[NC] = {v[j]}; boundary(w, one); }
                 }
             }
         } else {
             for (int w = t0; w <= t1; ++w) {
-                const float v = (float)srow[rev ? nIn - 1 - w : w];
-                if (w >= i0 && w <= i1) s0 += (double)v;
-                else boundary(w, v);
+                const float one[NC] = {(float)srow[rev ? nIn - 1 - w : w]};
+                if (w >= i0 && w <= i1) s0 += (double)one[0];
+                else boundary(w, one);
             }
         }
-        if (i0 <= i1) { sumVA += s0 + s1; sumA += (double)(i1 - i0 + 1); }
+        if (i0 <= i1) { sumVA[0] += s0 + s1; sumA += (double)(i1 - i0 + 1); }
     }
     for (int i = 0; i < nPend; ++i) {
         const unsigned short code = pending[i][tid];
@@ -162,10 +189,21 @@ __global__ __launch_bounds__(kRotBlock) void aai_rotated_runs_kernel(RotLaunch r
         const double area = wedge_pair_area<false>(r, px - (X - 0.5), py - (Y - 0.5), nearLeft, nearTop, r.policy, edgy);
         if (area != 0.0) {
             sumA += area;
-            sumVA += area * (double)img[virt_offset(r, X, Y, sv.rowStride)];
+            const T *p = img + virt_offset(r, X, Y, sv.rowStride, chan);
+            if (!MULTI) sumVA[0] += area * (double)p[0];
+            else {
+                float v[kMaxChan];
+                load_pixel(p, chan, v);
+#pragma unroll
+                for (int c = 0; c < NC; ++c)
+                    if (c < chan) sumVA[c] += area * (double)v[c];
+            }
         }
     }
-    *out = DBL_EPSILON < fabs(sumA) ? (float)(sumVA / sumA) : 0.f;   // Source.cpp:577
+    const bool any = DBL_EPSILON < fabs(sumA);                        // Source.cpp:577
+#pragma unroll
+    for (int c = 0; c < NC; ++c)
+        if (c < chan) out[c] = any ? (float)(sumVA[c] / sumA) : 0.f;
 }
 
 // ---- K4/K5 -------------------------------------------------------------------------------------------
@@ -278,8 +316,11 @@ static hipError_t launch_rotated_typed(const RotLaunch &r, const T *src, int src
     // production pass; then, only for geometries whose scan found knife edges (waveFlags != NULL), the fix-up
     // pass over the same grid
     if (r.chan > 1) {
-        // interleaved channels: the per-position kernels with the areas shared between the channels
-        if (r.mode == AAI_MODE_FAST) {
+        // interleaved channels: the same kernels with the areas shared between the channels
+        if (r.mode == AAI_MODE_AREA && r.runs) {
+            if (kernelName) *kernelName = "aai_rotated_runs_kernel<area, channels>";
+            hipLaunchKernelGGL((aai_rotated_runs_kernel<T, true>), grid, dim3(kRotBlock), 0, stream, r, src, sv, dst, dv);
+        } else if (r.mode == AAI_MODE_FAST) {
             if (kernelName) *kernelName = "aai_rotated_kernel<fast, channels>";
             hipLaunchKernelGGL((aai_rotated_kernel<AAI_MODE_FAST, false, T, true>), grid, dim3(kRotBlock), 0, stream, r, src, sv, dst, dv, waveFlags);
         } else {
@@ -295,7 +336,7 @@ static hipError_t launch_rotated_typed(const RotLaunch &r, const T *src, int src
             if (const char *p = strstr(env, "runs=")) runs = (atoi(p + 5) != 0 && r.scale == 1) ? 1 : 0;
         if (runs) {
             if (kernelName) *kernelName = "aai_rotated_runs_kernel<area>";
-            hipLaunchKernelGGL((aai_rotated_runs_kernel<T>), grid, dim3(kRotBlock), 0, stream, r, src, sv, dst, dv);
+            hipLaunchKernelGGL((aai_rotated_runs_kernel<T, false>), grid, dim3(kRotBlock), 0, stream, r, src, sv, dst, dv);
         } else {
             if (kernelName) *kernelName = "aai_rotated_kernel<area>";
             hipLaunchKernelGGL((aai_rotated_kernel<AAI_MODE_AREA, false, T>), grid, dim3(kRotBlock), 0, stream, r, src, sv, dst, dv, waveFlags);

@@ -156,7 +156,7 @@ int aai_resample_host(const aai_request *req, const void *src, int32_t src_dtype
 /* ---- interleaved channels --------------------------------------------------------------
  * Images whose pixels hold `channels` (1..4) interleaved values, e.g. RGB scans: element (x, y, c) of image b is
  * src[b*src_image_stride + y*src_stride + x*channels + c], and the output has the same layout (fp32).  Strides are in
- * ELEMENTS (src_stride >= width*channels, dst_stride >= dst_width*channels).  Every channel gets exactly the result
+ * ELEMENTS (src_stride >= width*channels, dst_stride >= dst_width*channels).  Every channel gets the result
  * of the single-channel call on that channel alone; the rotated-lattice kernels compute the overlap areas once per
  * pixel pair for all channels, the axis-aligned kernel reads every source byte once.  The reference only knows
  * single-channel images (IMG, Source.cpp:31). */
