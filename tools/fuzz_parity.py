@@ -48,6 +48,23 @@ for k in range(N):
         if e > 1e-5 or zm or dst.shape != gold.dst.shape or tuple(giso) != gold.dst_iso:
             bad += 1
             print("MISMATCH case", k, dict(W=W, H=H, sr=sr, dr=dr, ang=ang, iso=iso, mode=mode, policy=policy, dt=str(dt)), "err", e, "zero-mismatch", zm, aai.last_kernel())
+    # interleaved channels: every channel against the oracle on that channel
+    if k % 5 == 0 and mode in (1, 2):
+        C = int(rng.integers(2, 5))
+        if dt == "f32":
+            isrc = rng.random((H, W, C)).astype(np.float32)
+        else:
+            isrc = rng.integers(0, 256 if dt == "u8" else 65536, size=(H, W, C)).astype(np.uint8 if dt == "u8" else np.uint16)
+        rc, msg, idst, ilay = aai.resample_interleaved_host(isrc, sr, dr, iso, ang, mode=mode, policy=policy)
+        assert rc == 0, msg
+        for c in range(C):
+            g = po.oracle_run(omode, isrc[:, :, c].astype(np.float64), sr, dr, iso, ang, policy=policy).dst
+            if g.size:
+                e = (np.abs(idst[:, :, c] - g) / np.maximum(np.abs(g), 1e-3 * scale)).max()
+                worst = max(worst, e)
+                if e > 1e-5 or int(((g == 0) != (idst[:, :, c] == 0)).sum()):
+                    bad += 1
+                    print("CHANNEL MISMATCH case", k, dict(W=W, H=H, sr=sr, dr=dr, ang=ang, iso=iso, mode=mode, policy=policy, dt=str(dt), C=C, c=c), "err", e, aai.last_kernel())
     # row bands of the f32 cases must equal the full result bit for bit
     if dt == "f32" and lay.dst_height >= 32 and lay.dst_width > 0 and k % 2 == 0:
         rq = aai.make_request(W, H, sr, dr, iso, ang, mode=mode, policy=policy)
