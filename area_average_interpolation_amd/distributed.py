@@ -44,9 +44,10 @@ def tensor_to_request(t):
     return rq
 
 
-def broadcast_request(request, src=0, device="cpu"):
-    """Every rank returns rank `src`'s request (pass any placeholder Request on the other ranks)."""
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+def broadcast_request(request, src=0, device="cpu", force=False):
+    """Every rank returns rank `src`'s request (pass any placeholder Request on the other ranks).
+    force: run the collective even in a one-rank group (rehearsal of the RCCL path on a single GPU)."""
+    if not dist.is_initialized() or (dist.get_world_size() == 1 and not force):
         return request
     t = request_to_tensor(request if dist.get_rank() == src else L.Request(), device=device)
     dist.broadcast(t, src=src)

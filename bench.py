@@ -135,15 +135,23 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend; nccl (= RCCL) is the real one, gloo lets two ranks rehearse on one GPU")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="initialise torch.distributed even with one rank (rehearses the RCCL code path on a single GPU)")
     ap.add_argument("--gather", action="store_true", help="also time an RCCL gather of the outputs to rank 0 (reported separately)")
     args = ap.parse_args()
 
+    saved_stdout = None
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus > 1 or world > 1:
+    if args.gpus > 1 or world > 1 or args.force_dist:
         assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        # RCCL printf()s its version banner (NCCL_DEBUG=VERSION on these boxes) to stdout when the communicator is created:
+        # park fd 1 on stderr until the ONE JSON line is due
+        sys.stdout.flush()
+        saved_stdout = os.dup(1)
+        os.dup2(2, 1)
         local = local % torch.cuda.device_count()
         torch.cuda.set_device(local)
         if args.backend == "nccl":
@@ -166,7 +174,7 @@ def main():
     W, H, sr, dr, ang, mode, desc = WORKLOADS[args.workload]
     policy = aai.POLICY_REFERENCE if args.policy == "reference" else aai.POLICY_EXACT
     rq = aai.make_request(W, H, sr, dr, ((W - 1) / 2, (H - 1) / 2), ang, mode=mode, policy=policy)
-    rq = D.broadcast_request(rq, src=0, device=cdev)           # the only collective the path needs
+    rq = D.broadcast_request(rq, src=0, device=cdev, force=args.force_dist)           # the only collective the path needs
     rc, msg, lay = aai.query(rq)
     assert rc == 0, msg
     dW, dH = lay.dst_width, lay.dst_height
@@ -192,7 +200,7 @@ def main():
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if dist.is_initialized():
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -211,12 +219,12 @@ def main():
     kernel_name = aai.last_kernel()
 
     t = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
-    if world > 1:
+    if dist.is_initialized():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
 
     gather_ms = None
-    if args.gather and world > 1:
+    if args.gather and dist.is_initialized():
         fence()
         g0 = time.perf_counter()
         payload = dst if cdev == dev else dst.cpu()
@@ -257,8 +265,14 @@ def main():
         if world == 1 and not args.no_cpu_baseline and mode in (aai.MODE_AREA, aai.MODE_FAST):
             line["cpu_baseline"] = cpu_baseline(args.workload)
             line["cpu_baseline"]["gpu_over_cpu"] = line["value"] / line["cpu_baseline"]["value"]
+        if saved_stdout is not None:
+            sys.stdout.flush()
+            ctypes.CDLL(None).fflush(None)          # whatever C stdio still holds goes to stderr, not after the JSON line
+            os.dup2(saved_stdout, 1)
+            os.close(saved_stdout)
+            saved_stdout = None
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
 
