@@ -57,12 +57,15 @@ struct Plan {
     aai::AxisTables tabs;
     aai::AxisEntry *dLane = nullptr, *dRow = nullptr;
     aai::AxisStrip *dStrips = nullptr;
-    // K2/K3: per-wave knife-edge flags from the one-off scan; NULL when the geometry has none (the usual case)
-    unsigned *dFlags = nullptr;
-    unsigned knifeWaves = 0;
+    // K2/K3: the dst pixels flagged by the one-off scans (knife edges of the reference's classifier; decisions the fp32
+    // quad kernel leaves to double precision) as a list of (dx, dy) the fix-up pass runs over; `dense` when there are
+    // so many that the whole image takes that pass instead
+    void *dList = nullptr;
+    unsigned flaggedPixels = 0;
+    bool dense = false;
     ~Plan()
     {
-        if (dFlags) (void)hipFree(dFlags);
+        if (dList) (void)hipFree(dList);
         if (dLane) (void)hipFree(dLane);
         if (dRow) (void)hipFree(dRow);
         if (dStrips) (void)hipFree(dStrips);
@@ -72,6 +75,7 @@ struct Plan {
 std::mutex g_planMutex;
 std::list<Plan> g_plans;              // most recently used first
 constexpr size_t kMaxPlans = 32;
+constexpr unsigned kMaxListedPixels = 1u << 24;      // beyond 16 M flagged pixels the whole image takes the double-precision pass
 
 bool same_request(const aai_request &a, const aai_request &b)
 {
@@ -158,23 +162,33 @@ int get_plan(const aai_request &rq, int band0, int band1, int channels, Plan **o
     if (band0 >= 0 && p.kernel != AAI_KERNEL_AXIS && p.kernel != AAI_KERNEL_AXIS_WIDE)
         aai::rotated_band_source_rows(g, band0, band1, p.kernel == AAI_KERNEL_SAMPLE, p.srcRow0, p.srcRow1);
     if (p.kernel == AAI_KERNEL_ROTATED || p.kernel == AAI_KERNEL_FAST) {
-        // one-off knife-edge scan of this geometry (see aai_knife_scan_kernel); keeps the flags only if any
+        // one-off scans of this geometry (aai_knife_scan_kernel, and aai_quad_scan_kernel where the fp32 quad kernel
+        // serves it); keeps the flags and the list of flagged waves only if there are any
         const aai::RotLaunch r = aai::make_rot_launch(g, rq.mode, rq.policy);
-        const size_t words = aai::rotated_flag_words(r);
+        const size_t waves = aai::rotated_flag_words(r);
+        unsigned long long *dMasks = nullptr;
         unsigned *dCount = nullptr;
         unsigned count = 0;
         hipError_t e = hipSuccess;
-        if (words) {
-            e = hipMalloc((void **)&p.dFlags, words * sizeof(unsigned));
+        if (waves) {
+            e = hipMalloc((void **)&dMasks, waves * sizeof(unsigned long long));
             if (e == hipSuccess) e = hipMalloc((void **)&dCount, sizeof(unsigned));
             if (e == hipSuccess) e = hipMemset(dCount, 0, sizeof(unsigned));
-            if (e == hipSuccess) e = aai::launch_knife_scan(r, p.dFlags, dCount, nullptr);
+            if (e == hipSuccess) e = aai::launch_knife_scan(r, dMasks, dCount, nullptr);
+            if (e == hipSuccess && r.quad && channels == 1) e = aai::launch_quad_scan(r, dMasks, dCount, nullptr);
             if (e == hipSuccess) e = hipMemcpy(&count, dCount, sizeof(unsigned), hipMemcpyDeviceToHost);
+            if (e == hipSuccess && count > kMaxListedPixels) { p.dense = true; count = 0; }
+            if (e == hipSuccess && count) {
+                e = hipMalloc(&p.dList, (size_t)count * 2 * sizeof(unsigned));
+                if (e == hipSuccess) e = hipMemset(dCount, 0, sizeof(unsigned));
+                if (e == hipSuccess) e = aai::launch_flag_list(dMasks, waves, (unsigned)((g.dW + 15) / 16), p.dList, dCount, count, nullptr);
+                if (e == hipSuccess) e = hipDeviceSynchronize();
+            }
             if (dCount) (void)hipFree(dCount);
+            if (dMasks) (void)hipFree(dMasks);
         }
         if (e != hipSuccess) { g_plans.pop_front(); return hip_fail(e, "knife-edge scan"); }
-        p.knifeWaves = count;
-        if (count == 0 && p.dFlags) { (void)hipFree(p.dFlags); p.dFlags = nullptr; }
+        p.flaggedPixels = count;
     }
     while (g_plans.size() > kMaxPlans) g_plans.pop_back();
     *out = &p;
@@ -236,10 +250,13 @@ int enqueue(const aai_request &rq, int batch, const void *dSrc, int srcType, int
         aai::RotLaunch r = aai::make_rot_launch(g, rq.mode, rq.policy);
         if (band0 >= 0) { r.dyBase = band0; r.dyEnd = band1; r.srcRow0 = p->srcRow0; }
         r.chan = channels;
+        const aai::QuadMap qm = aai::make_quad_map(g, srcStride, r.srcRow0);
+        aai::RotFlags flags;
+        flags.list = p->dList; flags.count = p->flaggedPixels; flags.dense = p->dense;
         e = hipSuccess;
         for (int b0 = 0; b0 < batch && e == hipSuccess; b0 += kMaxGridZ)
-            e = aai::launch_rotated(r, src_at(dSrc, srcType, (int64_t)b0 * srcImageStride), srcType, sv, dDst + (int64_t)b0 * dstImageStride, dv,
-                                    std::min(batch - b0, kMaxGridZ), p->dFlags, stream, &name);
+            e = aai::launch_rotated(r, qm, src_at(dSrc, srcType, (int64_t)b0 * srcImageStride), srcType, sv, dDst + (int64_t)b0 * dstImageStride, dv,
+                                    std::min(batch - b0, kMaxGridZ), flags, stream, &name);
     }
     g_lastKernel = name;
     if (e != hipSuccess) return hip_fail(e, name);

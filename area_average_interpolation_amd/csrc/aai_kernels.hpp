@@ -40,12 +40,25 @@ hipError_t launch_axis(const AxisLaunch &a, const void *src, int srcType, ImageV
                        int batch, hipStream_t stream, const char **kernelName);
 
 // ---- K2/K3/K4/K5: per-output-pixel kernels on the rotated lattice --------------------------------------
-// Knife-edge flags (one 32-bit word per wave of the 16x16-pixel tiling, geometry only): launch_knife_scan fills
-// them and counts the flagged waves in counter[0]; launch_rotated runs the fix-up pass iff waveFlags != NULL.
-size_t rotated_flag_words(const RotLaunch &r);
-hipError_t launch_knife_scan(const RotLaunch &r, unsigned *waveFlags, unsigned *counter, hipStream_t stream);
-hipError_t launch_rotated(const RotLaunch &r, const void *src, int srcType, ImageView sv, float *dst, ImageView dv,
-                          int batch, const unsigned *waveFlags, hipStream_t stream, const char **kernelName);
+// Flagged dst pixels (geometry only), found once per plan: one 64-bit lane mask per wave of the 16x16-pixel tiling.
+// launch_knife_scan marks the pixels with a knife edge of the reference's classifier, launch_quad_scan adds the
+// pixels whose decisions the fp32 quad kernel must not take; both count the pixels they newly flag in counter[0].
+// launch_flag_list turns the masks into the list of (dx, dy) the double-precision fix-up pass runs over.
+struct RotFlags {
+    const void *list = nullptr;        // device array of uint2 (dx, dy), `count` entries
+    unsigned count = 0;
+    bool dense = false;                // so many that the whole image takes the double-precision pass instead
+};
+size_t rotated_flag_words(const RotLaunch &r);      // waves of the tiling = 64-bit words of the mask array
+hipError_t launch_knife_scan(const RotLaunch &r, unsigned long long *laneMasks, unsigned *counter, hipStream_t stream);
+hipError_t launch_quad_scan(const RotLaunch &r, unsigned long long *laneMasks, unsigned *counter, hipStream_t stream);
+hipError_t launch_flag_list(const unsigned long long *laneMasks, size_t waves, unsigned tilesX, void *list, unsigned *cursor, unsigned capacity,
+                            hipStream_t stream);
+hipError_t launch_rotated(const RotLaunch &r, const QuadMap &m, const void *src, int srcType, ImageView sv, float *dst, ImageView dv,
+                          int batch, const RotFlags &flags, hipStream_t stream, const char **kernelName);
+bool quad_can_address(const RotLaunch &r, int srcType, ImageView sv);
+hipError_t launch_quad(const RotLaunch &r, const QuadMap &m, const void *src, int srcType, ImageView sv, float *dst, ImageView dv,
+                       int batch, hipStream_t stream);
 
 // ---- utilities -----------------------------------------------------------------------------------------
 hipError_t launch_synth(float *dst, int W, int H, int64_t stride, uint64_t seed, hipStream_t stream);

@@ -1,6 +1,7 @@
 // aai_plan.cpp -- host-side validation, affine set-up and the separable tables for the axis-aligned
 // kernel.  Double precision throughout; mirrors Source.cpp:112-305 of the reference.
 #include "aai_plan.hpp"
+#include "aai_rot_quad.hpp"
 
 #include <algorithm>
 #include <cfloat>
@@ -143,7 +144,29 @@ RotLaunch make_rot_launch(const Geometry &g, int mode, int policy)
     // Footprints with an interior at least kRunsMinInterior pixels wide walk rows as runs (aai_rotated_runs_kernel);
     // the threshold is from profiles/r01_rotated_runs.txt.  Only without replication (scale 1: rows are straight lines).
     r.runs = (mode == AAI_MODE_AREA && g.scale == 1 && 2.0 * (h - r.k) >= kRunsMinInterior) ? 1 : 0;
+    // Footprints whose window of source pixels fits 8 x 8 take the fp32 quad formulation (aai_rot_quad.hpp), unless the
+    // reduced angle is so close to an axis that the reference's own corner-triangle rule amplifies fp32 coordinates
+    // beyond the parity bar (quad_supported).
+    r.quad = (mode == AAI_MODE_AREA && c > 0.0 && s > 0.0 && quad_supported(g.side, c, s)) ? 1 : 0;
     return r;
+}
+
+QuadMap make_quad_map(const Geometry &g, int64_t rowStride, int srcRow0)
+{
+    QuadMap m{};
+    m.nX = g.mW / g.scale; m.nY = g.mH / g.scale;
+    m.base = -(int64_t)srcRow0 * rowStride;
+    switch (g.quadrant) {
+    default:
+    case 0: m.strideX = 1;         m.flipX = 0; m.strideY = rowStride; m.flipY = 0; break;   // (X, Y)          -> (x, y) = (X, Y)
+    case 1: m.strideX = rowStride; m.flipX = 1; m.strideY = 1;         m.flipY = 0; break;   // (Y, mW-1-X)
+    case 2: m.strideX = 1;         m.flipX = 1; m.strideY = rowStride; m.flipY = 1; break;   // (mW-1-X, mH-1-Y)
+    case 3: m.strideX = rowStride; m.flipX = 0; m.strideY = 1;         m.flipY = 1; break;   // (mH-1-Y, X)
+    }
+    m.scale = g.scale;
+    m.invScale = (float)(1.0 / g.scale);
+    m.invScaleD = 1.0 / g.scale;
+    return m;
 }
 
 void rotated_band_source_rows(const Geometry &g, int row0, int row1, bool sampler, int &srcRow0, int &srcRow1)

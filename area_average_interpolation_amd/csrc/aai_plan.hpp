@@ -54,6 +54,22 @@ constexpr double kRunsMinInterior = 3.25;
 // Fills the uniform block of the per-output-pixel kernels (K2-K5) from the geometry.
 RotLaunch make_rot_launch(const Geometry &g, int mode, int policy);
 
+// Virtual pixel (X, Y) -> element of the source image for the quad kernel (Source.cpp:164-167: the pre-rotation only
+// flips / swaps axes, and (m - 1 - X) div scale = m / scale - 1 - X div scale because m is a multiple of scale):
+//   element = base + uX * strideX + uY * strideY,  uX = flipX ? nX - 1 - X div scale : X div scale  (uY alike)
+// with non-negative strides, so that a lane addresses its pixels with unsigned 32-bit byte offsets from one uniform
+// base.  rowStride in elements; srcRow0 = the source row the image pointer addresses (row bands).
+struct QuadMap {
+    int64_t base;                // elements; negative for a band (base = -srcRow0 * rowStride)
+    int64_t strideX, strideY;    // elements per step of uX / uY: 1 or rowStride
+    int nX, nY;                  // source pixels along virtual X / Y (mW / scale, mH / scale)
+    int flipX, flipY;
+    int scale;
+    float invScale;
+    double invScaleD;
+};
+QuadMap make_quad_map(const Geometry &g, int64_t rowStride, int srcRow0);
+
 // ---- K1: separable axis-aligned tables ---------------------------------------------------------------
 // One entry per output index along one axis: the source window [s0,s1] along the matching SOURCE axis
 // (original-image indices, ascending) and the three distinct weights a box footprint can produce.

@@ -1,0 +1,332 @@
+// aai_rot_quad.hpp -- second formulation of the rotated-lattice area average (K2), built for fp32 issue rates.
+//
+// Replaces Source.cpp:413-579 + 986-1431 of the reference for every dst pixel that does not sit on one of the
+// reference's DBL_EPSILON knife edges (those are redone by the strict replay, aai_strict.hpp).  Shared between
+// the HIP kernel (aai_rotated_quad.hip) and the host-side replay the CPU test-suite uses
+// (tests/emulation/host_emulation.cpp): AAI_HD, templated on the arithmetic type F (float in production,
+// double in the tests that compare the formulas with the older ones to 1e-12).
+//
+// Geometry, in the frame of the dst square (a along its top edge, b along its left edge; the square is
+// |a| <= h, |b| <= h, h = L/2 > sqrt(2)/2): a unit source pixel is a square turned by the reduced angle whose
+// corners lie at distance k = (c+s)/2 along either axis.  With A = h - |a| and B = h - |b| the inside-distances
+// of the pixel centre from the NEARER left/right and top/bottom edge line:
+//   * min(A,B) <= -k            the pixel is outside                                        (type 0)
+//   * min(A,B) >=  k            inside, area 1                                              (type 1)
+//   * max(A,B) >=  k            ONE edge line cuts it ("single"): the area is a function of t = min(A,B)+k
+//                               alone -- corner triangle, trapezoid or their complements   (types 2, 3, 4)
+//   * otherwise both near lines cut it ("double"): the pixel meets the quadrant the two near edges span at
+//     their common vertex V.  Either V lies inside the pixel -- exactly four pixels of every dst pixel, handled
+//     one vertex at a time by quad_vertex_area (types 7, 8, 9) -- or each edge, as a SEGMENT ending at V,
+//     crosses the whole pixel or misses it, so that area = G(u) S1 + G(v) S2 - S1 S2 with G the single-line
+//     area and S1, S2 two sign tests on V's position relative to the pixel (types 2-6).
+// The reference multiplies the complementary legs when a lone left/right edge cuts off exactly one pixel corner
+// (Source.cpp:1055-1062); policy REFERENCE reproduces that in the single-line term.
+//
+// Per dst pixel (quad_pixel): one uniform pass classifies the (at most 8 x 8) window positions into 64-bit position
+// masks -- four compares each, no area math -- while the window's pixel values are being fetched; the areas are
+// then evaluated class by class over the set bits, so that every lane of a wave runs the same formula at the same
+// time, reading the values from the staged window.
+//
+// Precision: everything is relative to the dst pixel's own centre, so fp32 carries absolute errors of a few
+// 1e-7 pixel.  The reference-policy areas are discontinuous where an edge passes through a pixel corner or a
+// vertex crosses a pixel side, so fp32 must not DECIDE such cases: SCAN mode runs the same code without pixel
+// loads and reports every dst pixel with a decision closer than QuadConsts::margin to its threshold, or with too
+// little total area for fp32 weights; the plan stores that per wave next to the knife-edge flags and the fix-up
+// pass redoes those waves in double precision (aai_rotated_kernel<STRICT>).
+#pragma once
+
+#include "aai_rot_math.hpp"
+
+namespace aai {
+
+constexpr int kQuadMaxWin = 8;        // window positions per axis that the 64-bit position masks can hold
+
+template <typename F>
+struct QuadConsts {
+    F c, s, h, k, k2;                 // cos, sin of the reduced angle (both > 0); L/2; (c+s)/2; c+s
+    F hmk, hpk;                       // h - k, h + k
+    F lo, hi;                         // min(c,s), max(c,s)
+    F r2cs, rhi, trapOff;             // 1/(2cs), 1/hi, lo/(2 hi)
+    F rc, rs, hrc;                    // 1/c, 1/s, 1/(2c)
+    F m1, im1;                        // s/c, c/s
+    F ox[4], oy[4];                   // vertex i = centre + (ox[i], oy[i]); 0 left/top, 1 right/top, 2 left/bottom, 3 right/bottom
+    F hbm;                            // h(c+s) - 1/2 + guard: half extent of the window of pixel CENTRES
+    F margin;                         // SCAN: decisions closer than this to their threshold are reported
+    F minArea;                        // SCAN: pixels whose total area is below this (and not zero) are reported
+    int ref;                          // 1 = AAI_POLICY_REFERENCE
+    int win;                          // window positions per axis, <= kQuadMaxWin
+};
+
+// fp32 error budget of a coordinate relative to the dst pixel's centre: the constants' rounding times an index of at
+// most the window size, two fused multiply-adds on magnitudes <= hb + 1, the centre's own fraction (see quad_pixel)
+AAI_HD double quad_coord_eps(double side, double c, double s) { return 1.1920929e-7 * (2.0 + 0.5 * side * (c + s)); }
+
+// Can the quad formulation serve this geometry?
+//   * the window of source pixels fits the 8 x 8 position masks;
+//   * h - k is well away from zero, so that the sign of a, b is never in doubt for a pixel both near lines cut;
+//   * the steepest area formula -- the reference's corner-triangle rule, slope (1/c + 1/s)/2 in t -- keeps a
+//     coordinate error of quad_coord_eps below ~1.5e-7 of the dst value (weights sum to about L^2; pixel values
+//     differ from their mean by a few tenths).  Closer to the axes than that (reduced angle within a few degrees
+//     of 0 or 90) the double-precision kernel serves the request.
+AAI_HD bool quad_supported(double side, double c, double s)
+{
+    if (!(c > 0.0 && s > 0.0)) return false;
+    const double h = 0.5 * side, k = 0.5 * (c + s);
+    const double m = h * (c + s) - 0.5 + 1e-5;
+    const double amp = 0.5 * (1.0 / c + 1.0 / s);
+    return (int)floor(2.0 * m) + 3 <= kQuadMaxWin && h - k > 1e-3 && amp * quad_coord_eps(side, c, s) * 0.5 <= 1.5e-7 * side * side;
+}
+
+template <typename F>
+AAI_HD QuadConsts<F> make_quad_consts(double side, double c, double s, int policy)
+{
+    QuadConsts<F> q;
+    const double h = 0.5 * side, k = 0.5 * (c + s);
+    const double lo = c < s ? c : s, hi = c < s ? s : c;
+    q.c = (F)c; q.s = (F)s; q.h = (F)h; q.k = (F)k; q.k2 = (F)(c + s);
+    q.hmk = (F)(h - k); q.hpk = (F)(h + k);
+    q.lo = (F)lo; q.hi = (F)hi;
+    q.r2cs = (F)(1.0 / (2.0 * c * s)); q.rhi = (F)(1.0 / hi); q.trapOff = (F)(lo / (2.0 * hi));
+    q.rc = (F)(1.0 / c); q.rs = (F)(1.0 / s); q.hrc = (F)(0.5 / c);
+    q.m1 = (F)(s / c); q.im1 = (F)(c / s);
+    const double o0x = -h * (c + s), o0y = h * (s - c), o1x = h * (c - s), o1y = -h * (s + c);
+    q.ox[0] = (F)o0x; q.oy[0] = (F)o0y; q.ox[1] = (F)o1x; q.oy[1] = (F)o1y;
+    q.ox[2] = (F)-o1x; q.oy[2] = (F)-o1y; q.ox[3] = (F)-o0x; q.oy[3] = (F)-o0y;
+    const double hb = h * (c + s);
+    const double eps = quad_coord_eps(side, c, s);
+    q.hbm = (F)(hb - 0.5 + 1e-5);
+    q.margin = (F)(3.0 * eps);
+    q.minArea = (F)(side * side < 4.0 ? 0.25 * side * side : 1.0);
+    q.ref = policy == AAI_POLICY_REFERENCE ? 1 : 0;
+    q.win = (int)floor(2.0 * (hb - 0.5 + 1e-5)) + 3;
+    return q;
+}
+
+template <typename F> AAI_HD F qmin(F a, F b) { return a < b ? a : b; }
+template <typename F> AAI_HD F qmax(F a, F b) { return a < b ? b : a; }
+AAI_HD float qabs(float a) { return __builtin_fabsf(a); }       // a source modifier on the GPU, not an instruction
+AAI_HD double qabs(double a) { return __builtin_fabs(a); }
+
+// Area of the part of a unit pixel on the inner side of ONE edge line that has entered it by t (0 <= t <= c+s,
+// measured from the pixel's extreme corner along the line's normal).  substitute: the line is a left/right edge
+// under policy REFERENCE -- the two corner-triangle cases take the reference's complementary legs.
+template <typename F>
+AAI_HD F quad_cut(const QuadConsts<F> &q, F t, bool substitute)
+{
+    const F tp = qmin(t, q.k2 - t);                       // from the nearer extreme corner: the cases mirror at t = k
+    const F trap = tp * q.rhi - q.trapOff;                // (tp - lo/2) / hi
+    const F triExact = tp * tp * q.r2cs;                  // legs tp/c, tp/s
+    const F triRef = (F(0.5) - q.hrc * tp) * (F(1) - q.rs * tp);
+    const F tri = substitute ? triRef : triExact;
+    const F g = tp <= q.lo ? tri : trap;
+    return t > q.k ? F(1) - g : g;
+}
+
+// A pixel cut by both near edge lines, the vertex V NOT inside it (a pixel that holds V gets 0 here and its area
+// from quad_vertex_area).  A, B as above; sameSign: a and b have the same sign, which makes edge 1 of the
+// canonical orientation (u, v) the left/right edge.  nearS (SCAN): distance of the closest live sign test from
+// its threshold.
+template <typename F, bool SCAN>
+AAI_HD F quad_double(const QuadConsts<F> &q, F A, F B, bool sameSign, F &nearS)
+{
+    const F u = sameSign ? A : B, v = sameSign ? B : A;
+    // V relative to the pixel centre along the pixel's own axes, in the orientation where the square lies
+    // towards -x, -y of V: edge 1 runs from V towards -y, edge 2 towards -x
+    const F cx = u * q.c + v * q.s, cy = v * q.c - u * q.s;
+    const bool r = cx >= F(0.5);
+    const bool S1 = r || cy >= F(0.5);                    // edge 1 crosses the pixel (V beyond its +x or +y side)
+    const bool S2 = r || cy <= F(-0.5);                   // edge 2 crosses the pixel (V beyond its +x or -y side)
+    if (SCAN) {
+        const F dx = qabs(cx - F(0.5));
+        nearS = dx;
+        if (cx < F(0.5) + q.margin) nearS = qmin(dx, qmin(qabs(cy - F(0.5)), qabs(cy + F(0.5))));
+    }
+    const F tu = qmin(qmax(u + q.k, F(0)), q.k2), tv = qmin(qmax(v + q.k, F(0)), q.k2);
+    const F gu = quad_cut(q, tu, false), gv = quad_cut(q, tv, false);
+    const F gl = quad_cut(q, sameSign ? tu : tv, q.ref != 0);          // the left/right edge alone
+    const F only1 = sameSign ? gl : gu, only2 = sameSign ? gv : gl;
+    const F both = qmax(gu + gv - F(1), F(0));
+    return S1 ? (S2 ? both : only1) : (S2 ? only2 : F(0));
+}
+
+// The pixel that holds vertex `vidx` of the dst square: area of the pixel inside the right-angled wedge the two
+// edges span at the vertex.  (fx, fy) = the vertex relative to the pixel centre, both in [-1/2, 1/2].  Half the
+// sum over the pixel's sides of (distance of the vertex from the side) x (length of the side inside the wedge);
+// vertices 1-3 are vertex 0 seen through a quarter turn.  Exact for both policies (Source.cpp:1276-1401).
+template <typename F>
+AAI_HD F quad_vertex_area(const QuadConsts<F> &q, F fx, F fy, int vidx)
+{
+    F x, y;
+    switch (vidx) {
+    case 0: x = fx; y = fy; break;
+    case 1: x = fy; y = -fx; break;
+    case 2: x = -fy; y = fx; break;
+    default: x = -fx; y = -fy; break;
+    }
+    // vertex 0: the wedge opens towards +x between the rays (c,-s) and (s,c)
+    const F dR = F(0.5) - x, dT = y + F(0.5), dB = F(0.5) - y;
+    const F y1 = y - dR * q.m1, y2 = y + dR * q.im1;      // where the two rays meet the line x = 1/2
+    const F lenR = qmin(y2, F(0.5)) - qmax(y1, F(-0.5));
+    const F lenT = qmax(F(0), F(0.5) - (x + dT * q.im1));  // ray 1 leaves through the top side
+    const F lenB = qmax(F(0), F(0.5) - (x + dB * q.m1));   // ray 2 leaves through the bottom side
+    return F(0.5) * (dR * lenR + dT * lenT + dB * lenB);
+}
+
+AAI_HD int quad_ctz64(unsigned long long m)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __ffsll((long long)m) - 1;
+#else
+    return __builtin_ctzll(m);
+#endif
+}
+
+// One dst pixel.  WIN = window positions per axis (QuadConsts::win, a compile-time constant so that the window pass
+// unrolls and the staged window has a fixed size); window position (i, j) is bit / slot j * WIN + i.
+// (Xc, Yc) = the virtual pixel nearest the centre, (fpx, fpy) = centre - (Xc, Yc), both in [-1/2, 1/2].
+// Source protocol:
+//   src.issue(xg0, yg0, valid)  start fetching the values of the window whose position (0, 0) is virtual pixel
+//                               (xg0, yg0); `valid` has the bits of the positions inside the mW x mH lattice
+//   src.commit()                make them addressable (the GPU parks them in LDS, one column per lane)
+//   src.at(slot)                value of a position whose valid bit is set
+// so that the loads are in flight while the window is classified and every later pass reads at LDS latency.
+// Returns the sums; the dst value is sumVA / sumA, or 0 when sumA is 0 (Source.cpp:577).
+// SCAN: src is never touched, every value counts as 1 and the return value says whether this pixel must be left to
+// the double-precision pass.
+template <typename F, int WIN, bool SCAN, typename Src>
+AAI_HD bool quad_pixel(const QuadConsts<F> &q, int Xc, int Yc, F fpx, F fpy, int mW, int mH, Src &src, F &sumA, F &sumVA)
+{
+    typedef unsigned long long u64;
+    static_assert(WIN >= 2 && WIN <= kQuadMaxWin, "window size");
+    sumA = F(0); sumVA = F(0);
+    // window origin: first pixel centre the square's bounding box can reach
+    const F fi0 = floor(fpx - q.hbm), fj0 = floor(fpy - q.hbm);
+    const int i0 = (int)fi0, j0 = (int)fj0;
+    const int xg0 = Xc + i0, yg0 = Yc + j0;
+
+    // positions inside the lattice
+    u64 valid;
+    {
+        const int ia = xg0 < 0 ? -xg0 : 0, ib = (mW - 1 - xg0 < WIN - 1) ? mW - 1 - xg0 : WIN - 1;
+        const int ja = yg0 < 0 ? -yg0 : 0, jb = (mH - 1 - yg0 < WIN - 1) ? mH - 1 - yg0 : WIN - 1;
+        if (ia > ib || ja > jb) return false;                                 // the whole window misses the image
+        const unsigned cols = (2u << ib) - (1u << ia);                         // bits ia..ib of one row
+        valid = 0;
+#pragma unroll
+        for (int j = 0; j < WIN; ++j)
+            if (j >= ja && j <= jb) valid |= (u64)cols << (j * WIN);
+    }
+    if (!SCAN) src.issue(xg0, yg0, valid);
+
+    // dst-frame coordinates of pixel (Xc, Yc)'s centre: (ex, ey) = -(fpx, fpy)
+    const F ac = fpy * q.s - fpx * q.c, bc = -(fpx * q.s + fpy * q.c);
+    bool uncertain = false;
+
+    // ---- pass 1: classify every window position --------------------------------------------------------------
+    // bit planes: |a| <= h - k, |b| <= h - k, touched; the class masks follow from them with three 64-bit operations
+    u64 pA = 0, pB = 0, pT = 0;
+#pragma unroll
+    for (int j = 0; j < WIN; ++j) {
+        const F fj = fj0 + (F)j;
+        const F rowA = ac - fj * q.s, rowB = bc + fj * q.c;
+#pragma unroll
+        for (int i = 0; i < WIN; ++i) {
+            const F fi = fi0 + (F)i;
+            const F a = qabs(rowA + fi * q.c), b = qabs(rowB + fi * q.s);
+            const u64 bit = (u64)1 << (j * WIN + i);
+            if (a <= q.hmk) pA |= bit;
+            if (b <= q.hmk) pB |= bit;
+            if (a < q.hpk && b < q.hpk) pT |= bit;
+            if (SCAN) {
+                // thresholds of |a| (the left/right line also switches formula at t = lo, hi under policy REFERENCE)
+                // and of |b|; one axis' thresholds only matter while the other axis does not already say "outside"
+                F na = qmin(qabs(a - q.hmk), qabs(a - q.hpk));
+                if (q.ref) na = qmin(na, qmin(qabs(a - (q.hpk - q.lo)), qabs(a - (q.hpk - q.hi))));
+                const F nb = qmin(qabs(b - q.hmk), qabs(b - q.hpk));
+                const bool live = (valid & bit) != 0;
+                if (live && ((na < q.margin && b < q.hpk + q.margin) || (nb < q.margin && a < q.hpk + q.margin))) uncertain = true;
+            }
+        }
+    }
+    pT &= valid;
+    u64 mIn = pA & pB & valid;                 // wholly inside (inside implies touched: h - k < h + k)
+    u64 mSingle = pT & (pA ^ pB);              // one near line clear of the pixel, the other cuts it
+    u64 mDouble = pT & ~(pA | pB);             // both near lines cut it
+    if (!SCAN) src.commit();
+
+    // ---- the four pixels that hold a vertex ----------------------------------------------------------------------
+#pragma unroll
+    for (int vtx = 0; vtx < 4; ++vtx) {
+        const F wx = fpx + q.ox[vtx], wy = fpy + q.oy[vtx];       // vertex relative to (Xc, Yc)
+        const F rx = floor(wx + F(0.5)), ry = floor(wy + F(0.5));
+        const F fx = wx - rx, fy = wy - ry;
+        const int i = (int)rx - i0, j = (int)ry - j0;
+        if (i < 0 || i >= WIN || j < 0 || j >= WIN) { if (SCAN) uncertain = true; continue; }   // cannot happen (the box holds the vertices)
+        const int slot = j * WIN + i;
+        const u64 bit = (u64)1 << slot;
+        if (SCAN && (qabs(fx) > F(0.5) - q.margin || qabs(fy) > F(0.5) - q.margin)) uncertain = true;
+        mDouble &= ~bit;
+        if (valid & bit) {
+            const F area = quad_vertex_area(q, fx, fy, vtx);
+            const F val = SCAN ? F(1) : (F)src.at(slot);
+            sumA += area;
+            sumVA += area * val;
+        }
+    }
+
+    // ---- pixels wholly inside: area 1 ------------------------------------------------------------------------------
+    while (mIn) {
+        const int slot = quad_ctz64(mIn);
+        mIn &= mIn - 1;
+        const F val = SCAN ? F(1) : (F)src.at(slot);
+        sumA += F(1);
+        sumVA += val;
+    }
+    // ---- pixels cut by one edge line ---------------------------------------------------------------------------------
+    while (mSingle) {
+        const int slot = quad_ctz64(mSingle);
+        mSingle &= mSingle - 1;
+        const int j = slot / WIN, i = slot - j * WIN;
+        const F val = SCAN ? F(1) : (F)src.at(slot);
+        const F fj = fj0 + (F)j, fi = fi0 + (F)i;
+        const F a = qabs((ac - fj * q.s) + fi * q.c), b = qabs((bc + fj * q.c) + fi * q.s);
+        const F A = q.h - a, B = q.h - b;
+        const bool isLR = A < B;                              // the smaller inside-distance belongs to the cutting line
+        const F t = qmin(qmax((isLR ? A : B) + q.k, F(0)), q.k2);
+        const F area = quad_cut(q, t, isLR && q.ref != 0);
+        sumA += area;
+        sumVA += area * val;
+    }
+    // ---- pixels cut by both near edge lines --------------------------------------------------------------------------
+    while (mDouble) {
+        const int slot = quad_ctz64(mDouble);
+        mDouble &= mDouble - 1;
+        const int j = slot / WIN, i = slot - j * WIN;
+        const F val = SCAN ? F(1) : (F)src.at(slot);
+        const F fj = fj0 + (F)j, fi = fi0 + (F)i;
+        const F a = (ac - fj * q.s) + fi * q.c, b = (bc + fj * q.c) + fi * q.s;
+        F nearS = F(1);
+        const F area = quad_double<F, SCAN>(q, q.h - qabs(a), q.h - qabs(b), (a < F(0)) == (b < F(0)), nearS);
+        if (SCAN && nearS < q.margin) uncertain = true;
+        sumA += area;
+        sumVA += area * val;
+    }
+    if (SCAN && sumA > F(0) && sumA < q.minArea) uncertain = true;
+    return uncertain;
+}
+
+// run-time window size -> the matching instantiation
+template <typename F, bool SCAN, typename Src>
+AAI_HD bool quad_pixel_any(const QuadConsts<F> &q, int Xc, int Yc, F fpx, F fpy, int mW, int mH, Src &src, F &sumA, F &sumVA)
+{
+    switch (q.win) {
+    case 3: return quad_pixel<F, 3, SCAN>(q, Xc, Yc, fpx, fpy, mW, mH, src, sumA, sumVA);
+    case 4: return quad_pixel<F, 4, SCAN>(q, Xc, Yc, fpx, fpy, mW, mH, src, sumA, sumVA);
+    case 5: return quad_pixel<F, 5, SCAN>(q, Xc, Yc, fpx, fpy, mW, mH, src, sumA, sumVA);
+    case 6: return quad_pixel<F, 6, SCAN>(q, Xc, Yc, fpx, fpy, mW, mH, src, sumA, sumVA);
+    case 7: return quad_pixel<F, 7, SCAN>(q, Xc, Yc, fpx, fpy, mW, mH, src, sumA, sumVA);
+    default: return quad_pixel<F, 8, SCAN>(q, Xc, Yc, fpx, fpy, mW, mH, src, sumA, sumVA);
+    }
+}
+
+}  // namespace aai

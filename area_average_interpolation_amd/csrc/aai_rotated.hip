@@ -25,6 +25,7 @@
 // general clip runs ~6 times per pixel, dense across the wave, instead of once per window position.
 #include "aai_rotated_kernel.hpp"
 
+#include <algorithm>
 #include <cstdlib>
 #include <cstring>
 
@@ -33,18 +34,19 @@ namespace aai {
 namespace {
 
 constexpr int kBlock = 256;
+constexpr int kMaxGridY = 65535;
 
 // ---- knife-edge scan (once per geometry) ------------------------------------------------------------------
-// Same tiling as aai_rotated_kernel: one word per wave says whether any of its 64 dst pixels has a vertex on
+// Same tiling as aai_rotated_kernel: one 64-bit word per wave has the bits of its dst pixels with a vertex on
 // a pixel-boundary line or an edge through a lattice point (aai_rot_math.hpp: pixel_on_knife_edge);
-// counter[0] counts the flagged waves.  Depends on the geometry only, so the plan runs it once and caches
-// the flags; generic geometries (every BASELINE configuration) flag nothing and never launch the fix-up pass.
-__global__ __launch_bounds__(kRotBlock) void aai_knife_scan_kernel(RotLaunch r, unsigned *__restrict__ waveFlags, unsigned *__restrict__ counter)
+// counter[0] counts the flagged pixels.  Depends on the geometry only, so the plan runs it once and keeps
+// the list of flagged pixels; generic geometries (every BASELINE configuration) have no knife edge.
+__global__ __launch_bounds__(kRotBlock) void aai_knife_scan_kernel(RotLaunch r, unsigned long long *__restrict__ laneMasks, unsigned *__restrict__ counter, int tileRow0)
 {
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int dx = blockIdx.x * 16 + (tid & 15);
-    const int dy = blockIdx.y * 16 + (tid >> 4);
+    const int dy = (tileRow0 + blockIdx.y) * 16 + (tid >> 4);
     bool knife = false;
     if (dx < r.dW && dy < r.dH) {
         double px, py;
@@ -53,8 +55,8 @@ __global__ __launch_bounds__(kRotBlock) void aai_knife_scan_kernel(RotLaunch r, 
     }
     const unsigned long long any = __ballot(knife);
     if ((tid & 63) == 0) {
-        waveFlags[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * (kRotBlock / 64) + wave] = any != 0ull ? 1u : 0u;
-        if (any != 0ull) atomicAdd(counter, 1u);
+        laneMasks[((size_t)(tileRow0 + blockIdx.y) * gridDim.x + blockIdx.x) * (kRotBlock / 64) + wave] = any;
+        if (any != 0ull) atomicAdd(counter, (unsigned)__popcll(any));
     }
 }
 
@@ -288,19 +290,39 @@ size_t rotated_flag_words(const RotLaunch &r)
     return (size_t)((r.dW + 15) / 16) * (size_t)((r.dH + 15) / 16) * (kRotBlock / 64);
 }
 
-hipError_t launch_knife_scan(const RotLaunch &r, unsigned *waveFlags, unsigned *counter, hipStream_t stream)
+hipError_t launch_knife_scan(const RotLaunch &r, unsigned long long *laneMasks, unsigned *counter, hipStream_t stream)
 {
     if (r.dW <= 0 || r.dH <= 0) return hipSuccess;
-    dim3 grid((r.dW + 15) / 16, (r.dH + 15) / 16, 1);
-    hipLaunchKernelGGL(aai_knife_scan_kernel, grid, dim3(kRotBlock), 0, stream, r, waveFlags, counter);
-    return hipGetLastError();
+    const int tileRows = (r.dH + 15) / 16;
+    for (int t0 = 0; t0 < tileRows; t0 += kMaxGridY) {      // grid.y carries at most 65535 tiles
+        dim3 grid((r.dW + 15) / 16, std::min(tileRows - t0, kMaxGridY), 1);
+        hipLaunchKernelGGL(aai_knife_scan_kernel, grid, dim3(kRotBlock), 0, stream, r, laneMasks, counter, t0);
+        const hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
 }
 
-template <typename T>
-static hipError_t launch_rotated_typed(const RotLaunch &r, const T *src, int srcType, ImageView sv, float *dst, ImageView dv,
-                                       int batch, const unsigned *waveFlags, hipStream_t stream, const char **kernelName)
+// experiments only: AAI_ROT_TUNE="runs=0|1 quad=0|1", read once per process
+struct RotTune { int runs = -1, quad = -1; };
+static const RotTune &rot_tune()
 {
-    if (r.dW <= 0 || r.dyEnd <= r.dyBase || batch <= 0) return hipSuccess;
+    static const RotTune t = [] {
+        RotTune v;
+        if (const char *env = getenv("AAI_ROT_TUNE")) {
+            if (const char *p = strstr(env, "runs=")) v.runs = atoi(p + 5) != 0;
+            if (const char *p = strstr(env, "quad=")) v.quad = atoi(p + 5) != 0;
+        }
+        return v;
+    }();
+    return t;
+}
+
+// one launch of at most 65535 tile rows (sampler: 4-row tiles, the others 16-row tiles)
+template <typename T>
+static hipError_t launch_rotated_band(const RotLaunch &r, const QuadMap &m, const T *src, int srcType, ImageView sv, float *dst, ImageView dv,
+                                      int batch, const RotFlags &flags, hipStream_t stream, const char **kernelName)
+{
     if (r.mode == AAI_MODE_BILINEAR || r.mode == AAI_MODE_BICUBIC) {
         dim3 grid((r.dW + 63) / 64, (r.dyEnd - r.dyBase + 3) / 4, batch);
         if (r.mode == AAI_MODE_BILINEAR) {
@@ -313,8 +335,7 @@ static hipError_t launch_rotated_typed(const RotLaunch &r, const T *src, int src
         return hipGetLastError();
     }
     dim3 grid((r.dW + 15) / 16, (r.dyEnd - r.dyBase + 15) / 16, batch);
-    // production pass; then, only for geometries whose scan found knife edges (waveFlags != NULL), the fix-up
-    // pass over the same grid
+    const RotTune &tune = rot_tune();
     if (r.chan > 1) {
         // interleaved channels: the same kernels with the areas shared between the channels
         if (r.mode == AAI_MODE_AREA && r.runs) {
@@ -322,39 +343,69 @@ static hipError_t launch_rotated_typed(const RotLaunch &r, const T *src, int src
             hipLaunchKernelGGL((aai_rotated_runs_kernel<T, true>), grid, dim3(kRotBlock), 0, stream, r, src, sv, dst, dv);
         } else if (r.mode == AAI_MODE_FAST) {
             if (kernelName) *kernelName = "aai_rotated_kernel<fast, channels>";
-            hipLaunchKernelGGL((aai_rotated_kernel<AAI_MODE_FAST, false, T, true>), grid, dim3(kRotBlock), 0, stream, r, src, sv, dst, dv, waveFlags);
+            hipLaunchKernelGGL((aai_rotated_kernel<AAI_MODE_FAST, false, T, true>), grid, dim3(kRotBlock), 0, stream, r, src, sv, dst, dv, nullptr, 0u);
         } else {
             if (kernelName) *kernelName = "aai_rotated_kernel<area, channels>";
-            hipLaunchKernelGGL((aai_rotated_kernel<AAI_MODE_AREA, false, T, true>), grid, dim3(kRotBlock), 0, stream, r, src, sv, dst, dv, waveFlags);
+            hipLaunchKernelGGL((aai_rotated_kernel<AAI_MODE_AREA, false, T, true>), grid, dim3(kRotBlock), 0, stream, r, src, sv, dst, dv, nullptr, 0u);
         }
     } else if (r.mode == AAI_MODE_FAST) {
         if (kernelName) *kernelName = "aai_rotated_kernel<fast>";
-        hipLaunchKernelGGL((aai_rotated_kernel<AAI_MODE_FAST, false, T>), grid, dim3(kRotBlock), 0, stream, r, src, sv, dst, dv, waveFlags);
+        hipLaunchKernelGGL((aai_rotated_kernel<AAI_MODE_FAST, false, T>), grid, dim3(kRotBlock), 0, stream, r, src, sv, dst, dv, nullptr, 0u);
+    } else if (r.quad && tune.quad != 0 && quad_can_address(r, srcType, sv)) {
+        // the fp32 quad formulation; the pixels flagged by the plan's scans are recomputed by the fix-up pass
+        if (kernelName) *kernelName = "aai_quad_kernel<area>";
+        return launch_quad(r, m, src, srcType, sv, dst, dv, batch, stream);
     } else {
-        int runs = r.runs;
-        if (const char *env = getenv("AAI_ROT_TUNE"))             // experiments: AAI_ROT_TUNE="runs=0|1"
-            if (const char *p = strstr(env, "runs=")) runs = (atoi(p + 5) != 0 && r.scale == 1) ? 1 : 0;
+        const int runs = tune.runs >= 0 ? (tune.runs && r.scale == 1) : r.runs;
         if (runs) {
             if (kernelName) *kernelName = "aai_rotated_runs_kernel<area>";
             hipLaunchKernelGGL((aai_rotated_runs_kernel<T, false>), grid, dim3(kRotBlock), 0, stream, r, src, sv, dst, dv);
         } else {
             if (kernelName) *kernelName = "aai_rotated_kernel<area>";
-            hipLaunchKernelGGL((aai_rotated_kernel<AAI_MODE_AREA, false, T>), grid, dim3(kRotBlock), 0, stream, r, src, sv, dst, dv, waveFlags);
+            hipLaunchKernelGGL((aai_rotated_kernel<AAI_MODE_AREA, false, T>), grid, dim3(kRotBlock), 0, stream, r, src, sv, dst, dv, nullptr, 0u);
         }
     }
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return e;
-    if (waveFlags) launch_rotated_fixup(r, grid, src, srcType, sv, dst, dv, waveFlags, stream);
     return hipGetLastError();
 }
 
-hipError_t launch_rotated(const RotLaunch &r, const void *src, int srcType, ImageView sv, float *dst, ImageView dv,
-                          int batch, const unsigned *waveFlags, hipStream_t stream, const char **kernelName)
+template <typename T>
+static hipError_t launch_rotated_typed(const RotLaunch &r, const QuadMap &m, const T *src, int srcType, ImageView sv, float *dst, ImageView dv,
+                                       int batch, const RotFlags &flags, hipStream_t stream, const char **kernelName)
+{
+    if (r.dW <= 0 || r.dyEnd <= r.dyBase || batch <= 0) return hipSuccess;
+    // grid.y carries at most 65535 tiles: taller outputs (more than ~1M rows, 262k for the samplers) go in several launches
+    const bool sampler = r.mode == AAI_MODE_BILINEAR || r.mode == AAI_MODE_BICUBIC;
+    if (!sampler && flags.dense) {
+        // (nearly) every pixel sits on a knife edge: the double-precision pass computes the whole image
+        if (kernelName) *kernelName = r.mode == AAI_MODE_FAST ? "aai_rotated_kernel<fast, strict>" : "aai_rotated_kernel<area, strict>";
+        for (int y0 = r.dyBase; y0 < r.dyEnd; y0 += kMaxGridY * 16) {
+            RotLaunch rb = r;
+            rb.dyBase = y0;
+            rb.dyEnd = r.dyEnd - y0 > kMaxGridY * 16 ? y0 + kMaxGridY * 16 : r.dyEnd;
+            launch_rotated_fixup(rb, batch, src, srcType, sv, dst + (int64_t)(y0 - r.dyBase) * dv.rowStride, dv, nullptr, 0u, stream);
+        }
+        return hipGetLastError();
+    }
+    const int maxRows = kMaxGridY * (sampler ? 4 : 16);
+    for (int y0 = r.dyBase; y0 < r.dyEnd; y0 += maxRows) {
+        RotLaunch rb = r;
+        rb.dyBase = y0;
+        rb.dyEnd = r.dyEnd - y0 > maxRows ? y0 + maxRows : r.dyEnd;
+        const hipError_t e = launch_rotated_band(rb, m, src, srcType, sv, dst + (int64_t)(y0 - r.dyBase) * dv.rowStride, dv, batch, flags, stream, kernelName);
+        if (e != hipSuccess) return e;
+    }
+    // the double-precision pass over the pixels the plan's scans flagged (none for the samplers)
+    if (!sampler && flags.count) launch_rotated_fixup(r, batch, src, srcType, sv, dst, dv, static_cast<const uint2 *>(flags.list), flags.count, stream);
+    return hipGetLastError();
+}
+
+hipError_t launch_rotated(const RotLaunch &r, const QuadMap &m, const void *src, int srcType, ImageView sv, float *dst, ImageView dv,
+                          int batch, const RotFlags &flags, hipStream_t stream, const char **kernelName)
 {
     switch (srcType) {
-    case SRC_U8: return launch_rotated_typed(r, static_cast<const unsigned char *>(src), srcType, sv, dst, dv, batch, waveFlags, stream, kernelName);
-    case SRC_U16: return launch_rotated_typed(r, static_cast<const unsigned short *>(src), srcType, sv, dst, dv, batch, waveFlags, stream, kernelName);
-    default: return launch_rotated_typed(r, static_cast<const float *>(src), srcType, sv, dst, dv, batch, waveFlags, stream, kernelName);
+    case SRC_U8: return launch_rotated_typed(r, m, static_cast<const unsigned char *>(src), srcType, sv, dst, dv, batch, flags, stream, kernelName);
+    case SRC_U16: return launch_rotated_typed(r, m, static_cast<const unsigned short *>(src), srcType, sv, dst, dv, batch, flags, stream, kernelName);
+    default: return launch_rotated_typed(r, m, static_cast<const float *>(src), srcType, sv, dst, dv, batch, flags, stream, kernelName);
     }
 }
 

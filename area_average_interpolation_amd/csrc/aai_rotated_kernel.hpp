@@ -48,11 +48,10 @@ __device__ __forceinline__ void load_pixel(const T *p, int chan, float v[4])
 }
 
 // STRICT = false: the production pass.  Every pair is answered by the fast path.
-// STRICT = true: the fix-up pass over the same grid, launched only when the plan's knife-edge scan
-//   (aai_knife_scan_kernel, run once per geometry) found flagged waves.  Waves whose flag is clear exit at
-//   once; flagged waves recompute their 64 pixels, replaying the reference's own arithmetic
-//   (aai_strict.hpp) for the knife-edge
-//   pairs.  In generic geometry -- every BASELINE configuration -- no flag is ever raised.
+// STRICT = true: the double-precision fix-up pass over the dst pixels the plan's scans flagged (once per geometry:
+//   aai_knife_scan_kernel for the reference's knife edges, aai_quad_scan_kernel for decisions the fp32
+//   production pass must not take).  Each listed pixel is recomputed in double precision, replaying
+//   the reference's own arithmetic (aai_strict.hpp) for the knife-edge pairs.
 // MULTI: interleaved channels (RotLaunch::chan = 2..4).  The geometry -- classification and overlap areas -- is computed
 // once per (dst, src) pair and applied to every channel; false compiles the single-channel kernel unchanged.
 constexpr int kMaxChan = 4;
@@ -60,18 +59,27 @@ constexpr int kMaxChan = 4;
 template <int MODE, bool STRICT, typename T, bool MULTI = false>
 __global__ __launch_bounds__(kRotBlock) void aai_rotated_kernel(RotLaunch r, const T *__restrict__ src, ImageView sv,
                                                               float *__restrict__ dst, ImageView dv,
-                                                              const unsigned *__restrict__ waveFlags)
+                                                              const uint2 *__restrict__ pixelList, unsigned nList)
 {
     __shared__ unsigned short pending[kRotListCap][kRotBlock];
 
     const int tid = threadIdx.x;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    // knife-edge flags depend on the geometry only, so one set serves every image of a batch
-    if (STRICT && waveFlags[((size_t)(blockIdx.y + r.dyBase / 16) * gridDim.x + blockIdx.x) * (kRotBlock / 64) + wave] == 0u) return;
-
-    const int dx = blockIdx.x * 16 + (tid & 15);
-    const int dy = r.dyBase + blockIdx.y * 16 + (tid >> 4);
-    const bool valid = dx < r.dW && dy < r.dyEnd;
+    int dx, dy;
+    bool valid;
+    if (STRICT && pixelList) {
+        // The fix-up pass runs over the plan's list of flagged dst pixels (one lane each).  The list depends on the
+        // geometry alone, so one list serves every image of a batch and every row band.
+        const unsigned e = blockIdx.x * kRotBlock + (unsigned)tid;
+        valid = e < nList;
+        const uint2 p = valid ? pixelList[e] : make_uint2(0u, 0u);
+        dx = (int)p.x; dy = (int)p.y;
+        valid = valid && dy >= r.dyBase && dy < r.dyEnd;
+    } else {
+        // (STRICT without a list: so many pixels are flagged that the whole image takes this pass)
+        dx = blockIdx.x * 16 + (tid & 15);
+        dy = r.dyBase + blockIdx.y * 16 + (tid >> 4);
+        valid = dx < r.dW && dy < r.dyEnd;
+    }
     const T *img = src + (int64_t)blockIdx.z * sv.imageStride;
 
     // (Staging the tile's source footprint in LDS with coalesced loads was measured and rejected: cfg3 1452 ->
@@ -266,7 +274,8 @@ __global__ __launch_bounds__(kRotBlock) void aai_rotated_kernel(RotLaunch r, con
 }
 
 // launches the fix-up pass (defined in aai_rotated_strict.hip)
-void launch_rotated_fixup(const RotLaunch &r, dim3 grid, const void *src, int srcType, ImageView sv, float *dst, ImageView dv,
-                          const unsigned *waveFlags, hipStream_t stream);
+// pixelList == NULL: the whole image (grid as for the production pass)
+void launch_rotated_fixup(const RotLaunch &r, int batch, const void *src, int srcType, ImageView sv, float *dst, ImageView dv,
+                          const uint2 *pixelList, unsigned nList, hipStream_t stream);
 
 }  // namespace aai

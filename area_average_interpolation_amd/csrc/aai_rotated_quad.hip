@@ -1,0 +1,242 @@
+// aai_rotated_quad.hip -- K2, the area average at a general rotation, in its fp32 "quad" formulation for gfx950
+// (the arithmetic lives in aai_rot_quad.hpp, shared with the CPU replay of the test-suite).
+//
+// Replaces Source.cpp:413-579 + 986-1431 of the reference.  One lane per dst pixel, a wave covers a 16 x 4 dst
+// tile, no barrier.  The dst pixel's centre is the only double-precision quantity (coordinates reach ~3e4 virtual
+// pixels); everything after it is relative to the nearest virtual pixel and runs in fp32 at twice the fp64 issue
+// rate and half the registers.
+//
+// Source pixels: every lane fetches its own WIN x WIN window with independent loads (all in flight while the
+// window is classified), parks it in one LDS column of its own (slot-major, so a wave's accesses are conflict
+// free and no barrier is needed) and the area passes read values at LDS latency instead of waiting for a
+// dependent global load per (dst, src) pair -- with loads inside the passes the kernel spent 42 % of its wave
+// cycles in s_waitcnt (profiles/r02_quad_counters.txt).  The bound is VALU issue, not HBM: cfg3 moves 26.9
+// algorithmic bytes per dst pixel through ~1.1 k vector instructions per wave.
+//
+// The production kernel takes no numerically delicate decision by itself: the plan runs the SCAN kernel once per
+// geometry (same code, no pixel loads); pixels it flags -- a decision within QuadConsts::margin of its threshold,
+// or a border pixel with too little total area for fp32 weights -- are recomputed afterwards by the
+// double-precision fix-up pass (aai_rotated_kernel<STRICT>), exactly like the knife-edge pixels.
+#include "aai_kernels.hpp"
+#include "aai_rot_quad.hpp"
+
+namespace aai {
+
+namespace {
+
+constexpr int kQuadBlock = 256;      // 16 x 16 dst pixels, the tiling of the scans
+
+// The staged window of one lane.  Offsets are unsigned bytes from the image's first element (QuadMap: non-negative
+// strides), one table per axis; positions outside the lattice are clamped onto it -- their values are fetched but
+// never read (quad_pixel only reads slots whose valid bit is set).
+template <typename T, int WIN, bool SCALED>
+struct QuadSrc {
+    const char *img;                 // first element of this image (band offset included)
+    const QuadMap *m;
+    int mW, mH;
+    float (*lds)[kQuadBlock];        // [WIN * WIN][kQuadBlock]
+    int tid;
+    T v[WIN * WIN];
+
+    __device__ __forceinline__ void issue(int xg0, int yg0, unsigned long long)
+    {
+        unsigned colOff[WIN], rowOff[WIN];
+        const unsigned sxb = (unsigned)m->strideX * (unsigned)sizeof(T), syb = (unsigned)m->strideY * (unsigned)sizeof(T);
+        if (!SCALED) {
+#pragma unroll
+            for (int i = 0; i < WIN; ++i) {
+                const int X = min(max(xg0 + i, 0), mW - 1), Y = min(max(yg0 + i, 0), mH - 1);
+                colOff[i] = (unsigned)(m->flipX ? m->nX - 1 - X : X) * sxb;
+                rowOff[i] = (unsigned)(m->flipY ? m->nY - 1 - Y : Y) * syb;
+            }
+        } else {
+            // floor division of coordinates that are >= -8 (the window meets the lattice): exact, (n + 0.5) / scale is
+            // at least 0.5 / scale away from an integer; inside the window (rem + i + 0.5) / scale with rem + i <
+            // scale + 8 is far from every integer compared with fp32 rounding
+            const int scale = m->scale;
+            const int tx = xg0 + 8 * scale, ty = yg0 + 8 * scale;
+            const int qx0 = (int)(((double)tx + 0.5) * m->invScaleD), qy0 = (int)(((double)ty + 0.5) * m->invScaleD);
+            const float remX = (float)(tx - qx0 * scale) + 0.5f, remY = (float)(ty - qy0 * scale) + 0.5f;
+#pragma unroll
+            for (int i = 0; i < WIN; ++i) {
+                const int ix = min(max(xg0 + i, 0), mW - 1) - xg0, iy = min(max(yg0 + i, 0), mH - 1) - yg0;
+                const int qx = qx0 - 8 + (int)((remX + (float)ix) * m->invScale), qy = qy0 - 8 + (int)((remY + (float)iy) * m->invScale);
+                colOff[i] = (unsigned)(m->flipX ? m->nX - 1 - qx : qx) * sxb;
+                rowOff[i] = (unsigned)(m->flipY ? m->nY - 1 - qy : qy) * syb;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < WIN; ++j)
+#pragma unroll
+            for (int i = 0; i < WIN; ++i)
+                v[j * WIN + i] = *reinterpret_cast<const T *>(img + (colOff[i] + rowOff[j]));
+    }
+    __device__ __forceinline__ void commit()
+    {
+#pragma unroll
+        for (int k = 0; k < WIN * WIN; ++k) lds[k][tid] = (float)v[k];
+    }
+    __device__ __forceinline__ float at(int slot) const { return lds[slot][tid]; }
+};
+
+struct NoSrc {
+    __device__ __forceinline__ void issue(int, int, unsigned long long) {}
+    __device__ __forceinline__ void commit() {}
+    __device__ __forceinline__ float at(int) const { return 1.f; }
+};
+
+template <typename T, int WIN, bool SCALED>
+__global__ __launch_bounds__(kQuadBlock) void aai_quad_kernel(RotLaunch r, QuadConsts<float> q, QuadMap m, const T *__restrict__ src,
+                                                             ImageView sv, float *__restrict__ dst, ImageView dv)
+{
+    __shared__ float window[WIN * WIN][kQuadBlock];
+    const int tid = threadIdx.x;
+    const int dx = blockIdx.x * 16 + (tid & 15);
+    const int dy = r.dyBase + blockIdx.y * 16 + (tid >> 4);
+    if (!(dx < r.dW && dy < r.dyEnd)) return;
+    float *out = dst + (int64_t)blockIdx.z * dv.imageStride + (int64_t)(dy - r.dyBase) * dv.rowStride + dx;
+
+    double px, py;
+    pixel_centre(r, dx, dy, px, py);
+    const double cx = floor(px + 0.5), cy = floor(py + 0.5);
+    float value = 0.f;
+    // a centre further than the window's reach from the lattice touches nothing (and stays inside int range)
+    if (cx > -16.0 && cx < (double)r.mW + 16.0 && cy > -16.0 && cy < (double)r.mH + 16.0) {
+        QuadSrc<T, WIN, SCALED> s;
+        s.img = reinterpret_cast<const char *>(src + (int64_t)blockIdx.z * sv.imageStride + m.base);
+        s.m = &m; s.mW = r.mW; s.mH = r.mH; s.lds = window; s.tid = tid;
+        float sumA, sumVA;
+        quad_pixel<float, WIN, false>(q, (int)cx, (int)cy, (float)(px - cx), (float)(py - cy), r.mW, r.mH, s, sumA, sumVA);
+        value = sumA > 0.f ? sumVA / sumA : 0.f;                      // Source.cpp:577
+    }
+    *out = value;
+}
+
+// Once per geometry: the same arithmetic without pixel loads.  Flags one bit per dst pixel in the 64-bit word of its
+// wave (the 16 x 16 tiling of aai_knife_scan_kernel, whose bits this kernel adds to) and counts the newly flagged
+// pixels in counter[0].
+template <int WIN>
+__global__ __launch_bounds__(kQuadBlock) void aai_quad_scan_kernel(RotLaunch r, QuadConsts<float> q, unsigned long long *__restrict__ laneMasks,
+                                                                  unsigned *__restrict__ counter, int tileRow0)
+{
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int dx = blockIdx.x * 16 + (tid & 15);
+    const int dy = (tileRow0 + blockIdx.y) * 16 + (tid >> 4);
+    bool uncertain = false;
+    if (dx < r.dW && dy < r.dH) {
+        double px, py;
+        pixel_centre(r, dx, dy, px, py);
+        const double cx = floor(px + 0.5), cy = floor(py + 0.5);
+        if (cx > -16.0 && cx < (double)r.mW + 16.0 && cy > -16.0 && cy < (double)r.mH + 16.0) {
+            NoSrc s;
+            float sumA, sumVA;
+            uncertain = quad_pixel<float, WIN, true>(q, (int)cx, (int)cy, (float)(px - cx), (float)(py - cy), r.mW, r.mH, s, sumA, sumVA);
+        }
+    }
+    const unsigned long long any = __ballot(uncertain);
+    if ((tid & 63) == 0 && any != 0ull) {
+        unsigned long long *f = laneMasks + ((size_t)(tileRow0 + blockIdx.y) * gridDim.x + blockIdx.x) * (kQuadBlock / 64) + wave;
+        const unsigned long long fresh = any & ~*f;
+        if (fresh) { *f |= fresh; atomicAdd(counter, (unsigned)__popcll(fresh)); }
+    }
+}
+
+// flagged dst pixels as a list of (dy << 32 | dx)... kept as two 32-bit words per pixel; any order (the fix-up pass
+// writes each listed pixel once)
+__global__ __launch_bounds__(256) void aai_flag_list_kernel(const unsigned long long *__restrict__ laneMasks, size_t waves, unsigned tilesX,
+                                                           uint2 *__restrict__ list, unsigned *__restrict__ cursor, unsigned capacity)
+{
+    for (size_t w = (size_t)blockIdx.x * 256 + threadIdx.x; w < waves; w += (size_t)gridDim.x * 256) {
+        unsigned long long mask = laneMasks[w];
+        if (!mask) continue;
+        unsigned k = atomicAdd(cursor, (unsigned)__popcll(mask));
+        const size_t tile = w >> 2;
+        const unsigned x0 = (unsigned)(tile % tilesX) * 16u, y0 = (unsigned)(tile / tilesX) * 16u + (unsigned)(w & 3) * 4u;
+        while (mask) {
+            const int lane = __ffsll((long long)mask) - 1;
+            mask &= mask - 1;
+            if (k < capacity) list[k] = make_uint2(x0 + (unsigned)(lane & 15), y0 + (unsigned)(lane >> 4));
+            ++k;
+        }
+    }
+}
+
+template <typename T, int WIN>
+hipError_t launch_quad_win(const RotLaunch &r, const QuadConsts<float> &q, const QuadMap &m, const T *src, ImageView sv, float *dst, ImageView dv,
+                           int batch, hipStream_t stream)
+{
+    const dim3 grid((r.dW + 15) / 16, (r.dyEnd - r.dyBase + 15) / 16, batch);      // at most 65535 tile rows: the caller bands taller outputs
+    if (m.scale > 1)
+        hipLaunchKernelGGL((aai_quad_kernel<T, WIN, true>), grid, dim3(kQuadBlock), 0, stream, r, q, m, src, sv, dst, dv);
+    else
+        hipLaunchKernelGGL((aai_quad_kernel<T, WIN, false>), grid, dim3(kQuadBlock), 0, stream, r, q, m, src, sv, dst, dv);
+    return hipGetLastError();
+}
+
+template <typename T>
+hipError_t launch_quad_typed(const RotLaunch &r, const QuadMap &m, const T *src, ImageView sv, float *dst, ImageView dv, int batch, hipStream_t stream)
+{
+    const QuadConsts<float> q = make_quad_consts<float>(r.side, r.c, r.s, r.policy);
+    switch (q.win) {
+    case 3: return launch_quad_win<T, 3>(r, q, m, src, sv, dst, dv, batch, stream);
+    case 4: return launch_quad_win<T, 4>(r, q, m, src, sv, dst, dv, batch, stream);
+    case 5: return launch_quad_win<T, 5>(r, q, m, src, sv, dst, dv, batch, stream);
+    case 6: return launch_quad_win<T, 6>(r, q, m, src, sv, dst, dv, batch, stream);
+    case 7: return launch_quad_win<T, 7>(r, q, m, src, sv, dst, dv, batch, stream);
+    default: return launch_quad_win<T, 8>(r, q, m, src, sv, dst, dv, batch, stream);
+    }
+}
+
+}  // namespace
+
+bool quad_can_address(const RotLaunch &r, int srcType, ImageView sv)
+{
+    // lanes address their pixels with unsigned 32-bit byte offsets from the image's first element
+    const int64_t esz = srcType == SRC_U8 ? 1 : srcType == SRC_U16 ? 2 : 4;
+    return (int64_t)r.H * sv.rowStride * esz < ((int64_t)1 << 32);
+}
+
+hipError_t launch_quad(const RotLaunch &r, const QuadMap &m, const void *src, int srcType, ImageView sv, float *dst, ImageView dv,
+                       int batch, hipStream_t stream)
+{
+    if (r.dW <= 0 || r.dyEnd <= r.dyBase || batch <= 0) return hipSuccess;
+    switch (srcType) {
+    case SRC_U8: return launch_quad_typed(r, m, static_cast<const unsigned char *>(src), sv, dst, dv, batch, stream);
+    case SRC_U16: return launch_quad_typed(r, m, static_cast<const unsigned short *>(src), sv, dst, dv, batch, stream);
+    default: return launch_quad_typed(r, m, static_cast<const float *>(src), sv, dst, dv, batch, stream);
+    }
+}
+
+hipError_t launch_quad_scan(const RotLaunch &r, unsigned long long *laneMasks, unsigned *counter, hipStream_t stream)
+{
+    if (r.dW <= 0 || r.dH <= 0) return hipSuccess;
+    const QuadConsts<float> q = make_quad_consts<float>(r.side, r.c, r.s, r.policy);
+    const int tileRows = (r.dH + 15) / 16;
+    for (int t0 = 0; t0 < tileRows; t0 += 65535) {         // grid.y carries at most 65535 tiles
+        const dim3 grid((r.dW + 15) / 16, tileRows - t0 < 65535 ? tileRows - t0 : 65535, 1);
+        switch (q.win) {
+        case 3: hipLaunchKernelGGL(aai_quad_scan_kernel<3>, grid, dim3(kQuadBlock), 0, stream, r, q, laneMasks, counter, t0); break;
+        case 4: hipLaunchKernelGGL(aai_quad_scan_kernel<4>, grid, dim3(kQuadBlock), 0, stream, r, q, laneMasks, counter, t0); break;
+        case 5: hipLaunchKernelGGL(aai_quad_scan_kernel<5>, grid, dim3(kQuadBlock), 0, stream, r, q, laneMasks, counter, t0); break;
+        case 6: hipLaunchKernelGGL(aai_quad_scan_kernel<6>, grid, dim3(kQuadBlock), 0, stream, r, q, laneMasks, counter, t0); break;
+        case 7: hipLaunchKernelGGL(aai_quad_scan_kernel<7>, grid, dim3(kQuadBlock), 0, stream, r, q, laneMasks, counter, t0); break;
+        default: hipLaunchKernelGGL(aai_quad_scan_kernel<8>, grid, dim3(kQuadBlock), 0, stream, r, q, laneMasks, counter, t0); break;
+        }
+        const hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
+}
+
+hipError_t launch_flag_list(const unsigned long long *laneMasks, size_t waves, unsigned tilesX, void *list, unsigned *cursor, unsigned capacity,
+                            hipStream_t stream)
+{
+    if (!waves) return hipSuccess;
+    const size_t blocks = (waves + 255) / 256;
+    hipLaunchKernelGGL(aai_flag_list_kernel, dim3((unsigned)(blocks > 4096 ? 4096 : blocks)), dim3(256), 0, stream, laneMasks, waves, tilesX,
+                       static_cast<uint2 *>(list), cursor, capacity);
+    return hipGetLastError();
+}
+
+}  // namespace aai

@@ -65,7 +65,9 @@ def hostemu(aai):
     srcs = [os.path.join(ROOT, "tests", "emulation", "host_emulation.cpp"),
             os.path.join(ROOT, "area_average_interpolation_amd", "csrc", "aai_plan.cpp"),
             os.path.join(ROOT, "area_average_interpolation_amd", "csrc", "aai_plan.hpp"),
-            os.path.join(ROOT, "area_average_interpolation_amd", "csrc", "aai_rot_math.hpp")]
+            os.path.join(ROOT, "area_average_interpolation_amd", "csrc", "aai_rot_math.hpp"),
+            os.path.join(ROOT, "area_average_interpolation_amd", "csrc", "aai_rot_quad.hpp"),
+            os.path.join(ROOT, "area_average_interpolation_amd", "csrc", "aai_strict.hpp")]
     if not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
         _run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-o", so, srcs[0]])
     lib = ctypes.CDLL(so)
@@ -112,6 +114,26 @@ def hostemu(aai):
     lib.knife_stats = knife_stats
     lib.aai_emu_missed_knife_pairs.restype = ctypes.c_long
     lib.aai_emu_missed_knife_pairs.argtypes = []
+    # the fp32 quad formulation of the rotated area kernel (csrc/aai_rot_quad.hpp)
+    lib.aai_emu_use_quad.restype = None
+    lib.aai_emu_use_quad.argtypes = [ctypes.c_int]
+    lib.aai_emu_quad_stats.restype = None
+    lib.aai_emu_quad_stats.argtypes = [ctypes.POINTER(ctypes.c_long), ctypes.POINTER(ctypes.c_long)]
+    lib.aai_emu_quad_pair_check.restype = ctypes.c_long
+    lib.aai_emu_quad_pair_check.argtypes = [ctypes.POINTER(L.Request), ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]
+
+    def quad_stats():
+        a, b = ctypes.c_long(), ctypes.c_long()
+        lib.aai_emu_quad_stats(ctypes.byref(a), ctypes.byref(b))
+        return a.value, b.value
+
+    def quad_pair_check(rq):
+        a, b = ctypes.c_double(), ctypes.c_double()
+        n = lib.aai_emu_quad_pair_check(ctypes.byref(rq), ctypes.byref(a), ctypes.byref(b))
+        return n, a.value, b.value
+
+    lib.quad_stats = quad_stats
+    lib.quad_pair_check = quad_pair_check
     lib.resample = resample
     lib.strip_stats = strip_stats
     return lib

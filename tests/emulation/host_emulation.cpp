@@ -14,6 +14,7 @@
 #include "../../area_average_interpolation_amd/csrc/aai_plan.cpp"
 #include "../../area_average_interpolation_amd/csrc/aai_rot_math.hpp"
 #include "../../area_average_interpolation_amd/csrc/aai_strict.hpp"
+#include "../../area_average_interpolation_amd/csrc/aai_rot_quad.hpp"
 
 using namespace aai;
 
@@ -130,12 +131,47 @@ static int emu_axis_channels(const Geometry &g, int mode, int C, const float *sr
 
 static int g_forceGeneral = 0;   // test hook: route every cut pair through pair_area (cross-checks the closed form)
 static int g_strict = 1;         // test hook: 0 = production pass only, 1 = production + knife-edge fix-up pass
-static long g_knifePairs = 0, g_knifePixels = 0, g_missedPairs = 0;   // missed: pair-level knife in a pixel the per-pixel test did not flag
+static long g_knifePairs = 0, g_knifePixels = 0, g_missedPairs = 0;
+static int g_useQuad = 0;        // test hook: 1 = unflagged area-mode pixels take the fp32 quad formulation (aai_rot_quad.hpp) like the GPU does
+static long g_quadPixels = 0, g_quadUncertain = 0;   // pixels answered by the quad path / left to the double-precision path by its scan
+
+// source access of the quad formulation: window slot -> virtual pixel -> image element (staged like the GPU does)
+template <int WIN>
+struct EmuQuadSrc {
+    const RotLaunch *r; const float *img; int64_t stride;
+    float v[WIN * WIN];
+    void issue(int xg0, int yg0, unsigned long long valid)
+    {
+        for (int j = 0; j < WIN; ++j)
+            for (int i = 0; i < WIN; ++i)
+                v[j * WIN + i] = ((valid >> (j * WIN + i)) & 1) ? img[virt_offset(*r, xg0 + i, yg0 + j, stride)] : -1e30f;   // poison: must never be read
+    }
+    void commit() {}
+    float at(int slot) const { return v[slot]; }
+};
+
+template <int WIN>
+static bool emu_quad_pixel(const QuadConsts<float> &qc, const RotLaunch &r, const float *img, int64_t stride, double px, double py, float &value)
+{
+    const double cxr = std::floor(px + 0.5), cyr = std::floor(py + 0.5);
+    if (!(std::fabs(cxr) < 1e9 && std::fabs(cyr) < 1e9)) return false;
+    const int Xc = (int)cxr, Yc = (int)cyr;
+    const float fpx = (float)(px - cxr), fpy = (float)(py - cyr);
+    EmuQuadSrc<WIN> qs{&r, img, stride, {}};
+    float sA, sVA;
+    if (quad_pixel<float, WIN, true>(qc, Xc, Yc, fpx, fpy, r.mW, r.mH, qs, sA, sVA)) return false;      // the scan leaves it to double precision
+    quad_pixel<float, WIN, false>(qc, Xc, Yc, fpx, fpy, r.mW, r.mH, qs, sA, sVA);
+    value = sA > 0.f ? sVA / sA : 0.f;
+    return true;
+}
 
 static void emu_rotated(const Geometry &g, const aai_request &rq, const float *img, int64_t srcStride, float *dst, int64_t dstStride)
 {
     const RotLaunch r = make_rot_launch(g, rq.mode, rq.policy);
     g_knifePairs = g_knifePixels = g_missedPairs = 0;
+    g_quadPixels = g_quadUncertain = 0;
+    const bool quad = g_useQuad && rq.mode == AAI_MODE_AREA && quad_supported(r.side, r.c, r.s);
+    const QuadConsts<float> qc = make_quad_consts<float>(r.side, r.c, r.s, r.policy);
     for (int dy = 0; dy < r.dH; ++dy)
         for (int dx = 0; dx < r.dW; ++dx) {
             double px, py;
@@ -149,6 +185,21 @@ static void emu_rotated(const Geometry &g, const aai_request &rq, const float *i
             long knifeHere = 0;
             // the production pass flags whole dst pixels; only flagged ones reach the strict replay
             const bool flagged = pixel_on_knife_edge(r, px, py, rq.mode != AAI_MODE_FAST);
+            if (quad && !flagged) {
+                // the GPU's production pass for generic pixels: fp32, relative to the nearest virtual pixel
+                float value = 0.f;
+                bool done;
+                switch (qc.win) {
+                case 3: done = emu_quad_pixel<3>(qc, r, img, srcStride, px, py, value); break;
+                case 4: done = emu_quad_pixel<4>(qc, r, img, srcStride, px, py, value); break;
+                case 5: done = emu_quad_pixel<5>(qc, r, img, srcStride, px, py, value); break;
+                case 6: done = emu_quad_pixel<6>(qc, r, img, srcStride, px, py, value); break;
+                case 7: done = emu_quad_pixel<7>(qc, r, img, srcStride, px, py, value); break;
+                default: done = emu_quad_pixel<8>(qc, r, img, srcStride, px, py, value); break;
+                }
+                if (done) { *out = value; ++g_quadPixels; continue; }
+                ++g_quadUncertain;
+            }
             if (rq.mode == AAI_MODE_FAST && !flagged) {
                 // production pass: one interval of centres per line (see aai_rotated_kernel): lines are source rows when
                 // there is no replication (virtual rows in quadrants 0/2, virtual columns in 1/3), else virtual rows
@@ -344,6 +395,69 @@ int aai_emu_resample_channels(const aai_request *rq, int C, const float *src, fl
 }
 
 void aai_emu_force_general(int on) { g_forceGeneral = on; }
+void aai_emu_use_quad(int on) { g_useQuad = on; }
+void aai_emu_quad_stats(long *pixels, long *uncertain) { *pixels = g_quadPixels; *uncertain = g_quadUncertain; }
+
+// Pair-by-pair comparison of the quad formulation (evaluated in DOUBLE) with the older fast path and with the
+// strict replay of the reference, over every window position of every dst pixel of an area-mode request:
+//   maxOld     largest |quad - old fast path| over all pairs
+//   maxStrict  largest |quad - strict replay| over the pairs of dst pixels without a knife edge
+// Returns the number of pairs compared, -1 when the geometry is not served by the quad formulation.
+long aai_emu_quad_pair_check(const aai_request *rq, double *maxOld, double *maxStrict)
+{
+    Geometry g;
+    std::string msg;
+    *maxOld = *maxStrict = 0;
+    if (make_geometry(*rq, g, msg) != AAI_OK || g.axisAligned) return -1;
+    const RotLaunch r = make_rot_launch(g, AAI_MODE_AREA, rq->policy);
+    if (!quad_supported(r.side, r.c, r.s)) return -1;
+    const QuadConsts<double> q = make_quad_consts<double>(r.side, r.c, r.s, r.policy);
+    long n = 0;
+    for (int dy = 0; dy < r.dH; ++dy)
+        for (int dx = 0; dx < r.dW; ++dx) {
+            double px, py;
+            pixel_centre(r, dx, dy, px, py);
+            const bool flagged = pixel_on_knife_edge(r, px, py, true);
+            const double hb = r.h * (r.c + r.s);
+            const int x0 = (int)std::floor(px - hb + 0.5 - AAI_KNIFE_GUARD), x1 = (int)std::ceil(px + hb - 0.5 + AAI_KNIFE_GUARD);
+            const int y0 = (int)std::floor(py - hb + 0.5 - AAI_KNIFE_GUARD), y1 = (int)std::ceil(py + hb - 0.5 + AAI_KNIFE_GUARD);
+            SVec sv4[4];
+            strict_vertices(r, dx, dy, sv4);
+            int vX[4], vY[4]; double vfx[4], vfy[4];
+            for (int v = 0; v < 4; ++v) {
+                const double wx = px + q.ox[v], wy = py + q.oy[v];
+                vX[v] = (int)std::floor(wx + 0.5); vY[v] = (int)std::floor(wy + 0.5);
+                vfx[v] = wx - vX[v]; vfy[v] = wy - vY[v];
+            }
+            for (int Y = y0; Y <= y1; ++Y)
+                for (int X = x0; X <= x1; ++X) {
+                    const double ex = X - px, ey = Y - py;
+                    const double a = ex * r.c - ey * r.s, b = ex * r.s + ey * r.c;
+                    // older fast path
+                    double d = 0; bool e1 = false, e2 = false;
+                    const int cls = classify_pair<false>(r, a, b, d, e1);
+                    double old = 0;
+                    if (cls == PAIR_INSIDE) old = 1;
+                    else if (cls == PAIR_GENERAL) old = wedge_pair_area<false>(r, px - (X - 0.5), py - (Y - 0.5), a < 0.0, b < 0.0, r.policy, e2);
+                    else if (cls != PAIR_OUTSIDE) old = single_cut_area<false>(r, d, cls == PAIR_CUT_LR, r.policy, e2);
+                    // quad formulation
+                    const double A = q.h - std::fabs(a), B = q.h - std::fabs(b);
+                    const double mn = std::min(A, B), mx = std::max(A, B);
+                    double area = 0;
+                    int vtx = -1;
+                    for (int v = 0; v < 4; ++v) if (vX[v] == X && vY[v] == Y) vtx = v;
+                    if (vtx >= 0) area = quad_vertex_area(q, vfx[vtx], vfy[vtx], vtx);
+                    else if (mn <= -q.k) area = 0;
+                    else if (mn >= q.k) area = 1;
+                    else if (mx >= q.k) area = quad_cut(q, std::min(std::max(mn + q.k, 0.0), q.k2), A < B && q.ref);
+                    else { double nearS; area = quad_double<double, false>(q, A, B, (a < 0) == (b < 0), nearS); }
+                    *maxOld = std::max(*maxOld, std::fabs(area - old));
+                    if (!flagged) *maxStrict = std::max(*maxStrict, std::fabs(area - strict_pair_area(sv4, X, Y, r.policy)));
+                    ++n;
+                }
+        }
+    return n;
+}
 void aai_emu_set_strict(int on) { g_strict = on; }
 void aai_emu_knife_stats(long *pairs, long *pixels) { *pairs = g_knifePairs; *pixels = g_knifePixels; }
 long aai_emu_missed_knife_pairs(void) { return g_missedPairs; }

@@ -378,3 +378,86 @@ def test_interleaved_channel_tables_replay_equals_planar(aai, hostemu):
                     assert np.abs(dst[:, :, c] - planar).max() <= 1e-6
                 else:
                     assert np.array_equal(dst[:, :, c], planar), (k, W, H, sr, dr, ang, C, c)
+
+
+# ---- the fp32 quad formulation of the rotated area kernel (csrc/aai_rot_quad.hpp) ----------------------------------
+QUAD_GEOMETRIES = [  # W, H, srcRes, dstRes, angle, isocenter
+    (64, 64, 3.0, 1.0, 17.5, (31.5, 31.5)), (64, 64, 8192.0, 2731.0, 17.5, (31.5, 31.5)), (32, 32, 1.0, 4.0, 45.0, (15.5, 15.5)),
+    (40, 30, 2.0, 1.0, 33.3, (10.25, 3.5)), (40, 30, 1.7, 1.0, 117.0, (10.25, 3.5)), (40, 30, 4.0, 1.0, 10.0, (10.25, 3.5)),
+    (40, 30, 4.0, 1.0, 80.5, (10.25, 3.5)), (40, 30, 1.0, 1.0, 200.0, (0.0, 0.0)), (33, 47, 1.0, 2.0, 300.0, (40.0, -2.0)),
+    (50, 50, 2.5, 1.0, 61.0, (24.5, 24.5)), (48, 48, 1.0, 1.3, 27.0, (3.0, 44.0)),
+]
+
+
+def test_quad_formulas_equal_the_strict_replay_pair_by_pair(aai, hostemu):
+    """Every (dst pixel, source pixel) pair of a set of geometries: the quad formulation's area (single-line term,
+    segment-crossing sign tests, vertex pixels), evaluated in double precision, against the older closed forms and
+    against the operation-by-operation replay of the reference's classifier (Source.cpp:986-1431) -- both policies."""
+    rng = np.random.default_rng(23)
+    cases = list(QUAD_GEOMETRIES)
+    for k in range(30):
+        W, H = int(rng.integers(8, 60)), int(rng.integers(8, 60))
+        cases.append((W, H, float(rng.uniform(0.5, 4.2)), float(rng.uniform(0.5, 2.0)), float(rng.uniform(-400, 400)),
+                      (float(rng.uniform(-3, W + 3)), float(rng.uniform(-3, H + 3)))))
+    served = pairs = 0
+    for (W, H, sr, dr, ang, iso) in cases:
+        for policy in (0, 1):
+            n, vs_old, vs_strict = hostemu.quad_pair_check(aai.make_request(W, H, sr, dr, iso, ang, mode=1, policy=policy))
+            if n < 0:
+                continue            # window wider than the masks, or too close to an axis: served by the double-precision kernel
+            served += 1
+            pairs += n
+            assert vs_old <= 1e-11 and vs_strict <= 1e-11, (W, H, sr, dr, ang, iso, policy, vs_old, vs_strict)
+    assert served >= 60 and pairs > 500000
+
+
+def test_quad_fp32_replay_matches_small_golden(aai, hostemu, po, small_golden):
+    """The GPU's production arrangement replayed on the CPU: fp32 quad formulation for every dst pixel its scan does
+    not flag, the double-precision path (with the strict replay at knife edges) for the rest -- against the
+    unmodified reference's golden outputs, no pixel excepted."""
+    z, manifest = small_golden
+    hostemu.aai_emu_use_quad(1)
+    try:
+        quad = flagged = 0
+        for i, c in enumerate(manifest):
+            src = po.synth_image(c["W"], c["H"], c["seed"])
+            rq = aai.make_request(c["W"], c["H"], c["src_res"], c["dst_res"], c["iso"], c["angle"], mode=1)
+            out, axis = hostemu.resample(rq, src)
+            gold = z["c%03d_exact" % i]
+            q, u = hostemu.quad_stats()
+            quad += q
+            flagged += u
+            assert rel_err(out, gold).max() <= 0.3 * TOL, (i, c, float(rel_err(out, gold).max()))
+            assert np.array_equal(gold == 0, out == 0), i
+        assert quad > 30000 and flagged < 0.08 * quad, (quad, flagged)      # small images: many border pixels
+    finally:
+        hostemu.aai_emu_use_quad(0)
+
+
+def test_quad_fp32_replay_against_oracle_at_larger_sizes(aai, hostemu, po):
+    """BASELINE config 3's ratio and angle, config 5's (x4 up-sampling at 45 degrees: replicated virtual pixels) and a few
+    others at sizes where border pixels no longer dominate: error well inside the bar and few pixels left to the
+    double-precision pass."""
+    hostemu.aai_emu_use_quad(1)
+    try:
+        for (W, sr, dr, ang, policy) in ((768, 8192.0, 2731.0, 17.5, 0), (512, 3.0, 1.0, 33.0, 0), (128, 1.0, 4.0, 45.0, 0),
+                                         (256, 1.0, 1.0, 61.0, 0), (200, 1.0, 2.0, 117.5, 1), (384, 2.0, 1.0, 215.0, 0)):
+            src = po.synth_image(W, W, 2)
+            iso = ((W - 1) / 2, (W - 1) / 2)
+            out, axis = hostemu.resample(aai.make_request(W, W, sr, dr, iso, ang, mode=1, policy=policy), src)
+            q, u = hostemu.quad_stats()
+            gold = po.oracle_run(po.MODE_EXACT, src.astype(np.float64), sr, dr, iso, ang, policy=policy).dst
+            assert not axis and q > 0 and u < 0.01 * q, (W, sr, dr, ang, q, u)
+            assert rel_err(out, gold).max() <= 0.3 * TOL, (W, sr, dr, ang, float(rel_err(out, gold).max()))
+            assert np.array_equal(gold == 0, out == 0)
+    finally:
+        hostemu.aai_emu_use_quad(0)
+
+
+def test_quad_serves_the_baseline_rotated_configs(aai, hostemu):
+    """configs 3 and 5 take the quad kernel; near-axis rotations and wide footprints stay on the double-precision kernels"""
+    def pairs(W, sr, dr, ang):
+        return hostemu.quad_pair_check(aai.make_request(W, W, sr, dr, ((W - 1) / 2, (W - 1) / 2), ang, mode=1))[0]
+    assert pairs(48, 8192.0, 2731.0, 17.5) > 0 and pairs(24, 1.0, 4.0, 45.0) > 0
+    assert pairs(48, 4.0, 1.0, 0.5) < 0 and pairs(48, 2.0, 1.0, 89.5) < 0      # corner-triangle rule too steep for fp32 coordinates
+    assert pairs(64, 8.0, 1.0, 17.5) < 0                                        # window wider than 8 x 8
