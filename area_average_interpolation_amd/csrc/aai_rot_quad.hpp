@@ -142,11 +142,11 @@ AAI_HD F quad_double(const QuadConsts<F> &q, F A, F B, bool sameSign, F &nearS)
         if (cx < F(0.5) + q.margin) nearS = qmin(dx, qmin(qabs(cy - F(0.5)), qabs(cy + F(0.5))));
     }
     const F tu = qmin(qmax(u + q.k, F(0)), q.k2), tv = qmin(qmax(v + q.k, F(0)), q.k2);
-    const F gu = quad_cut(q, tu, false), gv = quad_cut(q, tv, false);
-    const F gl = quad_cut(q, sameSign ? tu : tv, q.ref != 0);          // the left/right edge alone
-    const F only1 = sameSign ? gl : gu, only2 = sameSign ? gv : gl;
-    const F both = qmax(gu + gv - F(1), F(0));
-    return S1 ? (S2 ? both : only1) : (S2 ? only2 : F(0));
+    // the reference's corner rule applies to a left/right edge that crosses the pixel ALONE
+    const F g1 = quad_cut(q, tu, sameSign && q.ref != 0 && !S2);
+    const F g2 = quad_cut(q, tv, !sameSign && q.ref != 0 && !S1);
+    const F both = qmax(g1 + g2 - F(1), F(0));
+    return S1 ? (S2 ? both : g1) : (S2 ? g2 : F(0));
 }
 
 // The pixel that holds vertex `vidx` of the dst square: area of the pixel inside the right-angled wedge the two
@@ -172,7 +172,7 @@ AAI_HD F quad_vertex_area(const QuadConsts<F> &q, F fx, F fy, int vidx)
     return F(0.5) * (dR * lenR + dT * lenT + dB * lenB);
 }
 
-AAI_HD int quad_ctz64(unsigned long long m)
+AAI_HD int quad_ctz(unsigned long long m)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
     return __ffsll((long long)m) - 1;
@@ -180,6 +180,17 @@ AAI_HD int quad_ctz64(unsigned long long m)
     return __builtin_ctzll(m);
 #endif
 }
+AAI_HD int quad_ctz(unsigned m)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __ffs((int)m) - 1;
+#else
+    return __builtin_ctz(m);
+#endif
+}
+// position masks: one bit per window slot -- 32 bits are enough up to 5 x 5
+template <int WIN, bool SMALL = (WIN * WIN <= 32)> struct QuadMask { typedef unsigned long long type; };
+template <int WIN> struct QuadMask<WIN, true> { typedef unsigned type; };
 
 // One dst pixel.  WIN = window positions per axis (QuadConsts::win, a compile-time constant so that the window pass
 // unrolls and the staged window has a fixed size); window position (i, j) is bit / slot j * WIN + i.
@@ -196,7 +207,7 @@ AAI_HD int quad_ctz64(unsigned long long m)
 template <typename F, int WIN, bool SCAN, typename Src>
 AAI_HD bool quad_pixel(const QuadConsts<F> &q, int Xc, int Yc, F fpx, F fpy, int mW, int mH, Src &src, F &sumA, F &sumVA)
 {
-    typedef unsigned long long u64;
+    typedef typename QuadMask<WIN>::type u64;          // (32 bits for windows up to 5 x 5)
     static_assert(WIN >= 2 && WIN <= kQuadMaxWin, "window size");
     sumA = F(0); sumVA = F(0);
     // window origin: first pixel centre the square's bounding box can reach
@@ -276,7 +287,7 @@ AAI_HD bool quad_pixel(const QuadConsts<F> &q, int Xc, int Yc, F fpx, F fpy, int
 
     // ---- pixels wholly inside: area 1 ------------------------------------------------------------------------------
     while (mIn) {
-        const int slot = quad_ctz64(mIn);
+        const int slot = quad_ctz(mIn);
         mIn &= mIn - 1;
         const F val = SCAN ? F(1) : (F)src.at(slot);
         sumA += F(1);
@@ -284,22 +295,21 @@ AAI_HD bool quad_pixel(const QuadConsts<F> &q, int Xc, int Yc, F fpx, F fpy, int
     }
     // ---- pixels cut by one edge line ---------------------------------------------------------------------------------
     while (mSingle) {
-        const int slot = quad_ctz64(mSingle);
+        const int slot = quad_ctz(mSingle);
         mSingle &= mSingle - 1;
         const int j = slot / WIN, i = slot - j * WIN;
         const F val = SCAN ? F(1) : (F)src.at(slot);
         const F fj = fj0 + (F)j, fi = fi0 + (F)i;
         const F a = qabs((ac - fj * q.s) + fi * q.c), b = qabs((bc + fj * q.c) + fi * q.s);
-        const F A = q.h - a, B = q.h - b;
-        const bool isLR = A < B;                              // the smaller inside-distance belongs to the cutting line
-        const F t = qmin(qmax((isLR ? A : B) + q.k, F(0)), q.k2);
+        const bool isLR = a > b;                              // the line nearer the pixel centre is the cutting one
+        const F t = qmin(qmax(q.hpk - qmax(a, b), F(0)), q.k2);      // its inside-distance + k
         const F area = quad_cut(q, t, isLR && q.ref != 0);
         sumA += area;
         sumVA += area * val;
     }
     // ---- pixels cut by both near edge lines --------------------------------------------------------------------------
     while (mDouble) {
-        const int slot = quad_ctz64(mDouble);
+        const int slot = quad_ctz(mDouble);
         mDouble &= mDouble - 1;
         const int j = slot / WIN, i = slot - j * WIN;
         const F val = SCAN ? F(1) : (F)src.at(slot);

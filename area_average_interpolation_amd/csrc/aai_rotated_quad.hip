@@ -85,8 +85,12 @@ struct NoSrc {
     __device__ __forceinline__ float at(int) const { return 1.f; }
 };
 
+// waves per SIMD that the staged windows leave room for (160 KiB of LDS per CU, WIN * WIN KiB per 256-lane block):
+// the register budget follows it
+constexpr int quad_waves_per_simd(int win) { return 160 / (win * win) >= 8 ? 8 : 160 / (win * win); }
+
 template <typename T, int WIN, bool SCALED>
-__global__ __launch_bounds__(kQuadBlock) void aai_quad_kernel(RotLaunch r, QuadConsts<float> q, QuadMap m, const T *__restrict__ src,
+__global__ __launch_bounds__(kQuadBlock, quad_waves_per_simd(WIN)) void aai_quad_kernel(RotLaunch r, QuadConsts<float> q, QuadMap m, const T *__restrict__ src,
                                                              ImageView sv, float *__restrict__ dst, ImageView dv)
 {
     __shared__ float window[WIN * WIN][kQuadBlock];
