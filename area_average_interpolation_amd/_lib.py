@@ -20,6 +20,7 @@ ERR_BAD_ARGUMENT = 6
 ERR_TOO_LARGE = 7
 ERR_NO_DEVICE = 8
 ERR_HIP = 9
+ERR_EMPTY_OUTPUT = 10
 
 MODE_AREA, MODE_FAST, MODE_BILINEAR, MODE_BICUBIC = 1, 2, 3, 4
 POLICY_REFERENCE, POLICY_EXACT = 0, 1
@@ -73,6 +74,8 @@ SYMBOLS = {
     "aai_band_source_rows": (ctypes.c_int, [_RQ, ctypes.c_int32, ctypes.c_int32, ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int32)]),
     "aai_resample_band_device_f32": (ctypes.c_int, [_RQ, ctypes.c_int32, ctypes.c_int32, _P, _I64, _P, _I64, _P]),
     "aai_synth_device_f32": (ctypes.c_int, [_P, ctypes.c_int32, ctypes.c_int32, _I64, ctypes.c_uint64, _P]),
+    "aai_synth_rows_device_f32": (ctypes.c_int, [_P, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, _I64, ctypes.c_uint64, _P]),
+    "aai_prepare": (ctypes.c_int, [_RQ, ctypes.c_int32]),
     "aai_last_kernel": (ctypes.c_char_p, []),
 }
 

@@ -98,8 +98,9 @@ def resample_host(src, src_resolution, dst_resolution, src_isocenter, rotation_a
             return rc, last_error(), None, None, None
         return rc, "", dst, (out_lay.dst_iso_x, out_lay.dst_iso_y), out_lay
     if a.ndim != 2:
-        # the reference's two "no data" errors (Source.cpp:123-132)
-        a = a.reshape(0, 0) if a.size == 0 else a
+        if a.size != 0:
+            raise ValueError("src must be a 2-D image [H, W] (interleaved [H, W, C] images: resample_interleaved_host)")
+        a = a.reshape(0, 0)        # the reference's two "no data" errors (Source.cpp:123-132)
     if a.dtype != np.float32:
         a = a.astype(np.float64, copy=False)
     a = np.ascontiguousarray(a)
@@ -120,32 +121,40 @@ def resample_host(src, src_resolution, dst_resolution, src_isocenter, rotation_a
 _NP_DTYPES = {np.dtype(np.float32): L.DTYPE_F32, np.dtype(np.uint8): L.DTYPE_U8, np.dtype(np.uint16): L.DTYPE_U16}
 
 
-class PinnedArray:
-    """A numpy array in page-locked host memory (aai_host_alloc = hipHostMalloc), so that the pipelined host-batch
-    entry copies asynchronously.  Use `.array`; the memory is released by close() / the context manager / GC."""
+class _PinnedBlock:
+    """Owner of one hipHostMalloc allocation: freed when the last numpy view of it is gone."""
 
-    def __init__(self, shape, dtype):
-        self._ptr = None
-        lib = L.load()
-        self._ptr = ctypes.c_void_p()
-        n = int(np.prod(shape)) * np.dtype(dtype).itemsize
-        rc = lib.aai_host_alloc(ctypes.byref(self._ptr), n)
+    def __init__(self, nbytes):
+        self.ptr = ctypes.c_void_p()
+        rc = L.load().aai_host_alloc(ctypes.byref(self.ptr), nbytes)
         if rc != L.OK:
             raise AaiError(rc, last_error())
-        buf = (ctypes.c_char * max(n, 1)).from_address(self._ptr.value)
-        self.array = np.frombuffer(buf, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
 
-    def close(self):
-        ptr = getattr(self, "_ptr", None)
+    def __del__(self):
+        ptr, self.ptr = getattr(self, "ptr", None), None
         if ptr is not None and ptr.value:
-            self.array = None
-            self._ptr = None
             try:
                 L.load().aai_host_free(ptr)
             except Exception:           # interpreter shutdown: the runtime may already be gone
                 pass
 
-    __del__ = close
+
+class PinnedArray:
+    """A numpy array in page-locked host memory (aai_host_alloc = hipHostMalloc), so that the pipelined host-batch
+    entry copies asynchronously.  Use `.array`.  The allocation is owned by the array's base object: close() (or
+    leaving the `with` block) only drops this object's reference, and the memory is released when the last numpy view
+    of it -- `.array`, slices of it, an `out=` result of resample_batch_host -- has been garbage-collected, so a view
+    held elsewhere never dangles."""
+
+    def __init__(self, shape, dtype):
+        n = int(np.prod(shape)) * np.dtype(dtype).itemsize
+        block = _PinnedBlock(max(n, 1))
+        buf = (ctypes.c_char * max(n, 1)).from_address(block.ptr.value)
+        buf._aai_owner = block            # ndarray.base -> buf -> block keeps the allocation alive
+        self.array = np.frombuffer(buf, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
+
+    def close(self):
+        self.array = None
 
     def __enter__(self):
         return self
@@ -245,6 +254,21 @@ def resample_band_device(request, dst_row0, dst_row1, src_rows_ptr, src_stride, 
     """aai_resample_band_device_f32: src_rows_ptr addresses source row band_source_rows(...)[0], dst_rows_ptr output row dst_row0."""
     rc = L.load().aai_resample_band_device_f32(ctypes.byref(request), int(dst_row0), int(dst_row1), src_rows_ptr, src_stride,
                                                dst_rows_ptr, dst_stride, stream)
+    if rc != L.OK:
+        raise AaiError(rc, last_error())
+
+
+def prepare(request, channels=1):
+    """aai_prepare: build (and cache) the plan of this request on the current device now -- K1 tables, the one-off
+    scans of a rotated geometry -- instead of inside the first resampling call, which would then synchronise."""
+    rc = L.load().aai_prepare(ctypes.byref(request), int(channels))
+    if rc != L.OK:
+        raise AaiError(rc, last_error())
+
+
+def synth_rows_device(dst_ptr, width, height, row0, row1, stride, seed, stream=0):
+    """rows [row0, row1) of the synthetic width x height image; dst_ptr addresses row row0"""
+    rc = L.load().aai_synth_rows_device_f32(dst_ptr, int(width), int(height), int(row0), int(row1), int(stride), int(seed), stream)
     if rc != L.OK:
         raise AaiError(rc, last_error())
 

@@ -128,6 +128,16 @@ int get_plan(const aai_request &rq, int band0, int band1, int channels, Plan **o
 {
     int dev = -1;
     AAI_HIP(hipGetDevice(&dev));
+    {
+        // Only K1's tables depend on the row band.  The per-pixel kernels take the band as launch parameters and their
+        // one-off scans cover the whole image, so every band of a rotated request shares one plan (and the fp64 / fp32
+        // kernels of the interleaved / planar paths flag different pixels: channels only matters as "one or several").
+        aai::Geometry g0;
+        std::string msg0;
+        int rc0 = aai::make_geometry(rq, g0, msg0);
+        if (rc0 != AAI_OK) return fail(rc0, msg0);
+        if (pick_kernel(rq, g0) != AAI_KERNEL_AXIS) { band0 = band1 = -1; channels = channels > 1 ? 2 : 1; }
+    }
     for (auto it = g_plans.begin(); it != g_plans.end(); ++it) {
         if (it->device == dev && it->band0 == band0 && it->band1 == band1 && it->channels == channels && same_request(it->key, rq)) {
             g_plans.splice(g_plans.begin(), g_plans, it);
@@ -159,8 +169,6 @@ int get_plan(const aai_request &rq, int band0, int band1, int channels, Plan **o
         if (e == hipSuccess) e = upload(p.tabs.strips.data(), p.tabs.strips.size() * sizeof(aai::AxisStrip), (void **)&p.dStrips);
         if (e != hipSuccess) { g_plans.pop_front(); return hip_fail(e, "uploading axis tables"); }
     }
-    if (band0 >= 0 && p.kernel != AAI_KERNEL_AXIS && p.kernel != AAI_KERNEL_AXIS_WIDE)
-        aai::rotated_band_source_rows(g, band0, band1, p.kernel == AAI_KERNEL_SAMPLE, p.srcRow0, p.srcRow1);
     if (p.kernel == AAI_KERNEL_ROTATED || p.kernel == AAI_KERNEL_FAST) {
         // one-off scans of this geometry (aai_knife_scan_kernel, and aai_quad_scan_kernel where the fp32 quad kernel
         // serves it); keeps the flags and the list of flagged waves only if there are any
@@ -248,7 +256,11 @@ int enqueue(const aai_request &rq, int batch, const void *dSrc, int srcType, int
                                  std::min(batch - b0, kMaxGridZ), stream, &name);
     } else {
         aai::RotLaunch r = aai::make_rot_launch(g, rq.mode, rq.policy);
-        if (band0 >= 0) { r.dyBase = band0; r.dyEnd = band1; r.srcRow0 = p->srcRow0; }
+        if (band0 >= 0) {
+            int srcRow0 = 0, srcRow1 = g.H;
+            aai::rotated_band_source_rows(g, band0, band1, p->kernel == AAI_KERNEL_SAMPLE, srcRow0, srcRow1);
+            r.dyBase = band0; r.dyEnd = band1; r.srcRow0 = srcRow0;
+        }
         r.chan = channels;
         const aai::QuadMap qm = aai::make_quad_map(g, srcStride, r.srcRow0);
         aai::RotFlags flags;
@@ -355,6 +367,7 @@ const char *aai_error_string(int code)
     case AAI_ERR_TOO_LARGE: return "Image too large.";
     case AAI_ERR_NO_DEVICE: return "No HIP device available.";
     case AAI_ERR_HIP: return "HIP runtime error.";
+    case AAI_ERR_EMPTY_OUTPUT: return "Output image would be empty.";
     default: return "Unknown error.";
     }
 }
@@ -481,6 +494,36 @@ int aai_resample_band_device_f32(const aai_request *req, int32_t dst_row0, int32
     return rc;
 }
 
+int aai_prepare(const aai_request *req, int32_t channels)
+{
+    int rc = check_request(req);
+    if (rc != AAI_OK) return rc;
+    if (channels < 1 || channels > 4) return fail(AAI_ERR_BAD_ARGUMENT, "Channels must be 1..4.");
+    {
+        aai::Geometry g;
+        std::string msg;
+        rc = aai::make_geometry(*req, g, msg);
+        if (rc != AAI_OK) return fail(rc, msg);
+    }
+    rc = require_device();
+    if (rc != AAI_OK) return rc;
+    std::lock_guard<std::mutex> lock(g_planMutex);
+    Plan *p = nullptr;
+    rc = get_plan(*req, -1, -1, channels, &p);
+    if (rc == AAI_OK) g_lastError.clear();
+    return rc;
+}
+
+int aai_synth_rows_device_f32(float *d_dst, int32_t width, int32_t height, int32_t row0, int32_t row1, int64_t stride, uint64_t seed, void *stream)
+{
+    if (!d_dst || width < 0 || height < 0 || row0 < 0 || row1 < row0 || row1 > height || stride < width)
+        return fail(AAI_ERR_BAD_ARGUMENT, "Bad synthetic image arguments.");
+    int rc = require_device();
+    if (rc != AAI_OK) return rc;
+    AAI_HIP(aai::launch_synth_rows(d_dst, width, height, row0, row1, stride, seed, (hipStream_t)stream));
+    return AAI_OK;
+}
+
 int aai_synth_device_f32(float *d_dst, int32_t width, int32_t height, int64_t stride, uint64_t seed, void *stream)
 {
     if (!d_dst || width < 0 || height < 0 || stride < width) return fail(AAI_ERR_BAD_ARGUMENT, "Bad synthetic image arguments.");
@@ -515,8 +558,7 @@ int aai_resample_host(const aai_request *req, const void *src, int32_t src_dtype
         hipError_t e__ = (call);                                               \
         if (e__ != hipSuccess) { cleanup(); return hip_fail(e__, #call); }     \
     } while (0)
-    // +16 bytes: the last lanes of a strip may read a whole 4-column vector that ends past the final element
-    AAI_HIP_C(hipMalloc(&dSrc, esz * (size_t)g.W * g.H + 16));
+    AAI_HIP_C(hipMalloc(&dSrc, esz * (size_t)g.W * g.H));      // no padding: every kernel clamps its vector loads into the image
     AAI_HIP_C(hipMemcpy2D(dSrc, esz * g.W, src, esz * src_stride, esz * g.W, g.H, hipMemcpyHostToDevice));
     if (nDst) {
         AAI_HIP_C(hipMalloc((void **)&dDst, sizeof(float) * nDst));
@@ -582,7 +624,7 @@ int aai_resample_interleaved_host(const aai_request *req, int32_t channels, cons
         hipError_t e__ = (call);                                               \
         if (e__ != hipSuccess) { cleanup(); return hip_fail(e__, #call); }     \
     } while (0)
-    AAI_HIP_C(hipMalloc(&dSrc, esz * (size_t)rowIn * g.H + 16));
+    AAI_HIP_C(hipMalloc(&dSrc, esz * (size_t)rowIn * g.H));
     AAI_HIP_C(hipMemcpy2D(dSrc, esz * rowIn, src, esz * src_stride, esz * rowIn, g.H, hipMemcpyHostToDevice));
     if (nDst) {
         AAI_HIP_C(hipMalloc((void **)&dDst, sizeof(float) * nDst));
@@ -688,7 +730,7 @@ int aai_resample_batch_host(const aai_request *req, int32_t batch, const void *s
     if (batch > 0 && nDst) {
         std::lock_guard<std::mutex> lock(g_slotMutex);
         SlotPool &p = g_slots;
-        AAI_HIP(p.reserve(esz * (size_t)g.W * g.H + 16, sizeof(float) * nDst));
+        AAI_HIP(p.reserve(esz * (size_t)g.W * g.H, sizeof(float) * nDst));
         // Pageable buffers: the runtime's blocking copy (pinned bounce buffers, double-buffered) is its fastest path
         // and the asynchronous one much slower, so only page-locked buffers are copied asynchronously.
         const bool asyncUp = is_page_locked(src), asyncDown = is_page_locked(dst);

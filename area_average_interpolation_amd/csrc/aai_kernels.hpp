@@ -62,6 +62,7 @@ hipError_t launch_quad(const RotLaunch &r, const QuadMap &m, const void *src, in
 
 // ---- utilities -----------------------------------------------------------------------------------------
 hipError_t launch_synth(float *dst, int W, int H, int64_t stride, uint64_t seed, hipStream_t stream);
+hipError_t launch_synth_rows(float *dst, int W, int H, int row0, int row1, int64_t stride, uint64_t seed, hipStream_t stream);
 hipError_t launch_f64_to_f32(const double *src, float *dst, size_t n, hipStream_t stream);
 hipError_t launch_f32_to_f64(const float *src, double *dst, size_t n, hipStream_t stream);
 

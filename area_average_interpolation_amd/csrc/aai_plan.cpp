@@ -80,6 +80,9 @@ int make_geometry(const aai_request &rq, Geometry &g, std::string &msg)
         msg = "Output image too large."; return AAI_ERR_TOO_LARGE;
     }
     o.dW = (int)dWr; o.dH = (int)dHr;
+    // The reference runs into undefined behaviour (a crash in practice) when either extent rounds to zero: its
+    // edge-line tables index row / column dstSize - 1 (Source.cpp:243-305).  Report it instead.
+    if (o.dW <= 0 || o.dH <= 0) { msg = "Output image would be empty."; return AAI_ERR_EMPTY_OUTPUT; }
     const double dix = (o.isoX * o.cs + (o.mH - o.isoY) * o.sn) * o.ratio;
     const double diy = (o.isoX * o.sn + o.isoY * o.cs) * o.ratio;
     if (std::fabs(dix) >= 2147483647.0 || std::fabs(diy) >= 2147483647.0) {
@@ -295,33 +298,38 @@ AxisEntry fold(const VirtRange &vr, int m, int scale, bool reversed, double othe
 }  // namespace
 
 // Greedy strips: consecutive lane-axis outputs whose windows fit in STRIP_COLS source columns (elements of a source
-// row: with interleaved channels a pixel takes `channels` of them).
+// row: with interleaved channels a pixel takes `channels` of them, and entry k = pixel * channels + channel).
+// Windows mostly ascend, but not strictly: a parked empty entry sits on its predecessor's window, and the channel
+// entries of neighbouring pixels interleave (pixel p+1's channel 0 starts below pixel p's channel 2 when both
+// pixels share source columns), so the strip tracks the extent [lo, hi] of EVERYTHING it has accepted.  Strips break
+// on pixel boundaries only (and hold at most 256 - 256 % channels outputs), so that the channels of one pixel never
+// land in two strips.
 static void build_axis_strips(AxisTables &t, int srcRowElements)
 {
     t.strips.clear();
     t.maxOutputsPerStrip = 0;
     t.wide = srcRowElements < 4;      // the strip kernel loads whole 4-column vectors
     const int n = (int)t.lane.size();
+    const int ch = t.channels > 1 ? t.channels : 1;
+    // at most 256 outputs per strip: the kernel then keeps four window descriptions per lane in registers and stores
+    // 16 bytes per lane (up-sampling would otherwise put >1000 outputs in a strip)
+    const int maxOutputs = 256 - 256 % ch;
     int k = 0;
     while (k < n) {
-        AxisStrip s{};
-        s.k0 = k; s.x0 = t.lane[k].s0;
-        int x0 = s.x0;
+        int lo = t.lane[k].s0, hi = t.lane[k].s1;
         int kk = k;
-        while (kk < n) {
-            // windows are ascending, but parked empties may sit lower; keep x0 = min.  Ascending windows make the
-            // last one the binding constraint for the (possibly lowered) origin.
-            const int lo2 = std::min(x0, t.lane[kk].s0);
-            const int hi2 = t.lane[kk].s1;
-            if (hi2 - lo2 + 1 > STRIP_COLS) break;
-            // at most 256 outputs per strip: the kernel then keeps four window descriptions per lane in
-            // registers and stores 16 bytes per lane (up-sampling would otherwise put >1000 outputs in a strip)
-            if (kk - k >= 256) break;
-            x0 = lo2;
-            ++kk;
+        while (kk < n && kk - k + ch <= maxOutputs) {
+            // the next pixel: all its channel entries, or nothing
+            int plo = lo, phi = hi;
+            for (int c = 0; c < ch && kk + c < n; ++c) { plo = std::min(plo, t.lane[kk + c].s0); phi = std::max(phi, t.lane[kk + c].s1); }
+            if (phi - plo + 1 > STRIP_COLS) break;
+            lo = plo; hi = phi;
+            kk += ch;
         }
-        if (kk == k) { t.wide = true; kk = k + 1; }   // a single window wider than a strip
-        s.x0 = x0; s.k1 = kk;
+        if (kk > n) kk = n;
+        if (kk == k) { t.wide = true; kk = std::min(n, k + ch); lo = t.lane[k].s0; }   // a single pixel wider than a strip
+        AxisStrip s{};
+        s.k0 = k; s.k1 = kk; s.x0 = lo;
         t.maxOutputsPerStrip = std::max(t.maxOutputsPerStrip, s.k1 - s.k0);
         t.strips.push_back(s);
         k = kk;
@@ -345,7 +353,7 @@ static void finalize_axis_tables(const Geometry &g, AxisTables &t)
     for (size_t i = 0; i + 1 < t.row.size(); ++i)
         if (t.row[i].wMid + t.row[i].wFirst > 0.f && t.row[i + 1].wMid + t.row[i + 1].wFirst > 0.f && t.row[i].s1 >= t.row[i + 1].s0) { t.rowsShared = true; break; }
 
-    build_axis_strips(t, g.W);
+    build_axis_strips(t, g.W * (t.channels > 1 ? t.channels : 1));
 }
 
 void build_axis_tables(const Geometry &g, int mode, AxisTables &t, int channels)
@@ -401,7 +409,7 @@ void build_axis_tables(const Geometry &g, int mode, AxisTables &t, int channels)
         t.lane.swap(wideLane);
         t.nA = (int)t.lane.size();
         t.channels = channels;
-        build_axis_strips(t, g.W * channels);
+        build_axis_strips(t, g.W * channels);      // (t.channels is set: strips break on pixel boundaries)
     }
 }
 

@@ -37,14 +37,21 @@ unsigned stride_grid(size_t n)
 
 }  // namespace
 
+// rows [row0, row1) of the W x H pattern; dst addresses row row0
+hipError_t launch_synth_rows(float *dst, int W, int H, int row0, int row1, int64_t stride, uint64_t seed, hipStream_t stream)
+{
+    if (W <= 0 || row1 <= row0) return hipSuccess;
+    for (int y0 = row0; y0 < row1; y0 += 32768) {   // grid.y is limited to 65535
+        const int rows = (row1 - y0 < 32768) ? row1 - y0 : 32768;
+        hipLaunchKernelGGL(aai_synth_kernel, dim3((W + 255) / 256, rows), dim3(256), 0, stream, dst - (int64_t)row0 * stride, W, row1, stride, seed, y0);
+    }
+    (void)H;
+    return hipGetLastError();
+}
+
 hipError_t launch_synth(float *dst, int W, int H, int64_t stride, uint64_t seed, hipStream_t stream)
 {
-    if (W <= 0 || H <= 0) return hipSuccess;
-    for (int y0 = 0; y0 < H; y0 += 32768) {   // grid.y is limited to 65535
-        const int rows = (H - y0 < 32768) ? H - y0 : 32768;
-        hipLaunchKernelGGL(aai_synth_kernel, dim3((W + 255) / 256, rows), dim3(256), 0, stream, dst, W, H, stride, seed, y0);
-    }
-    return hipGetLastError();
+    return launch_synth_rows(dst, W, H, 0, H, stride, seed, stream);
 }
 
 hipError_t launch_f64_to_f32(const double *src, float *dst, size_t n, hipStream_t stream)

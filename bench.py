@@ -7,64 +7,88 @@ A "step" is one pass of the hot path over one batch of `--batch` device-resident
 launch through the C ABI).  Images of a batch are distinct buffers (default 4 x 256 MiB = 1 GiB per GPU,
 four times the 256 MiB Infinity Cache), so every step streams its source from HBM.
 
-Multi-GPU (`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...`): one process per
-GPU, weak scaling -- every rank resamples its own shard of the batch (no data-path collective: the images
-are independent; the request block is broadcast once over RCCL before timing).  value = images of all
-ranks x output pixels / max-over-ranks time.
+Timing: W warm-up steps, then the block of K steps is run `repeats` times back to back between two fences
+(barrier + device synchronize); `repeats` is chosen from the warm-up so that the timed GPU leg lasts about
+`--min-seconds` (an outside telemetry probe can then see it); ms_per_step = elapsed / (repeats * K), taken as the
+MAX over ranks.  Every step is also bracketed by HIP events on the launch stream: their mean is the kernel time
+behind `roofline`, their min / median / max are reported as `step_ms`.
+
+Multi-GPU: `python bench.py --gpus N` starts N worker processes itself (one per GPU; the parent makes no GPU call
+and relays rank 0's single JSON line), or run it under `python -m torch.distributed.run --nproc-per-node N`.
+Weak scaling over the batch (`--shard batch`, default): every rank resamples its own shard of the batch, no
+data-path collective -- the request block is broadcast once over RCCL before timing; `--gather` adds an RCCL
+gather of the outputs to rank 0, reported separately.  `--shard rows`: ONE image per step split into dst row
+bands over the ranks (strong scaling; each rank generates only the source rows its band reads).
 
 Prints ONE JSON line on rank 0.
 """
 import argparse
-import ctypes
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-import torch                      # device memory, streams, torch.distributed: plumbing only
-import torch.distributed as dist
-
-import area_average_interpolation_amd as aai
-from area_average_interpolation_amd import distributed as D
-
 HBM_PEAK_GBPS = 8000.0            # MI355X HBM3E datasheet peak (MI355X_MICROARCH.md: 8.0 TB/s spec, ~6.3 TB/s copy)
+MODE_AREA, MODE_FAST, MODE_BILINEAR, MODE_BICUBIC = 1, 2, 3, 4      # include/aai.h
 
 # name -> (W, H, srcRes, dstRes, angle, mode, description)
 WORKLOADS = {
-    "cfg1": (512, 512, 2.0, 1.0, 0.0, aai.MODE_AREA, "512x512 fp32 -> 256x256, rotation 0"),
-    "cfg2": (8192, 8192, 4.0, 1.0, 0.0, aai.MODE_AREA, "8192x8192 fp32 -> 2048x2048, rotation 0"),
-    "cfg3": (8192, 8192, 8192.0, 2731.0, 17.5, aai.MODE_AREA, "8192x8192 fp32 -> 3426x3426 (ratio 2731/8192), rotation 17.5"),
-    "cfg3fast": (8192, 8192, 8192.0, 2731.0, 17.5, aai.MODE_FAST, "8192x8192 fp32 -> 3426x3426, rotation 17.5, fast mode"),
-    "cfg4": (4096, 4096, 4.0, 1.0, 0.0, aai.MODE_AREA, "4096x4096 fp32 -> 1024x1024, rotation 0"),
-    "cfg5s": (512, 512, 1.0, 4.0, 45.0, aai.MODE_AREA, "512x512 fp32 -> 2896x2896 (x4 up), rotation 45 (1/8 linear scale of cfg5)"),
-    "cfg5": (4096, 4096, 1.0, 4.0, 45.0, aai.MODE_AREA, "4096x4096 fp32 -> 23170x23170 (x4 up), rotation 45"),
-    "cfg5bilinear": (4096, 4096, 1.0, 4.0, 45.0, aai.MODE_BILINEAR, "4096x4096 fp32 -> 23170x23170, rotation 45, bilinear"),
-    "cfg5bicubic": (4096, 4096, 1.0, 4.0, 45.0, aai.MODE_BICUBIC, "4096x4096 fp32 -> 23170x23170, rotation 45, bicubic"),
+    "cfg1": (512, 512, 2.0, 1.0, 0.0, MODE_AREA, "512x512 fp32 -> 256x256, rotation 0"),
+    "cfg2": (8192, 8192, 4.0, 1.0, 0.0, MODE_AREA, "8192x8192 fp32 -> 2048x2048, rotation 0"),
+    "cfg3": (8192, 8192, 8192.0, 2731.0, 17.5, MODE_AREA, "8192x8192 fp32 -> 3426x3426 (ratio 2731/8192), rotation 17.5"),
+    "cfg3fast": (8192, 8192, 8192.0, 2731.0, 17.5, MODE_FAST, "8192x8192 fp32 -> 3426x3426, rotation 17.5, fast mode"),
+    "cfg4": (4096, 4096, 4.0, 1.0, 0.0, MODE_AREA, "4096x4096 fp32 -> 1024x1024, rotation 0"),
+    "cfg5s": (512, 512, 1.0, 4.0, 45.0, MODE_AREA, "512x512 fp32 -> 2896x2896 (x4 up), rotation 45 (1/8 linear scale of cfg5)"),
+    "cfg5": (4096, 4096, 1.0, 4.0, 45.0, MODE_AREA, "4096x4096 fp32 -> 23170x23170 (x4 up), rotation 45"),
+    "cfg5bilinear": (4096, 4096, 1.0, 4.0, 45.0, MODE_BILINEAR, "4096x4096 fp32 -> 23170x23170, rotation 45, bilinear"),
+    "cfg5bicubic": (4096, 4096, 1.0, 4.0, 45.0, MODE_BICUBIC, "4096x4096 fp32 -> 23170x23170, rotation 45, bicubic"),
 }
 
 
-def cpu_baseline(name, budget_s=15.0):
-    """CPU baseline on this box's host cores (1 thread: the reference is single-threaded), on a BOUNDED
-    sample of the same workload sized from a short probe to take about `budget_s` seconds.
+# ---- CPU baseline -----------------------------------------------------------------------------------------------
+def _cpu_model():
+    try:
+        return [l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name")][0]
+    except Exception:
+        return ""
+
+
+def _ref_band(args):
+    """One worker of the multi-process CPU baseline: the unmodified reference on a full-width band of image `seed`."""
+    W, rows, sr, dr, ang, omode, seed = args
+    import numpy as np
+    from oracle import pyoracle as po
+    src = po.synth_image(W, rows, seed).astype(np.float64)
+    t0 = time.perf_counter()
+    r = po.ref_run(omode, src, sr, dr, ((W - 1) / 2, (rows - 1) / 2), ang)
+    dt = time.perf_counter() - t0
+    assert r.ok, r.msg
+    return r.dst.size, dt
+
+
+def cpu_baseline(name, budget_s=15.0, procs=0, pool=None):
+    """CPU baseline on this box's host cores, on a BOUNDED sample of the same workload sized from a short probe to
+    take about `budget_s` seconds.
 
     kind "reference": the unmodified reference (oracle/_ref/libaai_ref.so, built from Source.cpp by
     oracle/Makefile) when that build travelled with the repo; the sample is a full-width band of the
     image for rotation 0 (same ratio, same per-pixel work: the reference's cost per output pixel does not
-    depend on the image height) or a square crop for rotated workloads.
+    depend on the image height) or a square crop for rotated workloads.  1 thread: the reference has none.
     kind "port": otherwise, the CPU oracle (oracle/aai_oracle.c) on a band of output rows of the full image.
+    procs > 0 ("N processes over images -- state N"): additionally N processes,
+    each running the reference on a band of its own image, reported as `nproc`.
     """
-    from oracle import pyoracle as po          # checker / baseline only; never on the product path
+    import ctypes
     import numpy as np
+    from oracle import pyoracle as po          # checker / baseline only; never on the product path
     W, H, sr, dr, ang, mode, _ = WORKLOADS[name]
-    omode = {aai.MODE_AREA: po.MODE_EXACT, aai.MODE_FAST: po.MODE_FAST}.get(mode, mode)
-    cpu_model = ""
-    try:
-        cpu_model = [l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name")][0]
-    except Exception:
-        pass
+    omode = {MODE_AREA: po.MODE_EXACT, MODE_FAST: po.MODE_FAST}.get(mode, mode)
+    cpu_model = _cpu_model()
 
     if po.have_ref():
         def run_crop(w, h):
@@ -86,12 +110,24 @@ def cpu_baseline(name, budget_s=15.0):
             n, t = run_crop(256, 256)
             side = int(min(W, max(256, 256 * (budget_s / max(t, 1e-6)) ** 0.5)))
             n, t = run_crop(side, side)
+            rows_src = side
             sample = "unmodified reference (Source.cpp via oracle/_ref) on a %dx%d crop with the same ratio/rotation: %d output pixels, %.1f s" % (side, side, n, t)
-        return {"value": n / t / 1e6, "unit": "Mpixels/s (output)", "cores": 1, "kind": "reference",
-                "sample": sample, "host_cpus": os.cpu_count(), "cpu_model": cpu_model}
+        out = {"value": n / t / 1e6, "unit": "Mpixels/s (output)", "cores": 1, "kind": "reference",
+               "sample": sample, "host_cpus": os.cpu_count(), "cpu_model": cpu_model}
+        if procs > 1 and ang == 0.0 and pool is not None:
+            jobs = [(W, rows_src, sr, dr, ang, omode, b + 1) for b in range(procs)]
+            t0 = time.perf_counter()
+            parts = pool.map(_ref_band, jobs)
+            wall = time.perf_counter() - t0
+            pix = sum(p[0] for p in parts)
+            out["nproc"] = {"processes": procs, "value": pix / max(p[1] for p in parts) / 1e6, "unit": "Mpixels/s (output)",
+                            "sample": "%d processes, each the unmodified reference on a %dx%d band of its own image (seed b+1); "
+                                      "slowest worker %.1f s, wall %.1f s" % (procs, W, rows_src, max(p[1] for p in parts), wall)}
+        return out
 
     if not po.have_oracle():
         po.build()
+    import area_average_interpolation_amd as aai
     lib = po._load_oracle()
     lib.aai_oracle_rows.restype = ctypes.c_int
     lib.aai_oracle_rows.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int] + \
@@ -120,6 +156,290 @@ def cpu_baseline(name, budget_s=15.0):
             "host_cpus": os.cpu_count(), "cpu_model": cpu_model}
 
 
+# ---- self-launch --------------------------------------------------------------------------------------------------
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def spawn_ranks(n, argv):
+    """`python bench.py --gpus N` without a launcher: start one fresh worker process per GPU (RANK / LOCAL_RANK /
+    WORLD_SIZE / MASTER_* in their environment, like torch.distributed.run sets them) and relay rank 0's single JSON
+    line.  This parent never touches the GPU (children are new processes, never an exec of one that has)."""
+    port = os.environ.get("MASTER_PORT") or str(_free_port())
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=port, AAI_BENCH_CHILD="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=(r == 0)))
+    # wait for all of them; a rank that dies takes the others (blocked in a rendezvous or a collective) with it
+    while True:
+        codes = [p.poll() for p in procs]
+        if any(c not in (None, 0) for c in codes):
+            for p in procs:
+                if p.poll() is None:
+                    p.kill()              # exactly the processes started above
+            break
+        if all(c == 0 for c in codes):
+            break
+        time.sleep(0.05)
+    out0 = procs[0].stdout.read() if procs[0].stdout else ""
+    codes = [p.wait() for p in procs]
+    lines = [l for l in (out0 or "").splitlines() if l.startswith("{")]
+    if any(codes) or len(lines) != 1:
+        sys.stderr.write("bench.py: worker exit codes %r, %d JSON line(s) from rank 0\n" % (codes, len(lines)))
+        sys.exit(1)
+    print(lines[0], flush=True)
+    sys.exit(0)
+
+
+# ---- one rank -----------------------------------------------------------------------------------------------------
+def worker(args):
+    import ctypes
+    import torch                      # device memory, streams, torch.distributed: plumbing only
+    import torch.distributed as dist
+    import area_average_interpolation_amd as aai
+    from area_average_interpolation_amd import distributed as D
+
+    saved_stdout = None
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    mock = args.mock_device          # CPU rehearsal of the launch / collective / reporting path (tests): no GPU call at all
+    if args.mock_fail_rank == rank:
+        sys.exit(3)
+    # the worker processes of the multi-process CPU baseline (config 4) are started BEFORE this process touches the GPU
+    cpu_procs = args.cpu_procs if args.cpu_procs >= 0 else (min(16, os.cpu_count() or 1) if args.workload == "cfg4" else 0)
+    cpu_pool = None
+    if cpu_procs > 1 and world == 1 and not args.no_cpu_baseline and not mock:
+        from multiprocessing import get_context
+        cpu_pool = get_context("spawn").Pool(cpu_procs)
+    if args.gpus > 1 or world > 1 or args.force_dist:
+        assert world == args.gpus, "WORLD_SIZE=%d but --gpus %d" % (world, args.gpus)
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        # RCCL printf()s its version banner (NCCL_DEBUG=VERSION on these boxes) to stdout when the communicator is created:
+        # park fd 1 on stderr until the ONE JSON line is due
+        sys.stdout.flush()
+        saved_stdout = os.dup(1)
+        os.dup2(2, 1)
+        if not mock:
+            local = local % torch.cuda.device_count()
+            torch.cuda.set_device(local)
+        if args.backend == "nccl" and not mock:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))  # nccl == RCCL on ROCm
+        else:
+            dist.init_process_group("gloo")
+    elif not mock:
+        local = 0
+        torch.cuda.set_device(0)
+    backend = dist.get_backend() if dist.is_initialized() else None
+    world_seen = dist.get_world_size() if dist.is_initialized() else 1
+    dev = torch.device("cpu") if mock else torch.device("cuda", local)
+    cdev = dev if (world == 1 or backend == "nccl") else torch.device("cpu")     # where collective payloads live
+    if not mock:
+        aai.set_device(local)
+
+    if args.custom:
+        f = args.custom.split(",")
+        WORKLOADS["custom"] = (int(f[0]), int(f[1]), float(f[2]), float(f[3]), float(f[4]),
+                               MODE_FAST if len(f) > 5 and f[5] == "fast" else MODE_AREA,
+                               "custom %sx%s fp32, resolution %s -> %s, rotation %s" % tuple(f[:5]))
+        args.workload = "custom"
+    W, H, sr, dr, ang, mode, desc = WORKLOADS[args.workload]
+    policy = aai.POLICY_REFERENCE if args.policy == "reference" else aai.POLICY_EXACT
+    rq = aai.make_request(W, H, sr, dr, ((W - 1) / 2, (H - 1) / 2), ang, mode=mode, policy=policy)
+    rq = D.broadcast_request(rq, src=0, device=cdev, force=args.force_dist)           # the only collective the path needs
+    rc, msg, lay = aai.query(rq)
+    assert rc == 0, msg
+    dW, dH = lay.dst_width, lay.dst_height
+    esz, dcode = {"f32": (4, aai.DTYPE_F32), "u8": (1, aai.DTYPE_U8), "u16": (2, aai.DTYPE_U16)}[args.src_dtype]
+    rows_mode = args.shard == "rows"
+
+    B = 1 if rows_mode else args.batch
+    if rows_mode:
+        assert args.src_dtype == "f32", "--shard rows runs on fp32 sources"
+        # ONE image per step: this rank's band of dst rows and the source rows that band reads (no collective, no halo
+        # exchange: the footprint is generated locally from the same stateless hash)
+        align = 1 if lay.kernel in (aai._lib.KERNEL_AXIS, aai._lib.KERNEL_AXIS_WIDE) else 16
+        r0, r1 = D.shard_rows(dH, rank, world, align=align)
+        s0, s1 = aai.band_source_rows(rq, r0, r1) if r1 > r0 else (0, 0)
+        total_images = 1
+        out_rows = r1 - r0
+        src_rows = s1 - s0
+    else:
+        total_images = B * world
+        first, last = D.shard_bounds(total_images, rank, world)
+        assert last - first == B
+        out_rows, src_rows = dH, H
+
+    if mock:
+        stream = 0
+
+        def step():
+            time.sleep(0.002)
+    else:
+        stream = torch.cuda.current_stream().cuda_stream
+        if rows_mode:
+            src = torch.empty((max(src_rows, 1), W), dtype=torch.float32, device=dev)
+            dst = torch.empty((max(out_rows, 1), dW), dtype=torch.float32, device=dev)
+            if src_rows:
+                aai.synth_rows_device(src.data_ptr(), W, H, s0, s1, W, 1, stream)
+                aai.prepare(rq)
+
+            def step():
+                if out_rows:
+                    aai.resample_band_device(rq, r0, r1, src.data_ptr(), W, dst.data_ptr(), dW, stream)
+        else:
+            src = torch.empty((B, H, W), dtype=torch.float32, device=dev)
+            dst = torch.empty((B, dH, dW), dtype=torch.float32, device=dev)
+            for b in range(B):
+                aai.synth_device(src[b].data_ptr(), W, H, W, first + b + 1, stream)       # image g uses seed g+1
+            if args.src_dtype == "u8":
+                src = (src * 256.0).to(torch.uint8)
+            elif args.src_dtype == "u16":
+                src = (src * 65536.0).to(torch.int32).to(torch.int16)                       # bit pattern of the uint16 value
+
+            def step():
+                aai.resample_device(rq, src.data_ptr(), W, dst.data_ptr(), dW, stream, batch=B,
+                                    src_image_stride=W * H, dst_image_stride=dW * dH, src_dtype=dcode)
+
+    def fence():
+        if not mock:
+            torch.cuda.synchronize()
+        if dist.is_initialized():
+            dist.barrier()
+        if not mock:
+            torch.cuda.synchronize()
+
+    def events(n):
+        if mock:
+            return None
+        return [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n)]
+
+    # warm-up (also builds the plan), then a short probe that sizes `repeats`
+    for _ in range(max(args.warmup, 1)):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    probe = max(time.perf_counter() - t0, 1e-6)
+    repeats = args.repeats if args.repeats > 0 else max(1, min(100000, int(args.min_seconds / probe + 0.999)))
+    if dist.is_initialized():
+        t = torch.tensor([repeats], dtype=torch.int64, device=cdev)
+        dist.broadcast(t, src=0)
+        repeats = int(t.item())
+
+    n_timed = repeats * args.steps
+    evs = events(n_timed)
+    fence()
+    t0 = time.perf_counter()
+    for i in range(n_timed):
+        if evs:
+            evs[i][0].record()
+        step()
+        if evs:
+            evs[i][1].record()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if evs:
+        per_step = sorted(a.elapsed_time(b) for a, b in evs)            # HIP events on the launch stream, ms
+    else:
+        per_step = [elapsed / n_timed * 1e3] * n_timed
+    kernel_ms = sum(per_step) / len(per_step)
+    kernel_name = "mock" if mock else aai.last_kernel()
+
+    t = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
+    if dist.is_initialized():
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+    rank_ms = [kernel_ms]
+    if dist.is_initialized():
+        mine = torch.tensor([kernel_ms], dtype=torch.float64, device=cdev)
+        every = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)
+        rank_ms = [float(x.item()) for x in every]
+
+    gather_ms = None
+    if args.gather and dist.is_initialized() and not mock:
+        fence()
+        g0 = time.perf_counter()
+        payload = dst if cdev == dev else dst.cpu()
+        if rows_mode:
+            # bands differ in height: pad to the tallest
+            tallest = max(D.shard_rows(dH, r, world, align=align)[1] - D.shard_rows(dH, r, world, align=align)[0] for r in range(world))
+            pad = torch.zeros((max(tallest, 1), dW), dtype=payload.dtype, device=payload.device)
+            pad[: payload.shape[0]] = payload
+            payload = pad
+        parts = [torch.empty_like(payload) for _ in range(world)] if rank == 0 else None
+        dist.gather(payload, gather_list=parts, dst=0)
+        fence()
+        gather_ms = (time.perf_counter() - g0) * 1e3
+
+    if rank == 0:
+        out_pix = total_images * dW * dH * n_timed
+        alg_bytes = B * (esz * W * src_rows + 4 * dW * out_rows)              # per launch on this GPU (SURVEY 8(d))
+        achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
+        traffic, traffic_source = None, None                                  # measured HBM bytes per launch (rocprofv3 PMC)
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json"))).get(args.workload)
+            if pmc and pmc["batch"] == B and args.src_dtype == "f32" and not rows_mode:
+                traffic = pmc["bytes_per_launch"]
+                traffic_source = "profiles/pmc_traffic.json: rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE) committed with the repository, " \
+                                 "NOT collected by this run (%s)" % pmc.get("measured", "see profiles/README.md")
+        except Exception:
+            pass
+        mid = len(per_step) // 2
+        line = {
+            "metric": "Mpixels/s (output) and achieved HBM GB/s, 8192^2->2048^2 fp32, 1/2/4/8 GPU",
+            "value": out_pix / elapsed / 1e6,
+            "unit": "Mpixels/s (output)",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / n_timed * 1e3,
+            "higher_is_better": True, "scaling": "strong" if rows_mode else "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic" if args.src_dtype == "f32" else "synthetic (%s source)" % args.src_dtype,
+            "config": {"workload": "%s: %s, area-average, %s weight policy, isocenter = image centre" % (args.workload, desc, args.policy)
+                       if mode == MODE_AREA else "%s: %s" % (args.workload, desc),
+                       "images_per_gpu_per_step": B if not rows_mode else 1.0 / world, "src_bytes_per_gpu": esz * W * src_rows * B,
+                       "parallelism": ("one image in %d row bands" if rows_mode else "batch-sharded x%d") % world},
+            "timed": {"repeats": repeats, "steps_timed": n_timed, "seconds": elapsed,
+                      "step_ms": {"min": per_step[0], "median": per_step[mid], "max": per_step[-1]}},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_source,
+                         "kernel": kernel_name, "kernel_ms_per_launch": kernel_ms, "algorithmic_bytes_per_launch": alg_bytes},
+            "src_gbps_input_rate": esz * W * src_rows * B / (kernel_ms * 1e-3) / 1e9,
+            "distributed": {"backend": backend, "world_size_seen": world_seen, "kernel_ms_per_rank": rank_ms,
+                            "value_compute_only": out_pix / elapsed / 1e6},
+        }
+        if mock:
+            line["mock"] = True
+        if gather_ms is not None:
+            line["distributed"]["gather_ms"] = gather_ms
+            line["distributed"]["value_with_gather"] = total_images * dW * dH / (elapsed / n_timed + gather_ms * 1e-3) / 1e6
+        if world == 1 and not args.no_cpu_baseline and not mock and mode in (MODE_AREA, MODE_FAST):
+            line["cpu_baseline"] = cpu_baseline(args.workload, procs=cpu_procs, pool=cpu_pool)
+            line["cpu_baseline"]["gpu_over_cpu"] = line["value"] / line["cpu_baseline"]["value"]
+        if saved_stdout is not None:
+            sys.stdout.flush()
+            ctypes.CDLL(None).fflush(None)          # whatever C stdio still holds goes to stderr, not after the JSON line
+            os.dup2(saved_stdout, 1)
+            os.close(saved_stdout)
+            saved_stdout = None
+        print(json.dumps(line), flush=True)
+    if cpu_pool is not None:
+        cpu_pool.close()
+        cpu_pool.join()
+    if dist.is_initialized():
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -132,149 +452,25 @@ def main():
     ap.add_argument("--policy", default="reference", choices=["reference", "exact"])
     ap.add_argument("--src-dtype", default="f32", choices=["f32", "u8", "u16"],
                     help="source element type (the headline metric is f32; u8/u16 exercise the typed entry points)")
+    ap.add_argument("--shard", default="batch", choices=["batch", "rows"],
+                    help="batch: every rank resamples its own images (weak scaling); rows: ONE image split into dst row bands (strong scaling)")
+    ap.add_argument("--min-seconds", type=float, default=1.5, help="the timed leg repeats the block of --steps until it lasts about this long")
+    ap.add_argument("--repeats", type=int, default=0, help="fix the number of repeats of the --steps block (0 = from --min-seconds)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-procs", type=int, default=-1, help="processes of the extra multi-process CPU baseline (default: min(16, cores) for cfg4, else none)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend; nccl (= RCCL) is the real one, gloo lets two ranks rehearse on one GPU")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise torch.distributed even with one rank (rehearses the RCCL code path on a single GPU)")
     ap.add_argument("--gather", action="store_true", help="also time an RCCL gather of the outputs to rank 0 (reported separately)")
+    ap.add_argument("--mock-device", action="store_true", help=argparse.SUPPRESS)      # tests: launch / collective / report path on CPU
+    ap.add_argument("--mock-fail-rank", type=int, default=-1, help=argparse.SUPPRESS)
     args = ap.parse_args()
 
-    saved_stdout = None
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus > 1 or world > 1 or args.force_dist:
-        assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        # RCCL printf()s its version banner (NCCL_DEBUG=VERSION on these boxes) to stdout when the communicator is created:
-        # park fd 1 on stderr until the ONE JSON line is due
-        sys.stdout.flush()
-        saved_stdout = os.dup(1)
-        os.dup2(2, 1)
-        local = local % torch.cuda.device_count()
-        torch.cuda.set_device(local)
-        if args.backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local))  # nccl == RCCL on ROCm
-        else:
-            dist.init_process_group("gloo")
-    else:
-        local = 0
-        torch.cuda.set_device(0)
-    dev = torch.device("cuda", local)
-    cdev = dev if (world == 1 or args.backend == "nccl") else torch.device("cpu")     # where collective payloads live
-    aai.set_device(local)
-
-    if args.custom:
-        f = args.custom.split(",")
-        WORKLOADS["custom"] = (int(f[0]), int(f[1]), float(f[2]), float(f[3]), float(f[4]),
-                               aai.MODE_FAST if len(f) > 5 and f[5] == "fast" else aai.MODE_AREA,
-                               "custom %sx%s fp32, resolution %s -> %s, rotation %s" % tuple(f[:5]))
-        args.workload = "custom"
-    W, H, sr, dr, ang, mode, desc = WORKLOADS[args.workload]
-    policy = aai.POLICY_REFERENCE if args.policy == "reference" else aai.POLICY_EXACT
-    rq = aai.make_request(W, H, sr, dr, ((W - 1) / 2, (H - 1) / 2), ang, mode=mode, policy=policy)
-    rq = D.broadcast_request(rq, src=0, device=cdev, force=args.force_dist)           # the only collective the path needs
-    rc, msg, lay = aai.query(rq)
-    assert rc == 0, msg
-    dW, dH = lay.dst_width, lay.dst_height
-
-    B = args.batch
-    total_images = B * world
-    first, last = D.shard_bounds(total_images, rank, world)
-    assert last - first == B
-    src = torch.empty((B, H, W), dtype=torch.float32, device=dev)
-    dst = torch.empty((B, dH, dW), dtype=torch.float32, device=dev)
-    stream = torch.cuda.current_stream().cuda_stream
-    for b in range(B):
-        aai.synth_device(src[b].data_ptr(), W, H, W, first + b + 1, stream)       # image g uses seed g+1
-    esz, dcode = {"f32": (4, aai.DTYPE_F32), "u8": (1, aai.DTYPE_U8), "u16": (2, aai.DTYPE_U16)}[args.src_dtype]
-    if args.src_dtype == "u8":
-        src = (src * 256.0).to(torch.uint8)
-    elif args.src_dtype == "u16":
-        src = (src * 65536.0).to(torch.int32).to(torch.int16)                       # bit pattern of the uint16 value
-
-    def step():
-        aai.resample_device(rq, src.data_ptr(), W, dst.data_ptr(), dW, stream, batch=B,
-                            src_image_stride=W * H, dst_image_stride=dW * dH, src_dtype=dcode)
-
-    def fence():
-        torch.cuda.synchronize()
-        if dist.is_initialized():
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
-        step()
-    fence()
-    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
-    t0 = time.perf_counter()
-    for a, b in evs:
-        a.record()
-        step()
-        b.record()
-    fence()
-    elapsed = time.perf_counter() - t0
-    kernel_ms = sum(a.elapsed_time(b) for a, b in evs) / args.steps          # HIP events on the launch stream
-    kernel_name = aai.last_kernel()
-
-    t = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
-    if dist.is_initialized():
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed = float(t.item())
-
-    gather_ms = None
-    if args.gather and dist.is_initialized():
-        fence()
-        g0 = time.perf_counter()
-        payload = dst if cdev == dev else dst.cpu()
-        parts = [torch.empty_like(payload) for _ in range(world)] if rank == 0 else None
-        dist.gather(payload, gather_list=parts, dst=0)
-        fence()
-        gather_ms = (time.perf_counter() - g0) * 1e3
-
-    if rank == 0:
-        out_pix = total_images * dW * dH * args.steps
-        alg_bytes = B * (esz * W * H + 4 * dW * dH)                           # per launch, per GPU
-        achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
-        traffic = None                                                        # measured HBM bytes per launch (rocprofv3 PMC)
-        try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json"))).get(args.workload)
-            if pmc and pmc["batch"] == B and args.src_dtype == "f32":
-                traffic = pmc["bytes_per_launch"]
-        except Exception:
-            pass
-        line = {
-            "metric": "Mpixels/s (output) and achieved HBM GB/s, 8192^2->2048^2 fp32, 1/2/4/8 GPU",
-            "value": out_pix / elapsed / 1e6,
-            "unit": "Mpixels/s (output)",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic" if args.src_dtype == "f32" else "synthetic (%s source)" % args.src_dtype,
-            "config": {"workload": "%s: %s, area-average, %s weight policy, isocenter = image centre" % (args.workload, desc, args.policy)
-                       if mode == aai.MODE_AREA else "%s: %s" % (args.workload, desc),
-                       "images_per_gpu_per_step": B, "src_bytes_per_gpu": esz * W * H * B, "parallelism": "batch-sharded x%d" % world},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
-                         "kernel": kernel_name, "kernel_ms_per_launch": kernel_ms, "algorithmic_bytes_per_launch": alg_bytes},
-            "src_gbps_input_rate": esz * W * H * B / (kernel_ms * 1e-3) / 1e9,
-        }
-        if gather_ms is not None:
-            line["gather_ms"] = gather_ms
-        if world == 1 and not args.no_cpu_baseline and mode in (aai.MODE_AREA, aai.MODE_FAST):
-            line["cpu_baseline"] = cpu_baseline(args.workload)
-            line["cpu_baseline"]["gpu_over_cpu"] = line["value"] / line["cpu_baseline"]["value"]
-        if saved_stdout is not None:
-            sys.stdout.flush()
-            ctypes.CDLL(None).fflush(None)          # whatever C stdio still holds goes to stderr, not after the JSON line
-            os.dup2(saved_stdout, 1)
-            os.close(saved_stdout)
-            saved_stdout = None
-        print(json.dumps(line), flush=True)
-    if dist.is_initialized():
-        dist.barrier()
-        dist.destroy_process_group()
+    # No launcher around us and more than one GPU asked for: become the launcher (and never touch the GPU ourselves).
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        spawn_ranks(args.gpus, sys.argv[1:])
+    worker(args)
 
 
 if __name__ == "__main__":

@@ -46,7 +46,9 @@ enum {
     AAI_ERR_BAD_ARGUMENT = 6,         /* null pointer, unknown mode/policy, stride < width, batch < 0 ... */
     AAI_ERR_TOO_LARGE = 7,            /* output or virtual source would overflow 31-bit indexing */
     AAI_ERR_NO_DEVICE = 8,            /* no HIP device / runtime unavailable: the product has NO CPU fallback */
-    AAI_ERR_HIP = 9                   /* a HIP runtime call failed; message holds hipGetErrorString */
+    AAI_ERR_HIP = 9,                  /* a HIP runtime call failed; message holds hipGetErrorString */
+    AAI_ERR_EMPTY_OUTPUT = 10         /* dst width or height rounds to 0 (Source.cpp:179-180): the reference crashes there (its edge-line
+                                         tables index dstSize - 1, Source.cpp:243-305); we report it */
 };
 
 /* ---- what to compute ---------------------------------------------------------------------- */
@@ -132,7 +134,12 @@ int aai_resample_f64(const aai_request *req, const double *src, int64_t src_stri
 /* ---- resampling: device-resident buffers (the measured hot path) ---------------------------------------
  * Replaces the loops of Source.cpp:413-579 / 868-907 (and the modSrc / dstPos / edge-line tables of
  * Source.cpp:150-305, which are never materialised).  `stream` is a hipStream_t passed as void* (NULL =
- * default stream); the call only enqueues work and returns. */
+ * default stream).  The call only enqueues work and returns -- except the FIRST call for a given (request, device):
+ * that one builds the plan (K1: weight tables uploaded with blocking copies; rotated requests: one-off scans of the
+ * geometry for pixels that need the double-precision pass, read back with a blocking copy), so it synchronises with the
+ * device and must not run inside a stream capture.  aai_prepare takes that cost up front; plans are cached per
+ * process (32 most recently used), shared by batches, row bands (rotated requests) and streams. */
+int aai_prepare(const aai_request *req, int32_t channels /* 1 for plain images; 2..4: interleaved */);
 int aai_resample_device_f32(const aai_request *req, const float *d_src, int64_t src_stride,
                             float *d_dst, int64_t dst_stride, void *stream);
 
@@ -195,6 +202,9 @@ int aai_resample_band_device_f32(const aai_request *req, int32_t dst_row0, int32
  * known-answer test: idx = y*width + x, seed as given (image b of a batch uses seed b+1). */
 int aai_synth_device_f32(float *d_dst, int32_t width, int32_t height, int64_t stride,
                          uint64_t seed, void *stream);
+/* rows [row0, row1) of that width x height pattern only; d_dst addresses row row0 (the source footprint of a row band) */
+int aai_synth_rows_device_f32(float *d_dst, int32_t width, int32_t height, int32_t row0, int32_t row1, int64_t stride,
+                              uint64_t seed, void *stream);
 
 /* Name and launch geometry of the kernel that served the most recent device call on this thread
  * (for profiling / bench bookkeeping). */

@@ -146,9 +146,59 @@ def small_golden():
     return z, manifest
 
 
+@pytest.fixture(scope="session")
+def knife_golden():
+    """outputs of the UNMODIFIED reference on the structured knife-edge geometries (tests/golden/make_golden.py knife)"""
+    z = np.load(os.path.join(GOLDEN, "knife_cases.npz"))
+    manifest = json.loads(bytes(z["manifest"]).decode())
+    return z, manifest
+
+
 def load_full(name):
     z = np.load(os.path.join(GOLDEN, "full_%s.npz" % name))
     return z, json.loads(bytes(z["meta"]).decode())
+
+
+def sample_points(rq, lay, rows, device):
+    """Continuous original-image coordinates (pixel centres at integers) of the dst pixel centres of the given dst rows:
+    the reference's affine map restated from SURVEY.md Appendix A.1-A.3 (Source.cpp:139-219) in float64 torch."""
+    import math
+    import torch
+    W, H = rq.src_width, rq.src_height
+    rho = rq.dst_res_x / rq.src_res_x
+    scale = int(rho * math.sqrt(2.0) + 1 + 2.220446049250313e-16)
+    ang = rq.rotation_deg % 360.0
+    quadrant = int(ang // 90)
+    th = math.radians(ang - 90 * quadrant)
+    c, s = math.cos(th), math.sin(th)
+    mW, mH = ((H, W) if quadrant & 1 else (W, H))
+    mW, mH = mW * scale, mH * scale
+    isoX = rq.src_iso_x * scale + (scale - 1) / 2.0
+    isoY = rq.src_iso_y * scale + (scale - 1) / 2.0
+    r = rho / scale
+    L = 1.0 / r
+    Dx = (isoX * c + (mH - isoY) * s) * r
+    Dy = (isoX * s + isoY * c) * r
+    fx, fy = Dx - int(Dx), Dy - int(Dy)
+    corners = [(-isoX, -isoY), (mW - 1 - isoX, -isoY), (-isoX, mH - 1 - isoY), (mW - 1 - isoX, mH - 1 - isoY)]
+    offX = min([0.0] + [u * c - v * s + isoX for (u, v) in corners])
+    offY = min([0.0] + [u * s + v * c + isoY for (u, v) in corners])
+    assert (lay.scale, lay.quadrant) == (scale, quadrant)
+    dx = torch.arange(lay.dst_width, dtype=torch.float64, device=device)[None, :]
+    dy = torch.as_tensor(rows, dtype=torch.float64, device=device)[:, None]
+    Px = (dx + fx) * L - isoX + offX
+    Py = (dy + fy) * L - isoY + offY
+    X = Px * c + Py * s + isoX
+    Y = -Px * s + Py * c + isoY
+    if quadrant == 0:
+        sx, sy = (X + 0.5) / scale - 0.5, (Y + 0.5) / scale - 0.5
+    elif quadrant == 1:
+        sx, sy = (Y + 0.5) / scale - 0.5, (mW - 1 - X + 0.5) / scale - 0.5
+    elif quadrant == 2:
+        sx, sy = (mW - 1 - X + 0.5) / scale - 0.5, (mH - 1 - Y + 0.5) / scale - 0.5
+    else:
+        sx, sy = (mH - 1 - Y + 0.5) / scale - 0.5, (X + 0.5) / scale - 0.5
+    return sx, sy
 
 
 def rel_err(got, gold, floor=1e-3):

@@ -18,6 +18,110 @@
 
 using namespace aai;
 
+// ---- the four-edge form of the pair area: a cross-check of the product's closed forms, used by tests only ------------
+namespace aai {
+// integral over eta in [e0,e1] intersect [0,1] of clamp01(x(eta)), x(eta) = x0 + (eta-e0)*m
+template <bool INCREASING>
+AAI_HD double clamp_integral(double e0, double e1, double x0, double m, double im)
+{
+    const double a = fmax(e0, 0.0), b = fmin(e1, 1.0);
+    if (!(a < b)) return 0.0;
+    const double t0 = e0 - x0 * im;           // eta where x == 0
+    const double t1 = e0 + (1.0 - x0) * im;   // eta where x == 1
+    double ones, p, q;
+    if (INCREASING) { ones = fmax(b - fmax(a, t1), 0.0); p = fmax(a, t0); q = fmin(b, t1); }
+    else            { ones = fmax(fmin(b, t1) - a, 0.0); p = fmax(a, t1); q = fmin(b, t0); }
+    double ramp = 0.0;
+    if (q > p) {
+        const double xp = clamp01(x0 + (p - e0) * m), xq = clamp01(x0 + (q - e0) * m);
+        ramp = (q - p) * 0.5 * (xp + xq);
+    }
+    return ones + ramp;
+}
+
+// Overlap area of the dst square with the unit source pixel whose top-left corner is the local origin,
+// for any configuration (two edges, a dst vertex inside, ...).  lx,ly = dst centre in local coordinates.
+// policy REFERENCE applies the Appendix-B.2 substitution when a lone left/right edge SEGMENT cuts a corner.
+template <bool KNIFE>
+AAI_HD double pair_area(const RotLaunch &f, double lx, double ly, int policy, bool &edgy)
+{
+    if (KNIFE) edgy = false;
+    const double v0x = lx + f.o0x, v0y = ly + f.o0y;
+    const double v1x = lx + f.o1x, v1y = ly + f.o1y;
+    const double v2x = lx - f.o1x, v2y = ly - f.o1y;
+    const double v3x = lx - f.o0x, v3y = ly - f.o0y;
+
+    // exact area: right boundary (v1 -> v3 -> v2) minus left boundary (v1 -> v0 -> v2), clamped to [0,1]
+    double area = clamp_integral<true>(v1y, v3y, v1x, f.m1, f.im1)     // right edge
+                + clamp_integral<false>(v3y, v2y, v3x, f.m2, f.im2)    // bottom edge
+                - clamp_integral<false>(v1y, v0y, v1x, f.m2, f.im2)    // top edge
+                - clamp_integral<true>(v0y, v2y, v0x, f.m1, f.im1);    // left edge
+    area = clamp01(area);
+
+    // Knife edges, where the reference's answer hangs on its DBL_EPSILON rules (Source.cpp:330-342, 401-408,
+    // 500-564, 1430) and its area jumps: (a) a dst vertex on a side of the pixel, (b) a dst edge through a
+    // corner of the pixel.  "On" = within AAI_KNIFE_GUARD.  (Per-pair form, used by the fix-up pass only; the
+    // production pass tests the dst pixel as a whole with pixel_on_knife_edge below.)
+    if (KNIFE) {
+        const double g = AAI_KNIFE_GUARD, L = 2.0 * f.h;
+        auto onSide = [&](double vx, double vy) {
+            const double ex = fmin(fabs(vx), fabs(vx - 1.0)), ey = fmin(fabs(vy), fabs(vy - 1.0));
+            const bool inx = vx > -g && vx < 1.0 + g, iny = vy > -g && vy < 1.0 + g;
+            return (ex < g && iny) || (ey < g && inx);
+        };
+        if (onSide(v0x, v0y) || onSide(v1x, v1y) || onSide(v2x, v2y) || onSide(v3x, v3y)) edgy = true;
+        // inside-distances of the pixel's top-left corner from the left and the top edge line; the other
+        // corners and edges follow by adding c, s and subtracting from L
+        const double dl0 = -v0x * f.c + v0y * f.s, dt0 = -v0x * f.s - v0y * f.c;
+        auto onEdge = [&](double dl, double dt) {
+            const double dr = L - dl, db = L - dt;
+            return (fmin(fabs(dl), fabs(dr)) < g && dt > -g && db > -g) || (fmin(fabs(dt), fabs(db)) < g && dl > -g && dr > -g);
+        };
+        if (onEdge(dl0, dt0) || onEdge(dl0 + f.c, dt0 + f.s) || onEdge(dl0 - f.s, dt0 + f.c) || onEdge(dl0 + f.c - f.s, dt0 + f.s + f.c)) edgy = true;
+    }
+
+    // Which dst edges (as segments) pass through the pixel?  Slab clip of A + t*D, t in [0,1].
+    // top/bottom edges run along (c,-s): they enter through the left or bottom side.
+    {
+        const double txa = -v0x * f.rLc, txb = (1.0 - v0x) * f.rLc;
+        const double tya = (v0y - 1.0) * f.rLs, tyb = v0y * f.rLs;
+        if (fmax(fmax(txa, tya), 0.0) < fmin(fmin(txb, tyb), 1.0)) return area;   // top edge crosses
+    }
+    {
+        const double txa = -v2x * f.rLc, txb = (1.0 - v2x) * f.rLc;
+        const double tya = (v2y - 1.0) * f.rLs, tyb = v2y * f.rLs;
+        if (fmax(fmax(txa, tya), 0.0) < fmin(fmin(txb, tyb), 1.0)) return area;   // bottom edge crosses
+    }
+    // left/right edges run along (s,c): they enter through the top or left side and leave through the
+    // bottom or right side.  At most one of them can reach the pixel (they are L > sqrt 2 apart).
+    double ax = v0x, ay = v0y;
+    bool isLeft = true;
+    {
+        const double gl = fabs((0.5 - v0x) * f.c - (0.5 - v0y) * f.s);   // distance of the pixel centre to the left edge line
+        const double gr = fabs((0.5 - v1x) * f.c - (0.5 - v1y) * f.s);
+        if (gr < gl) { ax = v1x; ay = v1y; isLeft = false; }
+    }
+    const double txa = -ax * f.rLs, txb = (1.0 - ax) * f.rLs;      // x = 0, x = 1
+    const double tya = -ay * f.rLc, tyb = (1.0 - ay) * f.rLc;      // y = 0, y = 1
+    const double tin = fmax(txa, tya), tout = fmin(txb, tyb);
+    if (!(tin < tout) || !(tin > 0.0) || !(tout < 1.0)) return area;   // misses, or a dst vertex lies inside
+    const bool inTop = tya > txa, outRight = txb < tyb;
+    if (inTop != outRight) return area;                            // opposite sides: a straight cut, exact
+    if (policy != AAI_POLICY_REFERENCE) return area;
+    double tri;
+    if (inTop) {   // cuts the top-right corner: reference legs xa and 1-yb
+        const double xin = ax + tin * f.Ls, yout = ay + tout * f.Lc;
+        tri = 0.5 * xin * (1.0 - yout);
+    } else {       // cuts the bottom-left corner: reference legs 1-xb and ya
+        const double yin = ay + tin * f.Lc, xout = ax + tout * f.Ls;
+        tri = 0.5 * (1.0 - xout) * yin;
+    }
+    // left edge + top-right corner, or right edge + bottom-left corner: the corner is the inside part
+    return (isLeft == inTop) ? tri : 1.0 - tri;
+}
+
+}  // namespace aai
+
 static float row_w(const AxisEntry &e, int y) { return y == e.s0 ? e.wFirst : (y == e.s1 ? e.wLast : e.wMid); }
 
 static void emu_axis(const Geometry &g, int mode, const float *src, int64_t srcStride, float *dst, int64_t dstStride)
@@ -521,6 +625,27 @@ int aai_emu_axis_invariants(const aai_request *rq)
         next = s.k1;
     }
     if (next != t.nA) return 6;
+    // interleaved channels: entry k = pixel * C + channel over the ELEMENTS of the source row; strips still partition the
+    // lane axis, break on pixel boundaries only, hold <= 256 outputs and contain every window they own (windows of
+    // neighbouring pixels' channels interleave, and parked empties sit below their successors: the binding extent is
+    // not the last entry's)
+    for (int C = 2; C <= 4; ++C) {
+        AxisTables tc;
+        build_axis_tables(g, rq->mode, tc, C);
+        if (tc.nA != t.nA * C || tc.channels != C) return 11;
+        int nx = 0;
+        for (const auto &st : tc.strips) {
+            if (st.k0 != nx || st.k1 <= st.k0 || st.k1 - st.k0 > 256 || st.k0 % C != 0 || st.k1 % C != 0) return 12;
+            for (int k = st.k0; k < st.k1; ++k) {
+                const AxisEntry &e = tc.lane[k];
+                if (e.s0 % C != k % C && !(e.wFirst == 0.f && e.wMid == 0.f && e.wLast == 0.f)) return 13;       // taps stay on their channel
+                if (!tc.wide && (e.s0 < st.x0 || e.s1 >= st.x0 + STRIP_COLS)) return 14;
+                if (e.s1 >= g.W * C) return 15;
+            }
+            nx = st.k1;
+        }
+        if (nx != tc.nA) return 16;
+    }
     // band slicing: three bands re-create the table of dst rows, re-based to their own first source row
     const int n = g.dH;
     for (int part = 0; part < 3 && n >= 3; ++part) {

@@ -8,6 +8,7 @@ source text.  Run from the repo root in the build container (the reference is ab
 
     python tests/golden/make_golden.py small          # tests/golden/small_cases.npz      (seconds)
     python tests/golden/make_golden.py errors         # tests/golden/error_paths.json
+    python tests/golden/make_golden.py knife          # tests/golden/knife_cases.npz      (structured knife-edge geometries)
     python tests/golden/make_golden.py full cfg2      # tests/golden/full_cfg2.npz         (minutes, 1 core)
     python tests/golden/make_golden.py full all       # every BASELINE.json config that is CPU-feasible
     python tests/golden/make_golden.py oraclefull cfg5  # full-size config 5 through the CPU oracle (8 processes, minutes)
@@ -79,6 +80,47 @@ def gen_small():
         manifest.append(entry)
     store["manifest"] = np.frombuffer(json.dumps(manifest).encode(), dtype=np.uint8)
     path = os.path.join(HERE, "small_cases.npz")
+    np.savez_compressed(path, **store)
+    print("wrote", path, os.path.getsize(path), "bytes,", len(cases), "cases")
+
+
+def knife_case_list():
+    """Structured geometries that put dst edges through source-pixel corners and dst vertices on pixel sides (reduced
+    angles 30 / 45 / 60 / atan(1/2) / atan(3/4) / 22.5 degrees with commensurate ratios, isocenters on pixel centres,
+    corners and half-pixels): the reference's answer there hangs on its DBL_EPSILON end-point rules
+    (Source.cpp:330-342, 401-408, 500-564, 1430).  Deterministic (seeded), so the manifest is reproducible."""
+    import math
+    rng = np.random.default_rng(4)
+    angs = [30, 45, 60, math.degrees(math.atan(0.5)), math.degrees(math.atan(0.75)), 22.5, 135, 210, 315]
+    ratios = [(2, 1), (3, 1), (4, 1), (1, 1), (1, 2), (2.8284271247461903, 1), (1.4142135623730951, 1)]
+    cases = []
+    for ang in angs:
+        for (sr, dr) in ratios:
+            for kind in range(3):
+                W, H = int(rng.integers(16, 36)), int(rng.integers(16, 36))
+                if dr / sr > 1:
+                    W, H = W // 3 + 4, H // 3 + 4
+                iso = [((W - 1) / 2, (H - 1) / 2), (0.0, 0.0), (float(rng.integers(0, W)), float(rng.integers(0, H)) + 0.5)][kind]
+                cases.append(dict(W=W, H=H, seed=1000 + len(cases), src_res=float(sr), dst_res=float(dr), iso=[float(iso[0]), float(iso[1])],
+                                  angle=float(ang)))
+    return cases
+
+
+def gen_knife():
+    cases = knife_case_list()
+    store, manifest = {}, []
+    for i, c in enumerate(cases):
+        src = po.synth_image(c["W"], c["H"], c["seed"]).astype(np.float64)
+        entry = dict(c)
+        for mode, tag in ((po.MODE_EXACT, "exact"), (po.MODE_FAST, "fast")):
+            r = po.ref_run(mode, src, c["src_res"], c["dst_res"], c["iso"], c["angle"])        # the UNMODIFIED reference
+            assert r.ok, r.msg
+            store["k%03d_%s" % (i, tag)] = r.dst
+            entry["dst_iso"] = list(r.dst_iso)
+            entry["shape"] = list(r.dst.shape)
+        manifest.append(entry)
+    store["manifest"] = np.frombuffer(json.dumps(manifest).encode(), dtype=np.uint8)
+    path = os.path.join(HERE, "knife_cases.npz")
     np.savez_compressed(path, **store)
     print("wrote", path, os.path.getsize(path), "bytes,", len(cases), "cases")
 
@@ -210,6 +252,8 @@ if __name__ == "__main__":
         gen_small()
     elif what == "errors":
         gen_errors()
+    elif what == "knife":
+        gen_knife()
     elif what == "oraclefull":
         if not po.have_oracle():
             po.build()

@@ -141,11 +141,11 @@ def test_strips_cover_baseline_geometry(aai, hostemu):
     rc, (n, most, wide, span) = hostemu.strip_stats(aai.make_request(4096, 4096, 4, 1, (2047.5, 2047.5), 180))
     assert rc == 0 and (n, most, wide) == (16, 64, 0)
     # non-integer ratio, up-sampling, extreme down-sampling
-    for (w, h, sr, dr) in ((1000, 700, 8192, 2731), (300, 200, 1, 4), (5000, 40, 1000, 1), (257, 3, 1, 1)):
+    for (w, h, sr, dr) in ((1000, 700, 8192, 2731), (300, 200, 1, 4), (5000, 1200, 1000, 1), (257, 3, 1, 1)):
         for ang in (0, 90, 180, 270):
             rc, (n, most, wide, span) = hostemu.strip_stats(aai.make_request(w, h, sr, dr, ((w - 1) / 2, (h - 1) / 2), ang))
             assert rc == 0 and n >= 1, (w, h, sr, dr, ang, rc)
-    rc, (_, _, wide, _) = hostemu.strip_stats(aai.make_request(5000, 40, 1000, 1, (2499.5, 19.5), 0))
+    rc, (_, _, wide, _) = hostemu.strip_stats(aai.make_request(5000, 1200, 1000, 1, (2499.5, 599.5), 0))
     assert wide == 1
 
 
@@ -297,6 +297,31 @@ def test_knife_edge_geometries_match_oracle_exactly_in_class(aai, hostemu, po, s
     assert runs > 400 and knife > 50000          # the sweep really is made of knife edges
 
 
+def test_knife_edge_replay_matches_reference_goldens(aai, hostemu, po, knife_golden):
+    """The same class of geometries against fixtures produced by the UNMODIFIED reference (tests/golden/knife_cases.npz),
+    so that the strict replay (csrc/aai_strict.hpp) is not only compared with the oracle it shares its origin with:
+    production pass + knife-edge fix-up, with and without the fp32 quad formulation for the unflagged pixels; every
+    pixel within the bar, exact zeros exact."""
+    z, manifest = knife_golden
+    knife = 0
+    for quad in (0, 1):
+        hostemu.aai_emu_use_quad(quad)
+        try:
+            for i, c in enumerate(manifest):
+                src = po.synth_image(c["W"], c["H"], c["seed"])
+                for mode, tag in ((1, "exact"), (2, "fast")):
+                    rq = aai.make_request(c["W"], c["H"], c["src_res"], c["dst_res"], c["iso"], c["angle"], mode=mode)
+                    out, axis = hostemu.resample(rq, src)
+                    gold = z["k%03d_%s" % (i, tag)]
+                    knife += hostemu.knife_stats()[0]
+                    assert out.shape == gold.shape
+                    assert (rel_err(out, gold) > TOL).sum() == 0, (quad, i, tag, c)
+                    assert np.array_equal(gold == 0, out == 0), (quad, i, tag, c)
+        finally:
+            hostemu.aai_emu_use_quad(0)
+    assert knife > 50000
+
+
 def test_baseline_geometries_raise_no_knife_flags(aai, hostemu, po):
     """BASELINE configs 3 and 5 (at reduced size) never enter the strict path (zero end-point hits)."""
     for (W, sr, dr, ang) in ((768, 8192.0, 2731.0, 17.5), (96, 1.0, 4.0, 45.0)):
@@ -326,6 +351,18 @@ def test_planner_invariants_fuzzed(aai, hostemu):
         assert hostemu.aai_emu_axis_invariants(ctypes.byref(rq)) == 0, (W, H, sr, dr, quadrant, mode, fx, fy)
 
     check()
+    # wide footprints with interleaved channels: the windows of neighbouring pixels' channels interleave, and a parked
+    # empty entry sits below its successors -- the case where "the last window bounds the strip" used to be assumed
+    # (about 86:1 RGB: a channel entry's window ended 257 elements past the strip origin)
+    for (W, H, sr, dr, iso) in ((3000, 90, 86.0, 1.0, (1499.5, 44.5)), (3000, 90, 85.4, 1.0, (1400.0, 40.0)), (2600, 100, 86.3, 1.0, (2599.0, 0.0)),
+                                (4000, 64, 64.0, 1.0, (1999.5, 31.5)), (3000, 90, 83.0, 1.0, (-5.0, 44.5)), (2000, 70, 50.0, 1.0, (999.5, 34.5))):
+        for quadrant in range(4):
+            for mode in (1, 2):
+                rq = aai.make_request(W, H, sr, dr, iso, 90.0 * quadrant, mode=mode)
+                rc, msg, lay = aai.query(rq)
+                if rc != 0:
+                    continue
+                assert hostemu.aai_emu_axis_invariants(ctypes.byref(rq)) == 0, (W, H, sr, dr, iso, quadrant, mode)
 
 
 def test_line_runs_never_contradict_the_pair_classifier(aai, hostemu):
@@ -358,7 +395,7 @@ def test_interleaved_channel_tables_replay_equals_planar(aai, hostemu):
     4:1, up-sampling, odd widths, narrow images (per-pixel fallback), both modes."""
     rng = np.random.default_rng(51)
     cases = [(517, 40, 4, 1), (300, 33, 3, 1), (301, 21, 2, 1), (259, 17, 1, 1), (70, 50, 1, 2), (40, 30, 1, 4), (1030, 9, 8, 1),
-             (263, 31, 8192, 2731), (3000, 12, 700, 1), (3, 50, 2, 1), (1, 7, 1, 1), (90, 90, 5, 2)]
+             (263, 31, 8192, 2731), (3000, 800, 700, 1), (3, 50, 2, 1), (1, 7, 1, 1), (90, 90, 5, 2)]
     for k, (W, H, sr, dr) in enumerate(cases):
         for ang in (0.0, 90.0, 180.0, 270.0):
             C = 2 + (k + int(ang) // 90) % 3

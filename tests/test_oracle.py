@@ -6,7 +6,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import GOLDEN, load_full
+from conftest import GOLDEN, load_full, sample_points
 
 
 def _case_src(po, c):
@@ -24,6 +24,21 @@ def test_oracle_matches_small_golden_bit_exact(po, small_golden):
             gold = z["c%03d_%s" % (i, tag)]
             assert r.dst.shape == gold.shape == tuple(c["shape"])
             assert list(r.dst_iso) == c["dst_iso"]
+            assert np.array_equal(r.dst, gold), (i, tag, float(np.abs(r.dst - gold).max()))
+
+
+def test_oracle_matches_knife_golden_bit_exact(po, knife_golden):
+    """The structured knife-edge geometries (edges through pixel corners, vertices on pixel sides): outputs of the
+    unmodified reference, where its DBL_EPSILON end-point rules (Source.cpp:330-342, 401-408, 500-564, 1430) decide."""
+    z, manifest = knife_golden
+    assert len(manifest) >= 180
+    for i, c in enumerate(manifest):
+        src = _case_src(po, c)
+        for mode, tag in ((po.MODE_EXACT, "exact"), (po.MODE_FAST, "fast")):
+            r = po.oracle_run(mode, src, c["src_res"], c["dst_res"], c["iso"], c["angle"])
+            assert r.ok, (i, tag, r.msg)
+            gold = z["k%03d_%s" % (i, tag)]
+            assert r.dst.shape == gold.shape == tuple(c["shape"]) and list(r.dst_iso) == c["dst_iso"]
             assert np.array_equal(r.dst, gold), (i, tag, float(np.abs(r.dst - gold).max()))
 
 
@@ -128,3 +143,29 @@ def test_synth_generator_c_matches_numpy(po):
     lib.aai_oracle_synth_f32(a.ctypes.data, 53, 37, 9)
     b = po.synth_image(53, 37, 9)
     assert np.array_equal(a, b) and a.min() >= 0 and a.max() < 1
+
+
+def test_bilinear_restatement_equals_torch_grid_sample(po):
+    """The reference only names bilinear / bicubic (README.md:8), so those comparison paths have no reference output to
+    pin them.  The bilinear one is at least pinned to an implementation this repository did not write: clamp-to-edge
+    bilinear at the dst pixel centres mapped through the reference's affine map (Source.cpp:139-219) is exactly
+    torch.nn.functional.grid_sample(mode='bilinear', padding_mode='border', align_corners=False) at the same points
+    (float64), 0 outside the image extent -- all four quadrants, scale 1 and > 1."""
+    import torch
+    import area_average_interpolation_amd as aai
+    rng = np.random.default_rng(1)
+    for (W, H, sr, dr, ang, iso) in [(40, 30, 1.0, 4.0, 45.0, (19.5, 14.5)), (33, 47, 3.0, 2.0, 200.0, (10.0, 5.5)), (20, 20, 2.0, 1.0, 117.0, (9.5, 9.5)),
+                                     (25, 18, 1.0, 1.0, 300.0, (3.0, 3.0)), (31, 17, 1.0, 2.5, 17.5, (15.0, 8.0)), (28, 28, 4.0, 1.0, 0.0, (13.5, 13.5))]:
+        src = rng.random((H, W)).astype(np.float32)
+        rq = aai.make_request(W, H, sr, dr, iso, ang, mode=3)
+        rc, msg, lay = aai.query(rq)
+        assert rc == 0, msg
+        gold = po.oracle_run(3, src.astype(np.float64), sr, dr, iso, ang).dst
+        sx, sy = sample_points(rq, lay, list(range(lay.dst_height)), "cpu")
+        inside = (sx >= -0.5) & (sx <= W - 0.5) & (sy >= -0.5) & (sy <= H - 0.5)
+        grid = torch.stack(((2 * sx + 1) / W - 1, (2 * sy + 1) / H - 1), dim=-1)[None]
+        ref = torch.nn.functional.grid_sample(torch.from_numpy(src).double()[None, None], grid, mode="bilinear", padding_mode="border", align_corners=False)[0, 0]
+        ref = torch.where(inside, ref, torch.zeros_like(ref)).numpy()
+        assert gold.shape == ref.shape
+        assert np.abs(ref - gold).max() <= 1e-12, (W, H, sr, dr, ang)
+        assert np.array_equal(gold == 0, ref == 0)
