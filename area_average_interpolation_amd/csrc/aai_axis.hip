@@ -178,13 +178,17 @@ __global__ __launch_bounds__(kWaves * 64) void aai_axis_kernel(AxisLaunch a, con
                                                                 const AxisEntry *__restrict__ rowTab, const AxisStrip *__restrict__ strips,
                                                                 const T *__restrict__ src, ImageView sv,
                                                                 float *__restrict__ dst, ImageView dv,
-                                                                int rowsPerBlock, int interleave)
+                                                                int rowsPerBlock, int interleave, int swapXY)
 {
     __shared__ __attribute__((aligned(16))) float lds[kWaves][64 * VEC + 8];   // +8 keeps the lines 16-byte aligned and apart
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform: strip/row tables load through the scalar cache
-    const int strip = blockIdx.x * kWaves + wave;
+    // swapXY: the grid is launched (rows, strip blocks) so that consecutive workgroups -- which go to consecutive XCDs --
+    // take consecutive output ROWS of one strip block instead of the strip blocks of one row
+    const int bX = swapXY ? (int)blockIdx.y : (int)blockIdx.x, bY = swapXY ? (int)blockIdx.x : (int)blockIdx.y;
+    const int gY = swapXY ? (int)gridDim.x : (int)gridDim.y;
+    const int strip = bX * kWaves + wave;
     if (strip >= a.nStrips) return;   // waves are independent: no barrier is skipped by leaving early
 
     typedef int i4s __attribute__((ext_vector_type(4)));
@@ -197,8 +201,8 @@ __global__ __launch_bounds__(kWaves * 64) void aai_axis_kernel(AxisLaunch a, con
     const int colc = min(col, a.srcW - VEC);        // srcW >= VEC here (narrower images use the wide kernel)
     const int shift = col - colc;                    // 0 away from the right edge
 
-    const int rowStart = interleave ? (int)blockIdx.y : (int)blockIdx.y * rowsPerBlock;
-    const int rowStep = interleave ? (int)gridDim.y : 1;
+    const int rowStart = interleave ? bY : bY * rowsPerBlock;
+    const int rowStep = interleave ? gY : 1;
     const int rowEnd = interleave ? a.nB : min(rowStart + rowsPerBlock, a.nB);
     const int nOut = st.k1 - st.k0;
     // interleaved channels: taps `step` elements apart, dst element of lane entry ka split into (pixel, channel)
@@ -453,6 +457,27 @@ __global__ __launch_bounds__(256) void aai_axis_wide_kernel(AxisLaunch a, const 
 
 }  // namespace
 
+// Launch-shape overrides for experiments (tools/tune_axis.py): AAI_AXIS_TUNE="nt=1,rows=1,interleave=0,gy=0,swap=0,tile=1" is
+// read once per process; aai_debug_axis_tune() replaces it at run time (not part of the public ABI in include/aai.h).
+struct AxisTune { int nt = -1, rows = 0, interleave = -1, gy = -1, swap = -1, tile = -1; };
+static AxisTune parse_axis_tune(const char *spec)
+{
+    AxisTune t;
+    if (!spec) return t;
+    auto get = [&](const char *key, int &v) {
+        const char *p = strstr(spec, key);
+        if (p) v = atoi(p + strlen(key));
+    };
+    get("nt=", t.nt); get("rows=", t.rows); get("interleave=", t.interleave); get("gy=", t.gy); get("swap=", t.swap); get("tile=", t.tile);
+    return t;
+}
+static AxisTune &axis_tune()
+{
+    static AxisTune t = parse_axis_tune(getenv("AAI_AXIS_TUNE"));
+    return t;
+}
+void set_axis_tune(const char *spec) { axis_tune() = parse_axis_tune(spec); }
+
 template <typename T>
 static hipError_t launch_axis_typed(const AxisLaunch &a, const T *src, ImageView sv, float *dst, ImageView dv,
                                     int batch, hipStream_t stream, const char **kernelName);
@@ -489,7 +514,7 @@ static hipError_t launch_axis_typed(const AxisLaunch &a, const T *src, ImageView
     //     vs 2.5 at four and 1.4 at one); the up-sampling path (more than 256 outputs per strip) prefers 4;
     //   * 8- and 16-bit sources move 4x / 2x fewer bytes and are bound by per-wave latency, not by HBM: eight / four
     //     rows per workgroup (8192^2 u8 -> 2048^2: 28 us at one row, 21 at eight; profiles/r01_typed_sources.txt).
-    int nt = a.rowsShared ? 0 : 1, interleave = 0, gy = 0;
+    int nt = a.rowsShared ? 0 : 1, interleave = 0, gy = 0, swapXY = 0;
     int rows = a.maxRowSpan >= 4 ? (a.rowsShared ? 2 : 1) : 4;
     if (sizeof(T) < 4) {
         // ... as long as that leaves a few workgroups per CU
@@ -505,20 +530,19 @@ static hipError_t launch_axis_typed(const AxisLaunch &a, const T *src, ImageView
         if (a.maxOutputsPerStrip > 64) rows = a.maxRowSpan >= 2 ? 4 : 16;     // the four-column path (ratios below 4)
     }
     if (!a.transposed && a.maxOutputsPerStrip > 128 && a.maxOutputsPerStrip <= 256) rows = 32;      // ratios below 2: write-heavy
-    if (const char *env = getenv("AAI_AXIS_TUNE")) {
-        auto get = [&](const char *key, int &v) {
-            const char *p = strstr(env, key);
-            if (p) v = atoi(p + strlen(key));
-        };
-        get("nt=", nt); get("rows=", rows); get("interleave=", interleave); get("gy=", gy);
-        if (rows < 1) rows = 1;
-    }
+    // the plan's measured choice for this (geometry, device) -- fp32 sources only (aai_capi.cpp: tune_axis_plan)
+    if (sizeof(T) == 4 && a.tuneRows > 0) { rows = a.tuneRows; nt = a.tuneNt; swapXY = a.tuneSwap; }
+    const AxisTune &tune = axis_tune();
+    if (tune.nt >= 0) nt = tune.nt;
+    if (tune.rows > 0) rows = tune.rows;
+    if (tune.interleave >= 0) interleave = tune.interleave;
+    if (tune.gy >= 0) gy = tune.gy;
+    if (tune.swap >= 0) swapXY = tune.swap;
     // (measured, profiles/r01_axis_transposed.txt: wins below 2:1 -- 1:1 1.8 -> 2.3 TB/s, x4 up-sampling 1.2 -> 1.6 --
     // and loses 5-14 % to the four-column register path between 2:1 and 4:1)
     int tile = a.transposed && a.tapStep <= 1 && (a.outStrideB == 1 || a.outStrideB == -1) && a.maxOutputsPerStrip > 128 &&
                a.maxOutputsPerStrip <= 256;
-    if (const char *env = getenv("AAI_AXIS_TUNE"))
-        if (const char *p = strstr(env, "tile=")) tile = tile && atoi(p + 5) != 0;
+    if (tune.tile >= 0) tile = tile && tune.tile != 0;
     if (tile && (a.nB + kTileCols - 1) / kTileCols <= 65535) {
         // transposed quadrants at ratios below 4: LDS tile, stores along dst x (see aai_axis_tile_kernel)
         dim3 grid((a.nStrips + kWaves - 1) / kWaves, (a.nB + kTileCols - 1) / kTileCols, batch), block(kWaves * 64);
@@ -531,14 +555,15 @@ static hipError_t launch_axis_typed(const AxisLaunch &a, const T *src, ImageView
     int blocksY = (a.nB + rows - 1) / rows;
     if (interleave && gy > 0) blocksY = gy < a.nB ? gy : a.nB;
     while (blocksY > 65535) { rows *= 2; blocksY = (a.nB + rows - 1) / rows; }
-    dim3 grid(blocksX, blocksY, batch), block(kWaves * 64);
+    if (swapXY && blocksX > 65535) swapXY = 0;
+    dim3 grid(swapXY ? blocksY : blocksX, swapXY ? blocksX : blocksY, batch), block(kWaves * 64);
     if (kernelName) *kernelName = "aai_axis_kernel";
     if (a.tapStep > 1) {
-        if (nt) hipLaunchKernelGGL((aai_axis_kernel<true, T, true>), grid, block, 0, stream, a, a.laneTab, a.rowTab, a.strips, src, sv, dst, dv, rows, interleave);
-        else hipLaunchKernelGGL((aai_axis_kernel<false, T, true>), grid, block, 0, stream, a, a.laneTab, a.rowTab, a.strips, src, sv, dst, dv, rows, interleave);
+        if (nt) hipLaunchKernelGGL((aai_axis_kernel<true, T, true>), grid, block, 0, stream, a, a.laneTab, a.rowTab, a.strips, src, sv, dst, dv, rows, interleave, swapXY);
+        else hipLaunchKernelGGL((aai_axis_kernel<false, T, true>), grid, block, 0, stream, a, a.laneTab, a.rowTab, a.strips, src, sv, dst, dv, rows, interleave, swapXY);
     } else {
-        if (nt) hipLaunchKernelGGL((aai_axis_kernel<true, T, false>), grid, block, 0, stream, a, a.laneTab, a.rowTab, a.strips, src, sv, dst, dv, rows, interleave);
-        else hipLaunchKernelGGL((aai_axis_kernel<false, T, false>), grid, block, 0, stream, a, a.laneTab, a.rowTab, a.strips, src, sv, dst, dv, rows, interleave);
+        if (nt) hipLaunchKernelGGL((aai_axis_kernel<true, T, false>), grid, block, 0, stream, a, a.laneTab, a.rowTab, a.strips, src, sv, dst, dv, rows, interleave, swapXY);
+        else hipLaunchKernelGGL((aai_axis_kernel<false, T, false>), grid, block, 0, stream, a, a.laneTab, a.rowTab, a.strips, src, sv, dst, dv, rows, interleave, swapXY);
     }
     return hipGetLastError();
 }

@@ -9,6 +9,7 @@
 #include <climits>
 #include <cmath>
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
 #include <algorithm>
 #include <list>
@@ -57,6 +58,7 @@ struct Plan {
     aai::AxisTables tabs;
     aai::AxisEntry *dLane = nullptr, *dRow = nullptr;
     aai::AxisStrip *dStrips = nullptr;
+    int tuneRows = 0, tuneNt = 0, tuneSwap = 0;      // K1 launch shape measured on this device (0 rows = built-in default)
     // K2/K3: the dst pixels flagged by the one-off scans (knife edges of the reference's classifier; decisions the fp32
     // quad kernel leaves to double precision) as a list of (dx, dy) the fix-up pass runs over; `dense` when there are
     // so many that the whole image takes that pass instead
@@ -122,6 +124,84 @@ void fill_layout(const aai::Geometry &g, int kernel, aai_layout *out)
     *out = l;
 }
 
+// the argument block of K1 for a plan and a dst row stride (elements)
+aai::AxisLaunch make_axis_launch(const Plan &p, int channels, int64_t dstStride)
+{
+    const aai::AxisTables &t = p.tabs;
+    const aai::Geometry &g = p.g;
+    aai::AxisLaunch a{};
+    a.laneTab = p.dLane; a.rowTab = p.dRow; a.strips = p.dStrips;
+    a.nA = t.nA; a.nB = t.nB; a.nStrips = (int)t.strips.size();
+    a.srcW = g.W * channels; a.srcH = g.H;      // elements of a source row
+    a.wide = t.wide ? 1 : 0;
+    a.maxRowSpan = t.maxRowSpan;
+    a.rowsShared = t.rowsShared ? 1 : 0;
+    a.maxOutputsPerStrip = t.maxOutputsPerStrip;
+    // (ka,kb) -> dst element: the lane axis is dst x unless the quadrant transposes; flips run an axis
+    // backwards
+    // (with interleaved channels a dst pixel is `channels` elements wide and lane entry ka = pixel * channels + channel)
+    const int nApix = t.nA / channels;
+    const int64_t sa = t.transposed ? dstStride : channels, sb = t.transposed ? channels : dstStride;
+    a.outStrideA = t.flipA ? -sa : sa;
+    a.outStrideB = t.flipB ? -sb : sb;
+    a.outBase = (t.flipA ? (int64_t)(nApix - 1) * sa : 0) + (t.flipB ? (int64_t)(t.nB - 1) * sb : 0);
+    a.transposed = t.transposed ? 1 : 0;
+    a.tapStep = channels; a.outChan = channels;
+    if (channels > 1 && !t.transposed && !t.flipA) { a.outStrideA = 1; a.outChan = 1; }     // lane order = dst element order
+    a.tuneRows = p.tuneRows; a.tuneNt = p.tuneNt; a.tuneSwap = p.tuneSwap;
+    return a;
+}
+
+// K1 is HBM-bound and its best launch shape moves with the box by a few per cent (the same binary measured 5.8 to 6.9
+// TB/s across boxes of one pool: profiles/r01_axis_tune_sweep2.txt, profiles/r02_axis_autotune.txt), so a plan for a
+// large streaming geometry times the shapes that ever win -- output rows per workgroup, nontemporal or cached loads,
+// grid order -- once on this device, on scratch images larger than the Infinity Cache, and keeps the fastest.  Only the
+// common family (plain fp32 images, footprints of >= 4 source rows, un-transposed quadrants, whole image).
+void tune_axis_plan(Plan &p, int channels, int band0)
+{
+    static const bool enabled = [] { const char *e = getenv("AAI_AXIS_AUTOTUNE"); return !(e && atoi(e) == 0); }();
+    const aai::AxisTables &t = p.tabs;
+    const aai::Geometry &g = p.g;
+    const size_t srcBytes = sizeof(float) * (size_t)g.W * g.H, dstBytes = sizeof(float) * (size_t)g.dW * g.dH;
+    if (!enabled || channels != 1 || band0 >= 0 || t.wide || t.transposed || t.maxRowSpan < 4 || t.maxOutputsPerStrip > 64 ||
+        srcBytes < ((size_t)64 << 20) || !dstBytes)
+        return;
+    const int images = (int)std::min<size_t>(8, std::max<size_t>(2, (((size_t)1 << 30) + srcBytes - 1) / srcBytes));
+    float *src = nullptr, *dst = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    bool ok = hipMalloc((void **)&src, srcBytes * images) == hipSuccess && hipMalloc((void **)&dst, dstBytes * images) == hipSuccess &&
+              hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess;
+    for (int b = 0; b < images && ok; ++b)         // realistic data: the memory system's speed depends on what it moves
+        ok = aai::launch_synth(src + (size_t)b * g.W * g.H, g.W, g.H, g.W, (uint64_t)b + 1, nullptr) == hipSuccess;
+    struct Shape { int rows, nt, swap; float ms; };
+    Shape shapes[] = {{1, 1, 0, 0.f}, {2, 1, 0, 0.f}, {1, 0, 0, 0.f}, {2, 0, 0, 0.f}, {4, 1, 0, 0.f}};
+    const aai::ImageView sv{g.W, (int64_t)g.W * g.H}, dv{g.dW, (int64_t)g.dW * g.dH};
+    // the shapes take turns, three rounds, two launches per turn; each keeps its fastest turn
+    for (int round = 0; round < 4 && ok; ++round)
+        for (Shape &sh : shapes) {
+            p.tuneRows = sh.rows; p.tuneNt = sh.nt; p.tuneSwap = sh.swap;
+            const aai::AxisLaunch a = make_axis_launch(p, 1, g.dW);
+            float ms = 0.f;
+            ok = ok && hipEventRecord(e0, nullptr) == hipSuccess &&
+                 aai::launch_axis(a, src, aai::SRC_F32, sv, dst, dv, images, nullptr, nullptr) == hipSuccess &&
+                 aai::launch_axis(a, src, aai::SRC_F32, sv, dst, dv, images, nullptr, nullptr) == hipSuccess &&
+                 hipEventRecord(e1, nullptr) == hipSuccess && hipEventSynchronize(e1) == hipSuccess && hipEventElapsedTime(&ms, e0, e1) == hipSuccess;
+            if (ok && round > 0 && (sh.ms == 0.f || ms < sh.ms)) sh.ms = ms;       // round 0 warms up
+        }
+    p.tuneRows = 0; p.tuneNt = 0; p.tuneSwap = 0;
+    if (ok) {
+        const Shape *best = &shapes[0];
+        for (const Shape &sh : shapes)
+            if (sh.ms < best->ms * 0.99f) best = &sh;          // a later shape must win by more than the timing noise
+        p.tuneRows = best->rows; p.tuneNt = best->nt; p.tuneSwap = best->swap;
+    }
+    (void)hipGetLastError();
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    if (src) (void)hipFree(src);
+    if (dst) (void)hipFree(dst);
+}
+
 // Finds or builds the plan for (request, current device).  Returns a pointer valid until evicted; callers
 // hold g_planMutex for the duration of the launch (launches only enqueue, so this is short).
 int get_plan(const aai_request &rq, int band0, int band1, int channels, Plan **out)
@@ -168,6 +248,7 @@ int get_plan(const aai_request &rq, int band0, int band1, int channels, Plan **o
         if (e == hipSuccess) e = upload(p.tabs.row.data(), p.tabs.row.size() * sizeof(aai::AxisEntry), (void **)&p.dRow);
         if (e == hipSuccess) e = upload(p.tabs.strips.data(), p.tabs.strips.size() * sizeof(aai::AxisStrip), (void **)&p.dStrips);
         if (e != hipSuccess) { g_plans.pop_front(); return hip_fail(e, "uploading axis tables"); }
+        if (p.kernel == AAI_KERNEL_AXIS) tune_axis_plan(p, channels, band0);
     }
     if (p.kernel == AAI_KERNEL_ROTATED || p.kernel == AAI_KERNEL_FAST) {
         // one-off scans of this geometry (aai_knife_scan_kernel, and aai_quad_scan_kernel where the fp32 quad kernel
@@ -230,26 +311,7 @@ int enqueue(const aai_request &rq, int batch, const void *dSrc, int srcType, int
     const char *name = "";
     hipError_t e;
     if (p->kernel == AAI_KERNEL_AXIS || p->kernel == AAI_KERNEL_AXIS_WIDE) {
-        const aai::AxisTables &t = p->tabs;
-        aai::AxisLaunch a{};
-        a.laneTab = p->dLane; a.rowTab = p->dRow; a.strips = p->dStrips;
-        a.nA = t.nA; a.nB = t.nB; a.nStrips = (int)t.strips.size();
-        a.srcW = g.W * channels; a.srcH = g.H;      // elements of a source row
-        a.wide = t.wide ? 1 : 0;
-        a.maxRowSpan = t.maxRowSpan;
-        a.rowsShared = t.rowsShared ? 1 : 0;
-        a.maxOutputsPerStrip = t.maxOutputsPerStrip;
-        // (ka,kb) -> dst element: the lane axis is dst x unless the quadrant transposes; flips run an axis
-        // backwards
-        // (with interleaved channels a dst pixel is `channels` elements wide and lane entry ka = pixel * channels + channel)
-        const int nApix = t.nA / channels;
-        const int64_t sa = t.transposed ? dstStride : channels, sb = t.transposed ? channels : dstStride;
-        a.outStrideA = t.flipA ? -sa : sa;
-        a.outStrideB = t.flipB ? -sb : sb;
-        a.outBase = (t.flipA ? (int64_t)(nApix - 1) * sa : 0) + (t.flipB ? (int64_t)(t.nB - 1) * sb : 0);
-        a.transposed = t.transposed ? 1 : 0;
-        a.tapStep = channels; a.outChan = channels;
-        if (channels > 1 && !t.transposed && !t.flipA) { a.outStrideA = 1; a.outChan = 1; }     // lane order = dst element order
+        const aai::AxisLaunch a = make_axis_launch(*p, channels, dstStride);
         e = hipSuccess;
         for (int b0 = 0; b0 < batch && e == hipSuccess; b0 += kMaxGridZ)       // grid.z carries the batch
             e = aai::launch_axis(a, src_at(dSrc, srcType, (int64_t)b0 * srcImageStride), srcType, sv, dDst + (int64_t)b0 * dstImageStride, dv,
@@ -512,6 +574,23 @@ int aai_prepare(const aai_request *req, int32_t channels)
     rc = get_plan(*req, -1, -1, channels, &p);
     if (rc == AAI_OK) g_lastError.clear();
     return rc;
+}
+
+/* experiments only (tools/tune_axis.py); not declared in include/aai.h */
+void aai_debug_axis_tune(const char *spec) { aai::set_axis_tune(spec); }
+
+const char *aai_debug_plan_shape(const aai_request *req)
+{
+    // "rows=R nt=N swap=S" of the cached K1 plan of this request on the current device ("" when there is none)
+    static thread_local std::string text;
+    text.clear();
+    int dev = -1;
+    if (!req || hipGetDevice(&dev) != hipSuccess) return text.c_str();
+    std::lock_guard<std::mutex> lock(g_planMutex);
+    for (const Plan &p : g_plans)
+        if (p.device == dev && p.band0 < 0 && p.channels == 1 && same_request(p.key, *req) && p.kernel == AAI_KERNEL_AXIS)
+            text = "rows=" + std::to_string(p.tuneRows) + " nt=" + std::to_string(p.tuneNt) + " swap=" + std::to_string(p.tuneSwap);
+    return text.c_str();
 }
 
 int aai_synth_rows_device_f32(float *d_dst, int32_t width, int32_t height, int32_t row0, int32_t row1, int64_t stride, uint64_t seed, void *stream)

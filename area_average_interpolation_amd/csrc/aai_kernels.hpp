@@ -35,7 +35,11 @@ struct AxisLaunch {
     // (outChan = 1 when the lane order is already the dst element order: not transposed, not flipped)
     int tapStep, outChan;
     int transposed;             // the lane axis runs along dst y (quadrants 1 and 3)
+    // launch shape measured by the plan for this (geometry, device): output rows per workgroup (0 = built-in default),
+    // nontemporal source loads, grid order (see aai_axis_kernel)
+    int tuneRows, tuneNt, tuneSwap;
 };
+void set_axis_tune(const char *spec);      // experiments only (tools/tune_axis.py)
 hipError_t launch_axis(const AxisLaunch &a, const void *src, int srcType, ImageView sv, float *dst, ImageView dv,
                        int batch, hipStream_t stream, const char **kernelName);
 

@@ -210,4 +210,6 @@ def test_row_bands_of_two_ranks_concatenate_to_the_reference_rows(aai, name):
         assert int((out == 0).sum().item()) == m["zeros"], (name, world)
         total = float(out.sum(dtype=torch.float64).item())
         assert abs(total - float(m["sum"])) <= 2e-7 * float(m["sum"])
-        assert read < (1.0 if name == "cfg2" else 2.2) * H + 64 * world, (name, world, read)      # bands read their own footprint, not the image
+        # bands read their own footprint, not the image: exactly the image once without rotation; a rotated band also
+        # reads the rows its slanted ends reach (W sin(theta) of them)
+        assert read < (H + 64 * world if name == "cfg2" else world * 0.6 * H), (name, world, read)

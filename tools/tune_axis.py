@@ -1,14 +1,23 @@
 #!/usr/bin/env python3
-"""Sweep the launch knobs of the axis-aligned kernel (AAI_AXIS_TUNE) on the cfg2 workload.
-Variants are interleaved in ONE process, several rounds each; reports median and min per variant."""
+"""Sweep the launch knobs of the axis-aligned kernel on the cfg2 workload (through the library's experiment hook
+aai_debug_axis_tune, the run-time form of AAI_AXIS_TUNE).  Variants are interleaved in ONE process, several rounds each;
+reports median and min per variant, then what the plan's own autotune picked on this box (aai_debug_plan_shape)."""
 import itertools
 import os
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+import ctypes
 import torch
 import area_average_interpolation_amd as aai
+from area_average_interpolation_amd import _lib as L
+
+lib = L.load()
+lib.aai_debug_axis_tune.restype = None
+lib.aai_debug_axis_tune.argtypes = [ctypes.c_char_p]
+lib.aai_debug_plan_shape.restype = ctypes.c_char_p
+lib.aai_debug_plan_shape.argtypes = [ctypes.POINTER(L.Request)]
 
 W = H = int(os.environ.get("TUNE_SIZE", "8192"))
 B = int(os.environ.get("TUNE_BATCH", "4"))
@@ -24,6 +33,7 @@ stream = torch.cuda.current_stream().cuda_stream
 for b in range(B):
     aai.synth_device(src[b].data_ptr(), W, H, W, b + 1, stream)
 torch.cuda.synchronize()
+aai.prepare(rq)            # the plan (and its own launch-shape measurement) before any override is active
 alg = B * (4 * W * H + 4 * dW * dH)
 
 
@@ -35,16 +45,14 @@ variants = []
 if len(sys.argv) > 1:
     variants = sys.argv[1:]
 else:
-    for nt, pipe in itertools.product((0, 1), (0, 1)):
-        for rows in (2, 4, 8, 16, 32):
-            variants.append("nt=%d,pipe=%d,rows=%d,interleave=0" % (nt, pipe, rows))
-        for gy in (64, 128, 256, 512):
-            variants.append("nt=%d,pipe=%d,rows=8,interleave=1,gy=%d" % (nt, pipe, gy))
+    for nt, swap in itertools.product((1, 0), (0,)):
+        for rows in (1, 2, 4, 8):
+            variants.append("nt=%d,rows=%d,swap=%d" % (nt, rows, swap))
 ref = None
 times = {v: [] for v in variants}
 for r in range(ROUNDS):
     for v in variants:
-        os.environ["AAI_AXIS_TUNE"] = v
+        lib.aai_debug_axis_tune(v.encode())
         run()
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -64,3 +72,18 @@ for v in best:
     med, mn = t[len(t) // 2], t[0]
     print("%-46s median %.1f us (%.0f GB/s, %.1f%% of 8 TB/s)  min %.1f us (%.0f GB/s)" % (
         v, med * 1e3, alg / med / 1e6, alg / med / 1e6 / 80, mn * 1e3, alg / mn / 1e6))
+lib.aai_debug_axis_tune(b"")
+print("plan autotune on this box:", lib.aai_debug_plan_shape(ctypes.byref(rq)).decode())
+t = []
+for r in range(ROUNDS):
+    run()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(3):
+        run()
+    e1.record()
+    torch.cuda.synchronize()
+    t.append(e0.elapsed_time(e1) / 3)
+t.sort()
+print("as shipped (plan's shape)                      median %.1f us (%.0f GB/s, %.1f%% of 8 TB/s)" % (t[len(t) // 2] * 1e3, alg / t[len(t) // 2] / 1e6, alg / t[len(t) // 2] / 1e6 / 80))
