@@ -20,6 +20,7 @@
 //   with each other, so there is no s_barrier anywhere.
 #include "aai_kernels.hpp"
 
+#include <algorithm>
 #include <cstdlib>
 #include <cstring>
 
@@ -435,10 +436,10 @@ __global__ __launch_bounds__(kWaves * 64) void aai_axis_tile_kernel(AxisLaunch a
 // pixel walks its whole window.  Correct, not fast; such ratios leave almost no output to write.
 template <typename T>
 __global__ __launch_bounds__(256) void aai_axis_wide_kernel(AxisLaunch a, const T *__restrict__ src, ImageView sv,
-                                                             float *__restrict__ dst, ImageView dv)
+                                                             float *__restrict__ dst, ImageView dv, int kb0)
 {
     const int ka = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int kb = blockIdx.y * 4 + (threadIdx.x >> 6);
+    const int kb = kb0 + blockIdx.y * 4 + (threadIdx.x >> 6);
     if (ka >= a.nA || kb >= a.nB) return;
     const Win c = load_win(a.laneTab, ka), e = load_win(a.rowTab, kb);
     const T *img = src + (int64_t)blockIdx.z * sv.imageStride;
@@ -498,9 +499,11 @@ static hipError_t launch_axis_typed(const AxisLaunch &a, const T *src, ImageView
 {
     if (a.nA <= 0 || a.nB <= 0 || batch <= 0) return hipSuccess;
     if (a.wide) {
-        dim3 grid((a.nA + 63) / 64, (a.nB + 3) / 4, batch);
         if (kernelName) *kernelName = "aai_axis_wide_kernel";
-        hipLaunchKernelGGL((aai_axis_wide_kernel<T>), grid, dim3(256), 0, stream, a, src, sv, dst, dv);
+        for (int kb0 = 0; kb0 < a.nB; kb0 += 65535 * 4) {          // grid.y carries at most 65535 blocks of 4 rows
+            dim3 grid((a.nA + 63) / 64, (std::min(a.nB - kb0, 65535 * 4) + 3) / 4, batch);
+            hipLaunchKernelGGL((aai_axis_wide_kernel<T>), grid, dim3(256), 0, stream, a, src, sv, dst, dv, kb0);
+        }
         return hipGetLastError();
     }
     // Launch shape (see the kernel comment for the measurements behind the defaults).  Each knob can be

@@ -55,26 +55,39 @@ struct QuadConsts {
     F minArea;                        // SCAN: pixels whose total area is below this (and not zero) are reported
     int ref;                          // 1 = AAI_POLICY_REFERENCE
     int win;                          // window positions per axis, <= kQuadMaxWin
+    // Close to an axis (min(c,s) small) the reference's corner-triangle rule has slope ~1/(2 min(c,s)) in t, far too
+    // steep for fp32 coordinates: hiPrec evaluates the left/right edge's t = h + k - |a| in double precision from the
+    // centre's double-precision fraction (three fp64 operations per pair) and only then rounds it to F.
+    int hiPrec;
+    F marginT;                        // SCAN, hiPrec: margin of the t thresholds lo / hi taken on the precise t
+    double cD, sD, hpkD;
 };
 
 // fp32 error budget of a coordinate relative to the dst pixel's centre: the constants' rounding times an index of at
 // most the window size, two fused multiply-adds on magnitudes <= hb + 1, the centre's own fraction (see quad_pixel)
 AAI_HD double quad_coord_eps(double side, double c, double s) { return 1.1920929e-7 * (2.0 + 0.5 * side * (c + s)); }
 
+// Does fp32 carry the left/right edge's t?  The steepest area formula -- the reference's corner-triangle rule, slope
+// (1/c + 1/s)/2 in t -- must keep a coordinate error of quad_coord_eps below ~1.5e-7 of the dst value (weights sum to about
+// L^2; pixel values differ from their mean by a few tenths).  Closer to the axes than that (reduced angle within a few
+// degrees of 0 or 90) t is taken in double precision (QuadConsts::hiPrec).
+AAI_HD bool quad_needs_hiprec(double side, double c, double s)
+{
+    const double amp = 0.5 * (1.0 / c + 1.0 / s);
+    return amp * quad_coord_eps(side, c, s) * 0.5 > 1.5e-7 * side * side;
+}
+
 // Can the quad formulation serve this geometry?
 //   * the window of source pixels fits the 8 x 8 position masks;
 //   * h - k is well away from zero, so that the sign of a, b is never in doubt for a pixel both near lines cut;
-//   * the steepest area formula -- the reference's corner-triangle rule, slope (1/c + 1/s)/2 in t -- keeps a
-//     coordinate error of quad_coord_eps below ~1.5e-7 of the dst value (weights sum to about L^2; pixel values
-//     differ from their mean by a few tenths).  Closer to the axes than that (reduced angle within a few degrees
-//     of 0 or 90) the double-precision kernel serves the request.
+//   * the reduced angle is not within ~0.006 degrees of an axis (sin or cos below 1e-4: the double-precision kernel's
+//     territory, where even 1/sin overflows fp32 products).
 AAI_HD bool quad_supported(double side, double c, double s)
 {
-    if (!(c > 0.0 && s > 0.0)) return false;
+    if (!(c > 1e-4 && s > 1e-4)) return false;
     const double h = 0.5 * side, k = 0.5 * (c + s);
     const double m = h * (c + s) - 0.5 + 1e-5;
-    const double amp = 0.5 * (1.0 / c + 1.0 / s);
-    return (int)floor(2.0 * m) + 3 <= kQuadMaxWin && h - k > 1e-3 && amp * quad_coord_eps(side, c, s) * 0.5 <= 1.5e-7 * side * side;
+    return (int)floor(2.0 * m) + 3 <= kQuadMaxWin && h - k > 1e-3;
 }
 
 template <typename F>
@@ -99,6 +112,9 @@ AAI_HD QuadConsts<F> make_quad_consts(double side, double c, double s, int polic
     q.minArea = (F)(side * side < 4.0 ? 0.25 * side * side : 1.0);
     q.ref = policy == AAI_POLICY_REFERENCE ? 1 : 0;
     q.win = (int)floor(2.0 * (hb - 0.5 + 1e-5)) + 3;
+    q.hiPrec = (q.ref && quad_needs_hiprec(side, c, s)) ? 1 : 0;
+    q.marginT = (F)(1e-6 * lo);
+    q.cD = c; q.sD = s; q.hpkD = h + k;
     return q;
 }
 
@@ -111,15 +127,20 @@ AAI_HD double qabs(double a) { return __builtin_fabs(a); }
 // measured from the pixel's extreme corner along the line's normal).  substitute: the line is a left/right edge
 // under policy REFERENCE -- the two corner-triangle cases take the reference's complementary legs.
 template <typename F>
-AAI_HD F quad_cut(const QuadConsts<F> &q, F t, bool substitute)
+AAI_HD F quad_cut_tp(const QuadConsts<F> &q, F tp, bool flip, bool substitute)
 {
-    const F tp = qmin(t, q.k2 - t);                       // from the nearer extreme corner: the cases mirror at t = k
+    // tp = min(t, c + s - t): the line's distance from the NEARER extreme corner (the cases mirror at t = k); flip: t > k
     const F trap = tp * q.rhi - q.trapOff;                // (tp - lo/2) / hi
     const F triExact = tp * tp * q.r2cs;                  // legs tp/c, tp/s
     const F triRef = (F(0.5) - q.hrc * tp) * (F(1) - q.rs * tp);
     const F tri = substitute ? triRef : triExact;
     const F g = tp <= q.lo ? tri : trap;
-    return t > q.k ? F(1) - g : g;
+    return flip ? F(1) - g : g;
+}
+template <typename F>
+AAI_HD F quad_cut(const QuadConsts<F> &q, F t, bool substitute)
+{
+    return quad_cut_tp(q, qmin(t, q.k2 - t), t > q.k, substitute);
 }
 
 // A pixel cut by both near edge lines, the vertex V NOT inside it (a pixel that holds V gets 0 here and its area
@@ -127,8 +148,10 @@ AAI_HD F quad_cut(const QuadConsts<F> &q, F t, bool substitute)
 // canonical orientation (u, v) the left/right edge.  nearS (SCAN): distance of the closest live sign test from
 // its threshold.
 template <typename F, bool SCAN>
-AAI_HD F quad_double(const QuadConsts<F> &q, F A, F B, bool sameSign, F &nearS)
+AAI_HD F quad_double(const QuadConsts<F> &q, F A, F B, F tpA, bool flipA, F tB, bool sameSign, F &nearS)
 {
+    // (tpA, flipA) = the left/right edge's t = A + k in mirrored form (quad_cut_tp; from double precision under hiPrec);
+    // tB = B + k clamped to [0, c + s]
     const F u = sameSign ? A : B, v = sameSign ? B : A;
     // V relative to the pixel centre along the pixel's own axes, in the orientation where the square lies
     // towards -x, -y of V: edge 1 runs from V towards -y, edge 2 towards -x
@@ -141,10 +164,10 @@ AAI_HD F quad_double(const QuadConsts<F> &q, F A, F B, bool sameSign, F &nearS)
         nearS = dx;
         if (cx < F(0.5) + q.margin) nearS = qmin(dx, qmin(qabs(cy - F(0.5)), qabs(cy + F(0.5))));
     }
-    const F tu = qmin(qmax(u + q.k, F(0)), q.k2), tv = qmin(qmax(v + q.k, F(0)), q.k2);
-    // the reference's corner rule applies to a left/right edge that crosses the pixel ALONE
-    const F g1 = quad_cut(q, tu, sameSign && q.ref != 0 && !S2);
-    const F g2 = quad_cut(q, tv, !sameSign && q.ref != 0 && !S1);
+    // the reference's corner rule applies to a left/right edge that crosses the pixel ALONE (edge 1 iff sameSign)
+    const F gA = quad_cut_tp(q, tpA, flipA, q.ref != 0 && (sameSign ? !S2 : !S1));
+    const F gB = quad_cut(q, tB, false);
+    const F g1 = sameSign ? gA : gB, g2 = sameSign ? gB : gA;
     const F both = qmax(g1 + g2 - F(1), F(0));
     return S1 ? (S2 ? both : g1) : (S2 ? g2 : F(0));
 }
@@ -204,10 +227,12 @@ template <int WIN> struct QuadMask<WIN, true> { typedef unsigned type; };
 // Returns the sums; the dst value is sumVA / sumA, or 0 when sumA is 0 (Source.cpp:577).
 // SCAN: src is never touched, every value counts as 1 and the return value says whether this pixel must be left to
 // the double-precision pass.
-template <typename F, int WIN, bool SCAN, typename Src>
-AAI_HD bool quad_pixel(const QuadConsts<F> &q, int Xc, int Yc, F fpx, F fpy, int mW, int mH, Src &src, F &sumA, F &sumVA)
+// HP: QuadConsts::hiPrec as a compile-time switch (the double-precision code costs registers even where it never runs)
+template <typename F, int WIN, bool SCAN, bool HP, typename Src>
+AAI_HD bool quad_pixel(const QuadConsts<F> &q, int Xc, int Yc, double dfx, double dfy, int mW, int mH, Src &src, F &sumA, F &sumVA)
 {
-    typedef typename QuadMask<WIN>::type u64;          // (32 bits for windows up to 5 x 5)
+    typedef typename QuadMask<WIN>::type u64;
+    const F fpx = (F)dfx, fpy = (F)dfy;          // (32 bits for windows up to 5 x 5)
     static_assert(WIN >= 2 && WIN <= kQuadMaxWin, "window size");
     sumA = F(0); sumVA = F(0);
     // window origin: first pixel centre the square's bounding box can reach
@@ -231,6 +256,17 @@ AAI_HD bool quad_pixel(const QuadConsts<F> &q, int Xc, int Yc, F fpx, F fpy, int
 
     // dst-frame coordinates of pixel (Xc, Yc)'s centre: (ex, ey) = -(fpx, fpy)
     const F ac = fpy * q.s - fpx * q.c, bc = -(fpx * q.s + fpy * q.c);
+    const double acD = dfy * q.sD - dfx * q.cD;               // hiPrec: the left/right coordinate in double precision
+    // the left/right edge's t = h + k - |a| for window position (fi, fj) in double precision, clamped to [0, c + s] and
+    // mirrored about k there as well (near an axis both t and c + s - t can be tiny differences of numbers near 1)
+    auto precise_tp = [&](F fi, F fj, bool &flip) -> F {
+        const double ad = (acD - (double)fj * q.sD) + (double)fi * q.cD;
+        double t = q.hpkD - (ad < 0.0 ? -ad : ad);
+        const double k2 = q.cD + q.sD;
+        t = t < 0.0 ? 0.0 : (t > k2 ? k2 : t);
+        flip = t > 0.5 * k2;
+        return (F)(flip ? k2 - t : t);
+    };
     bool uncertain = false;
 
     // ---- pass 1: classify every window position --------------------------------------------------------------
@@ -252,7 +288,7 @@ AAI_HD bool quad_pixel(const QuadConsts<F> &q, int Xc, int Yc, F fpx, F fpy, int
                 // thresholds of |a| (the left/right line also switches formula at t = lo, hi under policy REFERENCE)
                 // and of |b|; one axis' thresholds only matter while the other axis does not already say "outside"
                 F na = qmin(qabs(a - q.hmk), qabs(a - q.hpk));
-                if (q.ref) na = qmin(na, qmin(qabs(a - (q.hpk - q.lo)), qabs(a - (q.hpk - q.hi))));
+                if (q.ref && !HP) na = qmin(na, qmin(qabs(a - (q.hpk - q.lo)), qabs(a - (q.hpk - q.hi))));
                 const F nb = qmin(qabs(b - q.hmk), qabs(b - q.hpk));
                 const bool live = (valid & bit) != 0;
                 if (live && ((na < q.margin && b < q.hpk + q.margin) || (nb < q.margin && a < q.hpk + q.margin))) uncertain = true;
@@ -303,7 +339,17 @@ AAI_HD bool quad_pixel(const QuadConsts<F> &q, int Xc, int Yc, F fpx, F fpy, int
         const F a = qabs((ac - fj * q.s) + fi * q.c), b = qabs((bc + fj * q.c) + fi * q.s);
         const bool isLR = a > b;                              // the line nearer the pixel centre is the cutting one
         const F t = qmin(qmax(q.hpk - qmax(a, b), F(0)), q.k2);      // its inside-distance + k
-        const F area = quad_cut(q, t, isLR && q.ref != 0);
+        F tp = qmin(t, q.k2 - t);
+        bool flip = t > q.k;
+        if (HP) {
+            bool pf;
+            const F pt = precise_tp(fi, fj, pf);
+            if (isLR) {
+                tp = pt; flip = pf;
+                if (SCAN && qabs(pt - q.lo) < q.marginT) uncertain = true;
+            }
+        }
+        const F area = quad_cut_tp(q, tp, flip, isLR && q.ref != 0);
         sumA += area;
         sumVA += area * val;
     }
@@ -316,7 +362,15 @@ AAI_HD bool quad_pixel(const QuadConsts<F> &q, int Xc, int Yc, F fpx, F fpy, int
         const F fj = fj0 + (F)j, fi = fi0 + (F)i;
         const F a = (ac - fj * q.s) + fi * q.c, b = (bc + fj * q.c) + fi * q.s;
         F nearS = F(1);
-        const F area = quad_double<F, SCAN>(q, q.h - qabs(a), q.h - qabs(b), (a < F(0)) == (b < F(0)), nearS);
+        const F A = q.h - qabs(a), B = q.h - qabs(b);
+        const F tA = qmin(qmax(A + q.k, F(0)), q.k2), tB = qmin(qmax(B + q.k, F(0)), q.k2);
+        F tpA = qmin(tA, q.k2 - tA);
+        bool flipA = tA > q.k;
+        if (HP) {
+            tpA = precise_tp(fi, fj, flipA);
+            if (SCAN && qabs(tpA - q.lo) < q.marginT) uncertain = true;
+        }
+        const F area = quad_double<F, SCAN>(q, A, B, tpA, flipA, tB, (a < F(0)) == (b < F(0)), nearS);
         if (SCAN && nearS < q.margin) uncertain = true;
         sumA += area;
         sumVA += area * val;
@@ -325,18 +379,18 @@ AAI_HD bool quad_pixel(const QuadConsts<F> &q, int Xc, int Yc, F fpx, F fpy, int
     return uncertain;
 }
 
-// run-time window size -> the matching instantiation
+// run-time window size and precision switch -> the matching instantiation
 template <typename F, bool SCAN, typename Src>
-AAI_HD bool quad_pixel_any(const QuadConsts<F> &q, int Xc, int Yc, F fpx, F fpy, int mW, int mH, Src &src, F &sumA, F &sumVA)
+AAI_HD bool quad_pixel_any(const QuadConsts<F> &q, int Xc, int Yc, double fpx, double fpy, int mW, int mH, Src &src, F &sumA, F &sumVA)
 {
+#define AAI_QUAD_CASE(W) case W: return q.hiPrec ? quad_pixel<F, W, SCAN, true>(q, Xc, Yc, fpx, fpy, mW, mH, src, sumA, sumVA) \
+                                                 : quad_pixel<F, W, SCAN, false>(q, Xc, Yc, fpx, fpy, mW, mH, src, sumA, sumVA);
     switch (q.win) {
-    case 3: return quad_pixel<F, 3, SCAN>(q, Xc, Yc, fpx, fpy, mW, mH, src, sumA, sumVA);
-    case 4: return quad_pixel<F, 4, SCAN>(q, Xc, Yc, fpx, fpy, mW, mH, src, sumA, sumVA);
-    case 5: return quad_pixel<F, 5, SCAN>(q, Xc, Yc, fpx, fpy, mW, mH, src, sumA, sumVA);
-    case 6: return quad_pixel<F, 6, SCAN>(q, Xc, Yc, fpx, fpy, mW, mH, src, sumA, sumVA);
-    case 7: return quad_pixel<F, 7, SCAN>(q, Xc, Yc, fpx, fpy, mW, mH, src, sumA, sumVA);
-    default: return quad_pixel<F, 8, SCAN>(q, Xc, Yc, fpx, fpy, mW, mH, src, sumA, sumVA);
+    AAI_QUAD_CASE(3) AAI_QUAD_CASE(4) AAI_QUAD_CASE(5) AAI_QUAD_CASE(6) AAI_QUAD_CASE(7)
+    default: return q.hiPrec ? quad_pixel<F, 8, SCAN, true>(q, Xc, Yc, fpx, fpy, mW, mH, src, sumA, sumVA)
+                             : quad_pixel<F, 8, SCAN, false>(q, Xc, Yc, fpx, fpy, mW, mH, src, sumA, sumVA);
     }
+#undef AAI_QUAD_CASE
 }
 
 }  // namespace aai

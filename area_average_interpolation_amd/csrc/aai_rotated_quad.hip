@@ -89,8 +89,8 @@ struct NoSrc {
 // the register budget follows it
 constexpr int quad_waves_per_simd(int win) { return 160 / (win * win) >= 8 ? 8 : 160 / (win * win); }
 
-template <typename T, int WIN, bool SCALED>
-__global__ __launch_bounds__(kQuadBlock, quad_waves_per_simd(WIN)) void aai_quad_kernel(RotLaunch r, QuadConsts<float> q, QuadMap m, const T *__restrict__ src,
+template <typename T, int WIN, bool SCALED, bool HP>
+__global__ __launch_bounds__(kQuadBlock, quad_waves_per_simd(WIN) - (HP && quad_waves_per_simd(WIN) > 2 ? 1 : 0)) void aai_quad_kernel(RotLaunch r, QuadConsts<float> q, QuadMap m, const T *__restrict__ src,
                                                              ImageView sv, float *__restrict__ dst, ImageView dv)
 {
     __shared__ float window[WIN * WIN][kQuadBlock];
@@ -110,7 +110,7 @@ __global__ __launch_bounds__(kQuadBlock, quad_waves_per_simd(WIN)) void aai_quad
         s.img = reinterpret_cast<const char *>(src + (int64_t)blockIdx.z * sv.imageStride + m.base);
         s.m = &m; s.mW = r.mW; s.mH = r.mH; s.lds = window; s.tid = tid;
         float sumA, sumVA;
-        quad_pixel<float, WIN, false>(q, (int)cx, (int)cy, (float)(px - cx), (float)(py - cy), r.mW, r.mH, s, sumA, sumVA);
+        quad_pixel<float, WIN, false, HP>(q, (int)cx, (int)cy, px - cx, py - cy, r.mW, r.mH, s, sumA, sumVA);
         value = sumA > 0.f ? sumVA / sumA : 0.f;                      // Source.cpp:577
     }
     *out = value;
@@ -119,7 +119,7 @@ __global__ __launch_bounds__(kQuadBlock, quad_waves_per_simd(WIN)) void aai_quad
 // Once per geometry: the same arithmetic without pixel loads.  Flags one bit per dst pixel in the 64-bit word of its
 // wave (the 16 x 16 tiling of aai_knife_scan_kernel, whose bits this kernel adds to) and counts the newly flagged
 // pixels in counter[0].
-template <int WIN>
+template <int WIN, bool HP>
 __global__ __launch_bounds__(kQuadBlock) void aai_quad_scan_kernel(RotLaunch r, QuadConsts<float> q, unsigned long long *__restrict__ laneMasks,
                                                                   unsigned *__restrict__ counter, int tileRow0)
 {
@@ -135,7 +135,7 @@ __global__ __launch_bounds__(kQuadBlock) void aai_quad_scan_kernel(RotLaunch r, 
         if (cx > -16.0 && cx < (double)r.mW + 16.0 && cy > -16.0 && cy < (double)r.mH + 16.0) {
             NoSrc s;
             float sumA, sumVA;
-            uncertain = quad_pixel<float, WIN, true>(q, (int)cx, (int)cy, (float)(px - cx), (float)(py - cy), r.mW, r.mH, s, sumA, sumVA);
+            uncertain = quad_pixel<float, WIN, true, HP>(q, (int)cx, (int)cy, px - cx, py - cy, r.mW, r.mH, s, sumA, sumVA);
         }
     }
     const unsigned long long any = __ballot(uncertain);
@@ -171,10 +171,13 @@ hipError_t launch_quad_win(const RotLaunch &r, const QuadConsts<float> &q, const
                            int batch, hipStream_t stream)
 {
     const dim3 grid((r.dW + 15) / 16, (r.dyEnd - r.dyBase + 15) / 16, batch);      // at most 65535 tile rows: the caller bands taller outputs
-    if (m.scale > 1)
-        hipLaunchKernelGGL((aai_quad_kernel<T, WIN, true>), grid, dim3(kQuadBlock), 0, stream, r, q, m, src, sv, dst, dv);
-    else
-        hipLaunchKernelGGL((aai_quad_kernel<T, WIN, false>), grid, dim3(kQuadBlock), 0, stream, r, q, m, src, sv, dst, dv);
+    if (m.scale > 1) {
+        if (q.hiPrec) hipLaunchKernelGGL((aai_quad_kernel<T, WIN, true, true>), grid, dim3(kQuadBlock), 0, stream, r, q, m, src, sv, dst, dv);
+        else hipLaunchKernelGGL((aai_quad_kernel<T, WIN, true, false>), grid, dim3(kQuadBlock), 0, stream, r, q, m, src, sv, dst, dv);
+    } else {
+        if (q.hiPrec) hipLaunchKernelGGL((aai_quad_kernel<T, WIN, false, true>), grid, dim3(kQuadBlock), 0, stream, r, q, m, src, sv, dst, dv);
+        else hipLaunchKernelGGL((aai_quad_kernel<T, WIN, false, false>), grid, dim3(kQuadBlock), 0, stream, r, q, m, src, sv, dst, dv);
+    }
     return hipGetLastError();
 }
 
@@ -220,12 +223,12 @@ hipError_t launch_quad_scan(const RotLaunch &r, unsigned long long *laneMasks, u
     for (int t0 = 0; t0 < tileRows; t0 += 65535) {         // grid.y carries at most 65535 tiles
         const dim3 grid((r.dW + 15) / 16, tileRows - t0 < 65535 ? tileRows - t0 : 65535, 1);
         switch (q.win) {
-        case 3: hipLaunchKernelGGL(aai_quad_scan_kernel<3>, grid, dim3(kQuadBlock), 0, stream, r, q, laneMasks, counter, t0); break;
-        case 4: hipLaunchKernelGGL(aai_quad_scan_kernel<4>, grid, dim3(kQuadBlock), 0, stream, r, q, laneMasks, counter, t0); break;
-        case 5: hipLaunchKernelGGL(aai_quad_scan_kernel<5>, grid, dim3(kQuadBlock), 0, stream, r, q, laneMasks, counter, t0); break;
-        case 6: hipLaunchKernelGGL(aai_quad_scan_kernel<6>, grid, dim3(kQuadBlock), 0, stream, r, q, laneMasks, counter, t0); break;
-        case 7: hipLaunchKernelGGL(aai_quad_scan_kernel<7>, grid, dim3(kQuadBlock), 0, stream, r, q, laneMasks, counter, t0); break;
-        default: hipLaunchKernelGGL(aai_quad_scan_kernel<8>, grid, dim3(kQuadBlock), 0, stream, r, q, laneMasks, counter, t0); break;
+        case 3: if (q.hiPrec) hipLaunchKernelGGL((aai_quad_scan_kernel<3, true>), grid, dim3(kQuadBlock), 0, stream, r, q, laneMasks, counter, t0); else hipLaunchKernelGGL((aai_quad_scan_kernel<3, false>), grid, dim3(kQuadBlock), 0, stream, r, q, laneMasks, counter, t0); break;
+        case 4: if (q.hiPrec) hipLaunchKernelGGL((aai_quad_scan_kernel<4, true>), grid, dim3(kQuadBlock), 0, stream, r, q, laneMasks, counter, t0); else hipLaunchKernelGGL((aai_quad_scan_kernel<4, false>), grid, dim3(kQuadBlock), 0, stream, r, q, laneMasks, counter, t0); break;
+        case 5: if (q.hiPrec) hipLaunchKernelGGL((aai_quad_scan_kernel<5, true>), grid, dim3(kQuadBlock), 0, stream, r, q, laneMasks, counter, t0); else hipLaunchKernelGGL((aai_quad_scan_kernel<5, false>), grid, dim3(kQuadBlock), 0, stream, r, q, laneMasks, counter, t0); break;
+        case 6: if (q.hiPrec) hipLaunchKernelGGL((aai_quad_scan_kernel<6, true>), grid, dim3(kQuadBlock), 0, stream, r, q, laneMasks, counter, t0); else hipLaunchKernelGGL((aai_quad_scan_kernel<6, false>), grid, dim3(kQuadBlock), 0, stream, r, q, laneMasks, counter, t0); break;
+        case 7: if (q.hiPrec) hipLaunchKernelGGL((aai_quad_scan_kernel<7, true>), grid, dim3(kQuadBlock), 0, stream, r, q, laneMasks, counter, t0); else hipLaunchKernelGGL((aai_quad_scan_kernel<7, false>), grid, dim3(kQuadBlock), 0, stream, r, q, laneMasks, counter, t0); break;
+        default: if (q.hiPrec) hipLaunchKernelGGL((aai_quad_scan_kernel<8, true>), grid, dim3(kQuadBlock), 0, stream, r, q, laneMasks, counter, t0); else hipLaunchKernelGGL((aai_quad_scan_kernel<8, false>), grid, dim3(kQuadBlock), 0, stream, r, q, laneMasks, counter, t0); break;
         }
         const hipError_t e = hipGetLastError();
         if (e != hipSuccess) return e;

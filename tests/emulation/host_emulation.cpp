@@ -260,11 +260,16 @@ static bool emu_quad_pixel(const QuadConsts<float> &qc, const RotLaunch &r, cons
     const double cxr = std::floor(px + 0.5), cyr = std::floor(py + 0.5);
     if (!(std::fabs(cxr) < 1e9 && std::fabs(cyr) < 1e9)) return false;
     const int Xc = (int)cxr, Yc = (int)cyr;
-    const float fpx = (float)(px - cxr), fpy = (float)(py - cyr);
+    const double fpx = px - cxr, fpy = py - cyr;
     EmuQuadSrc<WIN> qs{&r, img, stride, {}};
     float sA, sVA;
-    if (quad_pixel<float, WIN, true>(qc, Xc, Yc, fpx, fpy, r.mW, r.mH, qs, sA, sVA)) return false;      // the scan leaves it to double precision
-    quad_pixel<float, WIN, false>(qc, Xc, Yc, fpx, fpy, r.mW, r.mH, qs, sA, sVA);
+    if (qc.hiPrec) {
+        if (quad_pixel<float, WIN, true, true>(qc, Xc, Yc, fpx, fpy, r.mW, r.mH, qs, sA, sVA)) return false;      // the scan leaves it to double precision
+        quad_pixel<float, WIN, false, true>(qc, Xc, Yc, fpx, fpy, r.mW, r.mH, qs, sA, sVA);
+    } else {
+        if (quad_pixel<float, WIN, true, false>(qc, Xc, Yc, fpx, fpy, r.mW, r.mH, qs, sA, sVA)) return false;
+        quad_pixel<float, WIN, false, false>(qc, Xc, Yc, fpx, fpy, r.mW, r.mH, qs, sA, sVA);
+    }
     value = sA > 0.f ? sVA / sA : 0.f;
     return true;
 }
@@ -421,7 +426,54 @@ static void emu_rotated(const Geometry &g, const aai_request &rq, const float *i
         }
 }
 
+// debugging aid: the quad sums of one dst pixel in fp32 (as the GPU computes them) and in double precision
+template <typename F, int WIN>
+static void emu_quad_sums(const RotLaunch &r, const float *img, double px, double py, double *sumA, double *sumVA)
+{
+    struct Src {
+        const RotLaunch *r; const float *img; int64_t stride; float v[WIN * WIN];
+        void issue(int xg0, int yg0, unsigned long long valid) { for (int j = 0; j < WIN; ++j) for (int i = 0; i < WIN; ++i) v[j * WIN + i] = ((valid >> (j * WIN + i)) & 1) ? img[virt_offset(*r, xg0 + i, yg0 + j, stride)] : 0.f; }
+        void commit() {}
+        float at(int slot) const { return v[slot]; }
+    } qs{&r, img, r.W, {}};
+    const QuadConsts<F> q = make_quad_consts<F>(r.side, r.c, r.s, r.policy);
+    const double cxr = std::floor(px + 0.5), cyr = std::floor(py + 0.5);
+    F a, va;
+    if (q.hiPrec) quad_pixel<F, WIN, false, true>(q, (int)cxr, (int)cyr, px - cxr, py - cyr, r.mW, r.mH, qs, a, va);
+    else quad_pixel<F, WIN, false, false>(q, (int)cxr, (int)cyr, px - cxr, py - cyr, r.mW, r.mH, qs, a, va);
+    *sumA = a; *sumVA = va;
+}
+// per-slot areas of one dst pixel: the value source is 1 at one slot and 0 elsewhere
+template <typename F, int WIN>
+static void emu_quad_slot_areas(const RotLaunch &r, double px, double py, double *areas)
+{
+    struct Src { int hot; void issue(int, int, unsigned long long) {} void commit() {} float at(int slot) const { return slot == hot ? 1.f : 0.f; } };
+    const QuadConsts<F> q = make_quad_consts<F>(r.side, r.c, r.s, r.policy);
+    const double cxr = std::floor(px + 0.5), cyr = std::floor(py + 0.5);
+    for (int k = 0; k < WIN * WIN; ++k) {
+        Src qs{k};
+        F a, va;
+        if (q.hiPrec) quad_pixel<F, WIN, false, true>(q, (int)cxr, (int)cyr, px - cxr, py - cyr, r.mW, r.mH, qs, a, va);
+    else quad_pixel<F, WIN, false, false>(q, (int)cxr, (int)cyr, px - cxr, py - cyr, r.mW, r.mH, qs, a, va);
+        areas[k] = va;
+    }
+}
 extern "C" {
+int aai_emu_quad_slot_debug(const aai_request *rq, int dx, int dy, double *f32areas, double *f64areas)
+{
+    Geometry g; std::string msg;
+    if (make_geometry(*rq, g, msg) != AAI_OK) return -1;
+    const RotLaunch r = make_rot_launch(g, AAI_MODE_AREA, rq->policy);
+    double px, py; pixel_centre(r, dx, dy, px, py);
+    const QuadConsts<float> q = make_quad_consts<float>(r.side, r.c, r.s, r.policy);
+    switch (q.win) {
+    case 3: emu_quad_slot_areas<float, 3>(r, px, py, f32areas); emu_quad_slot_areas<double, 3>(r, px, py, f64areas); break;
+    case 4: emu_quad_slot_areas<float, 4>(r, px, py, f32areas); emu_quad_slot_areas<double, 4>(r, px, py, f64areas); break;
+    case 5: emu_quad_slot_areas<float, 5>(r, px, py, f32areas); emu_quad_slot_areas<double, 5>(r, px, py, f64areas); break;
+    default: return -2;
+    }
+    return q.win;
+}
 
 // Returns an AAI_* status; on success fills dW/dH and writes dW*dH floats to dst (if dst != NULL).
 int aai_emu_resample(const aai_request *rq, const float *src, float *dst, int *dW, int *dH, int *usedAxisPath)
@@ -500,6 +552,22 @@ int aai_emu_resample_channels(const aai_request *rq, int C, const float *src, fl
 
 void aai_emu_force_general(int on) { g_forceGeneral = on; }
 void aai_emu_use_quad(int on) { g_useQuad = on; }
+
+int aai_emu_quad_pixel_debug(const aai_request *rq, int dx, int dy, const float *img, double *out4)
+{
+    Geometry g; std::string msg;
+    if (make_geometry(*rq, g, msg) != AAI_OK) return -1;
+    const RotLaunch r = make_rot_launch(g, AAI_MODE_AREA, rq->policy);
+    double px, py; pixel_centre(r, dx, dy, px, py);
+    const QuadConsts<float> q = make_quad_consts<float>(r.side, r.c, r.s, r.policy);
+    switch (q.win) {
+    case 3: emu_quad_sums<float, 3>(r, img, px, py, out4 + 0, out4 + 1); emu_quad_sums<double, 3>(r, img, px, py, out4 + 2, out4 + 3); break;
+    case 4: emu_quad_sums<float, 4>(r, img, px, py, out4 + 0, out4 + 1); emu_quad_sums<double, 4>(r, img, px, py, out4 + 2, out4 + 3); break;
+    case 5: emu_quad_sums<float, 5>(r, img, px, py, out4 + 0, out4 + 1); emu_quad_sums<double, 5>(r, img, px, py, out4 + 2, out4 + 3); break;
+    default: return -2;
+    }
+    return 0;
+}
 void aai_emu_quad_stats(long *pixels, long *uncertain) { *pixels = g_quadPixels; *uncertain = g_quadUncertain; }
 
 // Pair-by-pair comparison of the quad formulation (evaluated in DOUBLE) with the older fast path and with the
@@ -554,7 +622,11 @@ long aai_emu_quad_pair_check(const aai_request *rq, double *maxOld, double *maxS
                     else if (mn <= -q.k) area = 0;
                     else if (mn >= q.k) area = 1;
                     else if (mx >= q.k) area = quad_cut(q, std::min(std::max(mn + q.k, 0.0), q.k2), A < B && q.ref);
-                    else { double nearS; area = quad_double<double, false>(q, A, B, (a < 0) == (b < 0), nearS); }
+                    else {
+                        double nearS;
+                        const double tA = std::min(std::max(A + q.k, 0.0), q.k2), tB = std::min(std::max(B + q.k, 0.0), q.k2);
+                        area = quad_double<double, false>(q, A, B, std::min(tA, q.k2 - tA), tA > q.k, tB, (a < 0) == (b < 0), nearS);
+                    }
                     *maxOld = std::max(*maxOld, std::fabs(area - old));
                     if (!flagged) *maxStrict = std::max(*maxStrict, std::fabs(area - strict_pair_area(sv4, X, Y, r.policy)));
                     ++n;

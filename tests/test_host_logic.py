@@ -478,23 +478,29 @@ def test_quad_fp32_replay_against_oracle_at_larger_sizes(aai, hostemu, po):
     hostemu.aai_emu_use_quad(1)
     try:
         for (W, sr, dr, ang, policy) in ((768, 8192.0, 2731.0, 17.5, 0), (512, 3.0, 1.0, 33.0, 0), (128, 1.0, 4.0, 45.0, 0),
-                                         (256, 1.0, 1.0, 61.0, 0), (200, 1.0, 2.0, 117.5, 1), (384, 2.0, 1.0, 215.0, 0)):
+                                         (256, 1.0, 1.0, 61.0, 0), (200, 1.0, 2.0, 117.5, 1), (384, 2.0, 1.0, 215.0, 0),
+                                         # close to an axis: the reference's corner-triangle rule is steep in t (slope 1 / (2 sin)),
+                                         # so the left/right edge's t comes from double precision (QuadConsts::hiPrec)
+                                         (512, 4.0, 1.0, 0.5, 0), (400, 2.0, 1.0, 89.5, 0), (400, 3.0, 1.0, 0.01, 0), (300, 1.0, 1.0, 179.9, 0),
+                                         (200, 1.0, 2.0, 0.2, 0), (384, 2.5, 1.0, 357.0, 1)):
             src = po.synth_image(W, W, 2)
             iso = ((W - 1) / 2, (W - 1) / 2)
             out, axis = hostemu.resample(aai.make_request(W, W, sr, dr, iso, ang, mode=1, policy=policy), src)
             q, u = hostemu.quad_stats()
             gold = po.oracle_run(po.MODE_EXACT, src.astype(np.float64), sr, dr, iso, ang, policy=policy).dst
             assert not axis and q > 0 and u < 0.01 * q, (W, sr, dr, ang, q, u)
-            assert rel_err(out, gold).max() <= 0.3 * TOL, (W, sr, dr, ang, float(rel_err(out, gold).max()))
+            assert rel_err(out, gold).max() <= 0.5 * TOL, (W, sr, dr, ang, float(rel_err(out, gold).max()))
             assert np.array_equal(gold == 0, out == 0)
     finally:
         hostemu.aai_emu_use_quad(0)
 
 
 def test_quad_serves_the_baseline_rotated_configs(aai, hostemu):
-    """configs 3 and 5 take the quad kernel; near-axis rotations and wide footprints stay on the double-precision kernels"""
+    """configs 3 and 5 take the quad kernel, and so do rotations close to an axis (with the left/right edge's t in double
+    precision); wide footprints and angles within ~0.006 degrees of an axis stay on the double-precision kernels"""
     def pairs(W, sr, dr, ang):
         return hostemu.quad_pair_check(aai.make_request(W, W, sr, dr, ((W - 1) / 2, (W - 1) / 2), ang, mode=1))[0]
     assert pairs(48, 8192.0, 2731.0, 17.5) > 0 and pairs(24, 1.0, 4.0, 45.0) > 0
-    assert pairs(48, 4.0, 1.0, 0.5) < 0 and pairs(48, 2.0, 1.0, 89.5) < 0      # corner-triangle rule too steep for fp32 coordinates
+    assert pairs(48, 4.0, 1.0, 0.5) > 0 and pairs(48, 2.0, 1.0, 89.5) > 0      # hiPrec
+    assert pairs(48, 3.0, 1.0, 0.004) < 0 and pairs(48, 3.0, 1.0, 90 - 1e-7) < 0
     assert pairs(64, 8.0, 1.0, 17.5) < 0                                        # window wider than 8 x 8
