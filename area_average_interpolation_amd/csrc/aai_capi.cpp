@@ -65,8 +65,16 @@ struct Plan {
     void *dList = nullptr;
     unsigned flaggedPixels = 0;
     bool dense = false;
+    // quad kernel: the lane masks of the flagged pixels (it skips them) and the side stream the fix-up pass runs on
+    unsigned long long *dMasks = nullptr;
+    hipStream_t side = nullptr;
+    hipEvent_t fork = nullptr, join = nullptr;
     ~Plan()
     {
+        if (side) { (void)hipStreamSynchronize(side); (void)hipStreamDestroy(side); }
+        if (fork) (void)hipEventDestroy(fork);
+        if (join) (void)hipEventDestroy(join);
+        if (dMasks) (void)hipFree(dMasks);
         if (dList) (void)hipFree(dList);
         if (dLane) (void)hipFree(dLane);
         if (dRow) (void)hipFree(dRow);
@@ -274,6 +282,14 @@ int get_plan(const aai_request &rq, int band0, int band1, int channels, Plan **o
                 if (e == hipSuccess) e = hipDeviceSynchronize();
             }
             if (dCount) (void)hipFree(dCount);
+            if (e == hipSuccess && count && r.quad && channels == 1) {
+                // keep the masks: the quad kernel skips the flagged pixels and the fix-up pass runs beside it
+                p.dMasks = dMasks;
+                dMasks = nullptr;
+                e = hipStreamCreateWithFlags(&p.side, hipStreamNonBlocking);
+                if (e == hipSuccess) e = hipEventCreateWithFlags(&p.fork, hipEventDisableTiming);
+                if (e == hipSuccess) e = hipEventCreateWithFlags(&p.join, hipEventDisableTiming);
+            }
             if (dMasks) (void)hipFree(dMasks);
         }
         if (e != hipSuccess) { g_plans.pop_front(); return hip_fail(e, "knife-edge scan"); }
@@ -327,6 +343,7 @@ int enqueue(const aai_request &rq, int batch, const void *dSrc, int srcType, int
         const aai::QuadMap qm = aai::make_quad_map(g, srcStride, r.srcRow0);
         aai::RotFlags flags;
         flags.list = p->dList; flags.count = p->flaggedPixels; flags.dense = p->dense;
+        flags.masks = p->dMasks; flags.side = p->side; flags.fork = p->fork; flags.join = p->join;
         e = hipSuccess;
         for (int b0 = 0; b0 < batch && e == hipSuccess; b0 += kMaxGridZ)
             e = aai::launch_rotated(r, qm, src_at(dSrc, srcType, (int64_t)b0 * srcImageStride), srcType, sv, dDst + (int64_t)b0 * dstImageStride, dv,

@@ -52,6 +52,12 @@ struct RotFlags {
     const void *list = nullptr;        // device array of uint2 (dx, dy), `count` entries
     unsigned count = 0;
     bool dense = false;                // so many that the whole image takes the double-precision pass instead
+    // With the lane masks kept, the quad kernel leaves the flagged pixels alone, so the fix-up pass no longer has to
+    // FOLLOW it: it runs beside it on the plan's side stream (fork / join through two events), where its few,
+    // latency-bound waves cost nothing instead of ~40 us behind the production pass.
+    const unsigned long long *masks = nullptr;
+    hipStream_t side = nullptr;
+    hipEvent_t fork = nullptr, join = nullptr;
 };
 size_t rotated_flag_words(const RotLaunch &r);      // waves of the tiling = 64-bit words of the mask array
 hipError_t launch_knife_scan(const RotLaunch &r, unsigned long long *laneMasks, unsigned *counter, hipStream_t stream);
@@ -62,7 +68,7 @@ hipError_t launch_rotated(const RotLaunch &r, const QuadMap &m, const void *src,
                           int batch, const RotFlags &flags, hipStream_t stream, const char **kernelName);
 bool quad_can_address(const RotLaunch &r, int srcType, ImageView sv);
 hipError_t launch_quad(const RotLaunch &r, const QuadMap &m, const void *src, int srcType, ImageView sv, float *dst, ImageView dv,
-                       int batch, hipStream_t stream);
+                       int batch, const unsigned long long *skipMasks, hipStream_t stream);
 
 // ---- utilities -----------------------------------------------------------------------------------------
 hipError_t launch_synth(float *dst, int W, int H, int64_t stride, uint64_t seed, hipStream_t stream);

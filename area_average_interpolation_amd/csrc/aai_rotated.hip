@@ -354,7 +354,7 @@ static hipError_t launch_rotated_band(const RotLaunch &r, const QuadMap &m, cons
     } else if (r.quad && tune.quad != 0 && quad_can_address(r, srcType, sv)) {
         // the fp32 quad formulation; the pixels flagged by the plan's scans are recomputed by the fix-up pass
         if (kernelName) *kernelName = "aai_quad_kernel<area>";
-        return launch_quad(r, m, src, srcType, sv, dst, dv, batch, stream);
+        return launch_quad(r, m, src, srcType, sv, dst, dv, batch, flags.count ? flags.masks : nullptr, stream);
     } else {
         const int runs = tune.runs >= 0 ? (tune.runs && r.scale == 1) : r.runs;
         if (runs) {
@@ -387,15 +387,32 @@ static hipError_t launch_rotated_typed(const RotLaunch &r, const QuadMap &m, con
         return hipGetLastError();
     }
     const int maxRows = kMaxGridY * (sampler ? 4 : 16);
+    // The double-precision pass over the pixels the plan's scans flagged (none for the samplers).  Behind the production
+    // pass on the same stream -- or, when the production kernel is the quad kernel and skips those pixels, beside it on
+    // the plan's side stream: fork before, join after.
+    const bool fixup = !sampler && flags.count != 0;
+    const bool beside = fixup && flags.masks && flags.side && r.mode == AAI_MODE_AREA && r.chan == 1 && r.quad && rot_tune().quad != 0 &&
+                        quad_can_address(r, srcType, sv);
+    hipError_t e = hipSuccess;
+    if (beside) {
+        e = hipEventRecord(flags.fork, stream);
+        if (e == hipSuccess) e = hipStreamWaitEvent(flags.side, flags.fork, 0);
+        if (e != hipSuccess) return e;
+        launch_rotated_fixup(r, batch, src, srcType, sv, dst, dv, static_cast<const uint2 *>(flags.list), flags.count, flags.side);
+        e = hipEventRecord(flags.join, flags.side);
+        if (e != hipSuccess) return e;
+    }
     for (int y0 = r.dyBase; y0 < r.dyEnd; y0 += maxRows) {
         RotLaunch rb = r;
         rb.dyBase = y0;
         rb.dyEnd = r.dyEnd - y0 > maxRows ? y0 + maxRows : r.dyEnd;
-        const hipError_t e = launch_rotated_band(rb, m, src, srcType, sv, dst + (int64_t)(y0 - r.dyBase) * dv.rowStride, dv, batch, flags, stream, kernelName);
+        RotFlags fb = flags;
+        if (!beside) fb.masks = nullptr;
+        e = launch_rotated_band(rb, m, src, srcType, sv, dst + (int64_t)(y0 - r.dyBase) * dv.rowStride, dv, batch, fb, stream, kernelName);
         if (e != hipSuccess) return e;
     }
-    // the double-precision pass over the pixels the plan's scans flagged (none for the samplers)
-    if (!sampler && flags.count) launch_rotated_fixup(r, batch, src, srcType, sv, dst, dv, static_cast<const uint2 *>(flags.list), flags.count, stream);
+    if (beside) return hipStreamWaitEvent(stream, flags.join, 0);
+    if (fixup) launch_rotated_fixup(r, batch, src, srcType, sv, dst, dv, static_cast<const uint2 *>(flags.list), flags.count, stream);
     return hipGetLastError();
 }
 

@@ -91,13 +91,20 @@ constexpr int quad_waves_per_simd(int win) { return 160 / (win * win) >= 8 ? 8 :
 
 template <typename T, int WIN, bool SCALED, bool HP>
 __global__ __launch_bounds__(kQuadBlock, quad_waves_per_simd(WIN) - (HP && quad_waves_per_simd(WIN) > 2 ? 1 : 0)) void aai_quad_kernel(RotLaunch r, QuadConsts<float> q, QuadMap m, const T *__restrict__ src,
-                                                             ImageView sv, float *__restrict__ dst, ImageView dv)
+                                                             ImageView sv, float *__restrict__ dst, ImageView dv,
+                                                             const unsigned long long *__restrict__ skipMasks)
 {
     __shared__ float window[WIN * WIN][kQuadBlock];
     const int tid = threadIdx.x;
     const int dx = blockIdx.x * 16 + (tid & 15);
     const int dy = r.dyBase + blockIdx.y * 16 + (tid >> 4);
     if (!(dx < r.dW && dy < r.dyEnd)) return;
+    if (skipMasks) {
+        // pixels the plan's scans flagged belong to the double-precision pass, which runs beside this kernel
+        const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+        const unsigned long long mask = skipMasks[((size_t)(blockIdx.y + r.dyBase / 16) * gridDim.x + blockIdx.x) * (kQuadBlock / 64) + wave];
+        if ((mask >> (tid & 63)) & 1ull) return;
+    }
     float *out = dst + (int64_t)blockIdx.z * dv.imageStride + (int64_t)(dy - r.dyBase) * dv.rowStride + dx;
 
     double px, py;
@@ -168,30 +175,31 @@ __global__ __launch_bounds__(256) void aai_flag_list_kernel(const unsigned long 
 
 template <typename T, int WIN>
 hipError_t launch_quad_win(const RotLaunch &r, const QuadConsts<float> &q, const QuadMap &m, const T *src, ImageView sv, float *dst, ImageView dv,
-                           int batch, hipStream_t stream)
+                           int batch, const unsigned long long *skipMasks, hipStream_t stream)
 {
     const dim3 grid((r.dW + 15) / 16, (r.dyEnd - r.dyBase + 15) / 16, batch);      // at most 65535 tile rows: the caller bands taller outputs
     if (m.scale > 1) {
-        if (q.hiPrec) hipLaunchKernelGGL((aai_quad_kernel<T, WIN, true, true>), grid, dim3(kQuadBlock), 0, stream, r, q, m, src, sv, dst, dv);
-        else hipLaunchKernelGGL((aai_quad_kernel<T, WIN, true, false>), grid, dim3(kQuadBlock), 0, stream, r, q, m, src, sv, dst, dv);
+        if (q.hiPrec) hipLaunchKernelGGL((aai_quad_kernel<T, WIN, true, true>), grid, dim3(kQuadBlock), 0, stream, r, q, m, src, sv, dst, dv, skipMasks);
+        else hipLaunchKernelGGL((aai_quad_kernel<T, WIN, true, false>), grid, dim3(kQuadBlock), 0, stream, r, q, m, src, sv, dst, dv, skipMasks);
     } else {
-        if (q.hiPrec) hipLaunchKernelGGL((aai_quad_kernel<T, WIN, false, true>), grid, dim3(kQuadBlock), 0, stream, r, q, m, src, sv, dst, dv);
-        else hipLaunchKernelGGL((aai_quad_kernel<T, WIN, false, false>), grid, dim3(kQuadBlock), 0, stream, r, q, m, src, sv, dst, dv);
+        if (q.hiPrec) hipLaunchKernelGGL((aai_quad_kernel<T, WIN, false, true>), grid, dim3(kQuadBlock), 0, stream, r, q, m, src, sv, dst, dv, skipMasks);
+        else hipLaunchKernelGGL((aai_quad_kernel<T, WIN, false, false>), grid, dim3(kQuadBlock), 0, stream, r, q, m, src, sv, dst, dv, skipMasks);
     }
     return hipGetLastError();
 }
 
 template <typename T>
-hipError_t launch_quad_typed(const RotLaunch &r, const QuadMap &m, const T *src, ImageView sv, float *dst, ImageView dv, int batch, hipStream_t stream)
+hipError_t launch_quad_typed(const RotLaunch &r, const QuadMap &m, const T *src, ImageView sv, float *dst, ImageView dv, int batch,
+                             const unsigned long long *skipMasks, hipStream_t stream)
 {
     const QuadConsts<float> q = make_quad_consts<float>(r.side, r.c, r.s, r.policy);
     switch (q.win) {
-    case 3: return launch_quad_win<T, 3>(r, q, m, src, sv, dst, dv, batch, stream);
-    case 4: return launch_quad_win<T, 4>(r, q, m, src, sv, dst, dv, batch, stream);
-    case 5: return launch_quad_win<T, 5>(r, q, m, src, sv, dst, dv, batch, stream);
-    case 6: return launch_quad_win<T, 6>(r, q, m, src, sv, dst, dv, batch, stream);
-    case 7: return launch_quad_win<T, 7>(r, q, m, src, sv, dst, dv, batch, stream);
-    default: return launch_quad_win<T, 8>(r, q, m, src, sv, dst, dv, batch, stream);
+    case 3: return launch_quad_win<T, 3>(r, q, m, src, sv, dst, dv, batch, skipMasks, stream);
+    case 4: return launch_quad_win<T, 4>(r, q, m, src, sv, dst, dv, batch, skipMasks, stream);
+    case 5: return launch_quad_win<T, 5>(r, q, m, src, sv, dst, dv, batch, skipMasks, stream);
+    case 6: return launch_quad_win<T, 6>(r, q, m, src, sv, dst, dv, batch, skipMasks, stream);
+    case 7: return launch_quad_win<T, 7>(r, q, m, src, sv, dst, dv, batch, skipMasks, stream);
+    default: return launch_quad_win<T, 8>(r, q, m, src, sv, dst, dv, batch, skipMasks, stream);
     }
 }
 
@@ -205,13 +213,13 @@ bool quad_can_address(const RotLaunch &r, int srcType, ImageView sv)
 }
 
 hipError_t launch_quad(const RotLaunch &r, const QuadMap &m, const void *src, int srcType, ImageView sv, float *dst, ImageView dv,
-                       int batch, hipStream_t stream)
+                       int batch, const unsigned long long *skipMasks, hipStream_t stream)
 {
     if (r.dW <= 0 || r.dyEnd <= r.dyBase || batch <= 0) return hipSuccess;
     switch (srcType) {
-    case SRC_U8: return launch_quad_typed(r, m, static_cast<const unsigned char *>(src), sv, dst, dv, batch, stream);
-    case SRC_U16: return launch_quad_typed(r, m, static_cast<const unsigned short *>(src), sv, dst, dv, batch, stream);
-    default: return launch_quad_typed(r, m, static_cast<const float *>(src), sv, dst, dv, batch, stream);
+    case SRC_U8: return launch_quad_typed(r, m, static_cast<const unsigned char *>(src), sv, dst, dv, batch, skipMasks, stream);
+    case SRC_U16: return launch_quad_typed(r, m, static_cast<const unsigned short *>(src), sv, dst, dv, batch, skipMasks, stream);
+    default: return launch_quad_typed(r, m, static_cast<const float *>(src), sv, dst, dv, batch, skipMasks, stream);
     }
 }
 

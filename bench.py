@@ -222,6 +222,10 @@ def worker(args):
     if args.gpus > 1 or world > 1 or args.force_dist:
         assert world == args.gpus, "WORLD_SIZE=%d but --gpus %d" % (world, args.gpus)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world == 1:                   # --force-dist without a launcher: a one-rank group
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
+            os.environ.setdefault("MASTER_PORT", str(_free_port()))
         # RCCL printf()s its version banner (NCCL_DEBUG=VERSION on these boxes) to stdout when the communicator is created:
         # park fd 1 on stderr until the ONE JSON line is due
         sys.stdout.flush()

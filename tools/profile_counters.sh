@@ -5,8 +5,8 @@ TAG=$1; shift
 OUT=gpurun_out/pmc_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
-rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_WAVE_CYCLES --kernel-trace --output-format csv -d $OUT/a -- python3 bench.py --no-cpu-baseline --steps 3 --warmup 1 "$@" > $OUT/a.json 2> $OUT/a.err
-rocprofv3 --pmc SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS SQ_INST_CYCLES_VMEM SQ_BUSY_CYCLES --kernel-trace --output-format csv -d $OUT/b -- python3 bench.py --no-cpu-baseline --steps 3 --warmup 1 "$@" > $OUT/b.json 2> $OUT/b.err
+rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_WAVE_CYCLES --kernel-trace --output-format csv -d $OUT/a -- python3 bench.py --no-cpu-baseline --steps 3 --warmup 1 --repeats 1 "$@" > $OUT/a.json 2> $OUT/a.err
+rocprofv3 --pmc SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS SQ_INST_CYCLES_VMEM SQ_BUSY_CYCLES --kernel-trace --output-format csv -d $OUT/b -- python3 bench.py --no-cpu-baseline --steps 3 --warmup 1 --repeats 1 "$@" > $OUT/b.json 2> $OUT/b.err
 python3 - $OUT <<'PY'
 import csv, glob, sys, collections
 out = sys.argv[1]

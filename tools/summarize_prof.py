@@ -25,17 +25,18 @@ for f in find("trace/**/*kernel_trace.csv"):
     rows = list(csv.DictReader(open(f)))
     if rows:
         r = [x for x in rows if "aai_" in x.get("Kernel_Name", "")]
-        seen = set()
-        print("\n## launch geometry (%s)" % os.path.relpath(f, out))
+        # per launch shape: the plan's one-off launch-shape measurement (aai_capi.cpp: tune_axis_plan) shows up as a few
+        # launches of other grids; the shape with most launches is the one the timed steps ran
+        shapes = defaultdict(list)
         for x in r:
-            key = (x["Kernel_Name"], x.get("Grid_Size_X"), x.get("Grid_Size_Y"), x.get("Grid_Size_Z"))
-            if key in seen:
-                continue
-            seen.add(key)
-            print("%s grid=(%s,%s,%s) wg=(%s,%s,%s) vgpr=%s sgpr=%s lds=%s scratch=%s" % (
-                x["Kernel_Name"][:70], x.get("Grid_Size_X"), x.get("Grid_Size_Y"), x.get("Grid_Size_Z"),
-                x.get("Workgroup_Size_X"), x.get("Workgroup_Size_Y"), x.get("Workgroup_Size_Z"),
-                x.get("VGPR_Count"), x.get("SGPR_Count"), x.get("LDS_Block_Size"), x.get("Scratch_Size")))
+            key = (x["Kernel_Name"][:70], x.get("Grid_Size_X"), x.get("Grid_Size_Y"), x.get("Grid_Size_Z"),
+                   x.get("Workgroup_Size_X"), x.get("Workgroup_Size_Y"), x.get("Workgroup_Size_Z"),
+                   x.get("VGPR_Count"), x.get("SGPR_Count"), x.get("LDS_Block_Size"), x.get("Scratch_Size"))
+            shapes[key].append(int(x["End_Timestamp"]) - int(x["Start_Timestamp"]))
+        print("\n## launch geometry and duration per shape (%s)" % os.path.relpath(f, out))
+        for key, d in sorted(shapes.items(), key=lambda kv: -len(kv[1])):
+            print("%s grid=(%s,%s,%s) wg=(%s,%s,%s) vgpr=%s sgpr=%s lds=%s scratch=%s  launches=%d avg_ns=%.0f min_ns=%d max_ns=%d" % (
+                key + (len(d), sum(d) / len(d), min(d), max(d))))
 for tag in ("pmc_fetch", "pmc_write"):
     for f in find(tag + "/**/*counter_collection.csv"):
         acc = defaultdict(list)
