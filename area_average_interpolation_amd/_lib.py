@@ -64,6 +64,8 @@ SYMBOLS = {
     "aai_resample_f64": (ctypes.c_int, [_RQ, _P, _I64, _P, _I64, _LY]),
     "aai_resample_device_f32": (ctypes.c_int, [_RQ, _P, _I64, _P, _I64, _P]),
     "aai_resample_batch_device_f32": (ctypes.c_int, [_RQ, ctypes.c_int32, _P, _I64, _I64, _P, _I64, _I64, _P]),
+    "aai_resample_batch_multi_device_f32": (ctypes.c_int, [_RQ, ctypes.c_int32, ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int32),
+                                                          ctypes.POINTER(_P), _I64, _I64, ctypes.POINTER(_P), _I64, _I64, ctypes.POINTER(_P)]),
     "aai_resample_batch_device": (ctypes.c_int, [_RQ, ctypes.c_int32, _P, ctypes.c_int32, _I64, _I64, _P, _I64, _I64, _P]),
     "aai_resample_host": (ctypes.c_int, [_RQ, _P, ctypes.c_int32, _I64, _P, _I64, _LY]),
     "aai_resample_interleaved_device": (ctypes.c_int, [_RQ, ctypes.c_int32, ctypes.c_int32, _P, ctypes.c_int32, _I64, _I64, _P, _I64, _I64, _P]),

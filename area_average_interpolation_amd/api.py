@@ -241,6 +241,21 @@ def resample_device(request, src_ptr, src_stride, dst_ptr, dst_stride, stream=0,
         raise AaiError(rc, last_error())
 
 
+def resample_multi_device(request, shards, src_stride, src_image_stride, dst_stride, dst_image_stride):
+    """aai_resample_batch_multi_device_f32: `shards` is a list of (device, count, src_ptr, dst_ptr, stream) -- one batch of
+    independent images spread over several GPUs of this process, no collective."""
+    n = len(shards)
+    devs = (ctypes.c_int32 * n)(*[int(s[0]) for s in shards])
+    cnts = (ctypes.c_int32 * n)(*[int(s[1]) for s in shards])
+    srcs = (ctypes.c_void_p * n)(*[s[2] for s in shards])
+    dsts = (ctypes.c_void_p * n)(*[s[3] for s in shards])
+    strs = (ctypes.c_void_p * n)(*[s[4] for s in shards])
+    rc = L.load().aai_resample_batch_multi_device_f32(ctypes.byref(request), n, devs, cnts, srcs, src_stride, src_image_stride,
+                                                     dsts, dst_stride, dst_image_stride, strs)
+    if rc != L.OK:
+        raise AaiError(rc, last_error())
+
+
 def band_source_rows(request, dst_row0, dst_row1):
     """aai_band_source_rows: source rows [a, b) that dst rows [dst_row0, dst_row1) read.  Needs no GPU."""
     a, b = ctypes.c_int32(), ctypes.c_int32()

@@ -528,6 +528,39 @@ int aai_resample_batch_device(const aai_request *req, int32_t batch, const void 
     return resample_batch_device_typed(req, batch, d_src, src_dtype, src_stride, src_image_stride, d_dst, dst_stride, dst_image_stride, stream);
 }
 
+int aai_resample_batch_multi_device_f32(const aai_request *req, int32_t n_shards, const int32_t *devices, const int32_t *counts,
+                                        const float *const *d_src, int64_t src_stride, int64_t src_image_stride,
+                                        float *const *d_dst, int64_t dst_stride, int64_t dst_image_stride, void *const *streams)
+{
+    int rc = check_request(req);
+    if (rc != AAI_OK) return rc;
+    if (n_shards < 0 || (n_shards > 0 && (!devices || !counts || !d_src || !d_dst))) return fail(AAI_ERR_BAD_ARGUMENT, "Bad shard description.");
+    {
+        aai::Geometry g;
+        std::string msg;
+        rc = aai::make_geometry(*req, g, msg);
+        if (rc != AAI_OK) return fail(rc, msg);
+    }
+    for (int i = 0; i < n_shards; ++i) {
+        if (counts[i] < 0) return fail(AAI_ERR_BAD_ARGUMENT, "Negative batch.");
+        if (counts[i] > 0 && (!d_src[i] || !d_dst[i])) return fail(AAI_ERR_BAD_ARGUMENT, "Null image pointer.");
+    }
+    rc = require_device();
+    if (rc != AAI_OK) return rc;
+    int home = 0;
+    AAI_HIP(hipGetDevice(&home));
+    for (int i = 0; i < n_shards && rc == AAI_OK; ++i) {
+        if (counts[i] == 0) continue;
+        const hipError_t e = hipSetDevice(devices[i]);
+        if (e != hipSuccess) { rc = hip_fail(e, "hipSetDevice"); break; }
+        rc = enqueue(*req, counts[i], d_src[i], aai::SRC_F32, src_stride, src_image_stride, d_dst[i], dst_stride, dst_image_stride,
+                     streams ? (hipStream_t)streams[i] : nullptr);
+    }
+    (void)hipSetDevice(home);
+    if (rc == AAI_OK) g_lastError.clear();
+    return rc;
+}
+
 int aai_resample_device_f32(const aai_request *req, const float *d_src, int64_t src_stride,
                             float *d_dst, int64_t dst_stride, void *stream)
 {

@@ -150,6 +150,16 @@ int aai_resample_batch_device_f32(const aai_request *req, int32_t batch,
                                   float *d_dst, int64_t dst_stride, int64_t dst_image_stride,
                                   void *stream);
 
+/* The same batch spread over SEVERAL GPUs of this process (images are independent, there is no
+ * exchange step, so no collective library is needed): shard i = counts[i] images resident on device devices[i] at
+ * d_src[i] / d_dst[i], enqueued on streams[i] (a stream of THAT device, or NULL).  Every shard is launched before the
+ * call returns; nothing is synchronised (the first call per device builds that device's plan, see aai_prepare).  The
+ * caller's current device is restored.  One process, N GPUs: what a C++ user of the reference's class needs to use a
+ * whole node; the one-process-per-GPU form over RCCL is area_average_interpolation_amd/distributed.py. */
+int aai_resample_batch_multi_device_f32(const aai_request *req, int32_t n_shards, const int32_t *devices, const int32_t *counts,
+                                        const float *const *d_src, int64_t src_stride, int64_t src_image_stride,
+                                        float *const *d_dst, int64_t dst_stride, int64_t dst_image_stride, void *const *streams);
+
 /* ---- typed sources (8-bit / 16-bit unsigned, or fp32): SURVEY.md section 8(f) N3 ----------------------------
  * Same semantics as the f32 entries above with `src` holding elements of `src_dtype` (AAI_DTYPE_*); strides are
  * in source ELEMENTS.  The reference only accepts doubles (Source.cpp:31); callers holding 8/16-bit images would

@@ -645,3 +645,49 @@ def test_reference_style_class(gpu, po):
     (ok, msg), dst, iso = a.fastAreaAverageInterpolation(src, (150, 150), (25.4, 25.4), (31, 23), 1.5)
     gold = po.oracle_run(po.MODE_FAST, src, 150, 25.4, (31, 23), 1.5)
     assert ok and rel_err(dst, gold.dst).max() <= TOL
+
+
+def test_multi_device_entry_and_prepare(gpu):
+    """aai_resample_batch_multi_device_f32: one batch spread over several shards (device, count, pointers, stream) of ONE
+    process -- on this one-GPU box both shards live on device 0, on two streams -- bit-identical to the batched call.
+    aai_prepare builds the plan up front, so that a captured stream only sees launches."""
+    import torch
+    W = H = 768
+    for (sr, dr, ang) in ((4, 1, 0.0), (3, 1, 17.5)):
+        rq = gpu.make_request(W, H, sr, dr, ((W - 1) / 2, (H - 1) / 2), ang)
+        gpu.prepare(rq)
+        rc, msg, lay = gpu.query(rq)
+        dW, dH = lay.dst_width, lay.dst_height
+        src = torch.empty((5, H, W), dtype=torch.float32, device="cuda")
+        for b in range(5):
+            gpu.synth_device(src[b].data_ptr(), W, H, W, b + 1)
+        whole = _device_run(gpu, rq, src, batch=5)
+        dst = torch.full((5, dH, dW), -1.0, dtype=torch.float32, device="cuda")
+        s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+        torch.cuda.synchronize()
+        gpu.resample_multi_device(rq, [(0, 2, src[0].data_ptr(), dst[0].data_ptr(), s1.cuda_stream),
+                                       (0, 3, src[2].data_ptr(), dst[2].data_ptr(), s2.cuda_stream)], W, W * H, dW, dW * dH)
+        torch.cuda.synchronize()
+        assert torch.equal(dst, whole), (sr, ang)
+        # after aai_prepare a stream capture only records launches (no allocation, no blocking copy)
+        g = torch.cuda.CUDAGraph()
+        out = torch.full((dH, dW), -1.0, dtype=torch.float32, device="cuda")
+        cs = torch.cuda.Stream()
+        with torch.cuda.graph(g, stream=cs):
+            gpu.resample_device(rq, src[1].data_ptr(), W, out.data_ptr(), dW, torch.cuda.current_stream().cuda_stream)
+        g.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(out, whole[1]), (sr, ang)
+
+
+def test_pinned_array_views_outlive_close(gpu):
+    """PinnedArray.close() drops the owner's reference only: a view held elsewhere keeps the page-locked block alive."""
+    import gc
+    p = gpu.PinnedArray((64, 64), np.float32)
+    p.array[...] = 3.5
+    view = p.array[10:20]
+    p.close()
+    gc.collect()
+    assert p.array is None and float(view.sum()) == 3.5 * 10 * 64
+    del view
+    gc.collect()
