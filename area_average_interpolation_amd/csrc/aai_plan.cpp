@@ -151,6 +151,24 @@ RotLaunch make_rot_launch(const Geometry &g, int mode, int policy)
     // reduced angle is so close to an axis that the reference's own corner-triangle rule amplifies fp32 coordinates
     // beyond the parity bar (quad_supported).
     r.quad = (mode == AAI_MODE_AREA && c > 0.0 && s > 0.0 && quad_supported(g.side, c, s)) ? 1 : 0;
+    {
+        // virtual centre: X = dx (side cs) + dy (side sn) + X0, Y = -dx (side sn) + dy (side cs) + Y0   (pixel_centre)
+        const double u0 = g.fracX * g.side - g.isoX + g.offX, v0 = g.fracY * g.side - g.isoY + g.offY;
+        const double Xa = g.side * g.cs, Xb = g.side * g.sn, X0 = u0 * g.cs + v0 * g.sn + g.isoX;
+        const double Ya = -g.side * g.sn, Yb = g.side * g.cs, Y0 = -u0 * g.sn + v0 * g.cs + g.isoY;
+        const double is = 1.0 / g.scale;
+        // continuous virtual -> continuous original coordinates per quadrant, then (v + 1/2) / scale - 1/2
+        double xa, xb, x0, ya, yb, y0;       // virtual-lattice combination that feeds source x / source y
+        switch (g.quadrant) {
+        default:
+        case 0: xa = Xa; xb = Xb; x0 = X0;               ya = Ya; yb = Yb; y0 = Y0;               break;
+        case 1: xa = Ya; xb = Yb; x0 = Y0;               ya = -Xa; yb = -Xb; y0 = g.mW - 1 - X0;  break;
+        case 2: xa = -Xa; xb = -Xb; x0 = g.mW - 1 - X0;  ya = -Ya; yb = -Yb; y0 = g.mH - 1 - Y0;  break;
+        case 3: xa = -Ya; xb = -Yb; x0 = g.mH - 1 - Y0;  ya = Xa; yb = Xb; y0 = X0;               break;
+        }
+        r.sAx = xa * is; r.sBx = xb * is; r.sCx = (x0 + 0.5) * is - 0.5;
+        r.sAy = ya * is; r.sBy = yb * is; r.sCy = (y0 + 0.5) * is - 0.5;
+    }
     return r;
 }
 

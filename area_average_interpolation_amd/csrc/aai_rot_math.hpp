@@ -49,6 +49,10 @@ struct RotLaunch {
     int chan;                       // interleaved channels per pixel (1 = a plain image): element = pixel offset * chan + channel
     int lt45;                       // reduced angle < 45 degrees
     double tsn, tcs, ttn;           // tmpSin, tmpCos, tmpTan (tan snapped to 0 below DBL_EPSILON)
+    // samplers (K4/K5): the dst pixel centre in continuous ORIGINAL-image coordinates (pixel centres at integers) is
+    // affine in (dx, dy): sx = sAx dx + sBx dy + sCx, sy alike -- pixel_centre, the quadrant's pre-rotation
+    // (Source.cpp:164-167) and the 1/scale of the replication composed once on the host in double precision
+    double sAx, sBx, sCx, sAy, sBy, sCy;
 };
 
 // Decisions closer than this (in virtual-source pixels) to their threshold are "knife edges": the fast

@@ -209,15 +209,6 @@ __global__ __launch_bounds__(kRotBlock) void aai_rotated_runs_kernel(RotLaunch r
 }
 
 // ---- K4/K5 -------------------------------------------------------------------------------------------
-// img already points at the channel; pitch = elements per pixel
-template <typename T>
-__device__ __forceinline__ float tap(const T *img, int64_t rowStride, int W, int H, int x, int y, int srcRow0 = 0, int pitch = 1)
-{
-    x = min(max(x, 0), W - 1);
-    y = min(max(y, 0), H - 1);
-    return (float)img[(int64_t)(y - srcRow0) * rowStride + (int64_t)x * pitch];
-}
-
 __device__ __forceinline__ void keys(float t, float w[4])
 {
     const float a = -0.5f, t2 = t * t, t3 = t2 * t;
@@ -235,18 +226,9 @@ __global__ __launch_bounds__(kBlock) void aai_sample_kernel(RotLaunch r, const T
     const int dy = r.dyBase + blockIdx.y * 4 + (threadIdx.x >> 6);
     if (dx >= r.dW || dy >= r.dyEnd) return;
     const T *img = src + (int64_t)blockIdx.z * sv.imageStride;
-    double X, Y;
-    pixel_centre(r, dx, dy, X, Y);
-    // continuous virtual coordinates -> continuous original-image coordinates (pixel centres at integers)
-    const double is = r.invScale;      // a multiplication instead of two fp64 divisions per pixel
-    double sx, sy;
-    switch (r.quadrant) {
-    default:
-    case 0: sx = (X + 0.5) * is - 0.5;             sy = (Y + 0.5) * is - 0.5;             break;
-    case 1: sx = (Y + 0.5) * is - 0.5;             sy = (r.mW - 1 - X + 0.5) * is - 0.5;  break;
-    case 2: sx = (r.mW - 1 - X + 0.5) * is - 0.5;  sy = (r.mH - 1 - Y + 0.5) * is - 0.5;  break;
-    case 3: sx = (r.mH - 1 - Y + 0.5) * is - 0.5;  sy = (X + 0.5) * is - 0.5;             break;
-    }
+    // the sample point in continuous original-image coordinates: affine in (dx, dy), coefficients from the host
+    const double ddx = (double)dx, ddy = (double)dy;
+    const double sx = fma(ddx, r.sAx, fma(ddy, r.sBx, r.sCx)), sy = fma(ddx, r.sAy, fma(ddy, r.sBy, r.sCy));
     const int chan = r.chan > 1 ? r.chan : 1;          // interleaved channels share the taps' positions and weights
     float *out = dst + (int64_t)blockIdx.z * dv.imageStride + (int64_t)(dy - r.dyBase) * dv.rowStride + (int64_t)dx * chan;
     if (sx < -0.5 || sx > r.W - 0.5 || sy < -0.5 || sy > r.H - 0.5) {
@@ -256,24 +238,33 @@ __global__ __launch_bounds__(kBlock) void aai_sample_kernel(RotLaunch r, const T
     const double fx = floor(sx), fy = floor(sy);
     const int ix = (int)fx, iy = (int)fy;
     const float tx = (float)(sx - fx), ty = (float)(sy - fy);
+    // clamp-to-edge taps: column offsets (elements) and row offsets once per pixel, then plain loads
+    constexpr int N = MODE == AAI_MODE_BILINEAR ? 2 : 4, FIRST = MODE == AAI_MODE_BILINEAR ? 0 : -1;
+    int xo[N];
+    int64_t yo[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        xo[i] = min(max(ix + FIRST + i, 0), r.W - 1) * chan;
+        yo[i] = (int64_t)(min(max(iy + FIRST + i, 0), r.H - 1) - r.srcRow0) * sv.rowStride;
+    }
     float wx[4], wy[4];
     if (MODE != AAI_MODE_BILINEAR) { keys(tx, wx); keys(ty, wy); }
     for (int c = 0; c < chan; ++c) {
         const T *ch = img + c;
         float v;
         if (MODE == AAI_MODE_BILINEAR) {
-            const float v00 = tap(ch, sv.rowStride, r.W, r.H, ix, iy, r.srcRow0, chan), v10 = tap(ch, sv.rowStride, r.W, r.H, ix + 1, iy, r.srcRow0, chan);
-            const float v01 = tap(ch, sv.rowStride, r.W, r.H, ix, iy + 1, r.srcRow0, chan), v11 = tap(ch, sv.rowStride, r.W, r.H, ix + 1, iy + 1, r.srcRow0, chan);
+            const float v00 = (float)ch[yo[0] + xo[0]], v10 = (float)ch[yo[0] + xo[1]];
+            const float v01 = (float)ch[yo[N - 1] + xo[0]], v11 = (float)ch[yo[N - 1] + xo[1]];
             // explicit fused multiply-adds: the same rounding whatever the compiler does with the channel loop
             const float top = fmaf(v10 - v00, tx, v00), bot = fmaf(v11 - v01, tx, v01);
             v = fmaf(bot - top, ty, top);
         } else {
             float acc = 0.f;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
+            for (int j = 0; j < N; ++j) {
                 float row = 0.f;
 #pragma unroll
-                for (int i = 0; i < 4; ++i) row = fmaf(wx[i], tap(ch, sv.rowStride, r.W, r.H, ix - 1 + i, iy - 1 + j, r.srcRow0, chan), row);
+                for (int i = 0; i < N; ++i) row = fmaf(wx[i], (float)ch[yo[j] + xo[i]], row);
                 acc = fmaf(wy[j], row, acc);
             }
             v = acc;
