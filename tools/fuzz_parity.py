@@ -18,7 +18,8 @@ st = torch.cuda.current_stream().cuda_stream
 special = [0, 30, 45, 60, 90, 180, 270, math.degrees(math.atan(0.5)), 17.5, 1e-6, 89.999999]
 worst, bad = 0.0, 0
 for k in range(N):
-    W, H = int(rng.integers(1, 140)), int(rng.integers(1, 140))
+    BIG = int(os.environ.get("FUZZ_MAX", "140"))
+    W, H = int(rng.integers(1, BIG)), int(rng.integers(1, BIG))
     sr = float(rng.choice([1, 2, 3, 4, 5])) if k % 3 == 0 else float(rng.uniform(0.4, 8))
     dr = float(rng.choice([1, 2])) if k % 3 == 0 else float(rng.uniform(0.4, 3))
     if dr / sr > 2.2:
@@ -36,6 +37,9 @@ for k in range(N):
     omode = {1: po.MODE_EXACT, 2: po.MODE_FAST, 3: 3, 4: 4}[mode]
     gold = po.oracle_run(omode, src.astype(np.float64), sr, dr, iso, ang, policy=policy)
     rc, msg, dst, giso, lay = aai.resample_host(src, sr, dr, iso, ang, mode=mode, policy=policy)
+    if gold.dst.size == 0:
+        assert rc == L.ERR_EMPTY_OUTPUT, (rc, msg)          # an extent that rounds to 0: the reference crashes, the library reports it
+        continue
     assert rc == 0, msg
     tol = 2e-5 * scale if mode in (3, 4) else None
     if dst.size:
