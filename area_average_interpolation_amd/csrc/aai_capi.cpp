@@ -218,13 +218,12 @@ int get_plan(const aai_request &rq, int band0, int band1, int channels, Plan **o
     AAI_HIP(hipGetDevice(&dev));
     {
         // Only K1's tables depend on the row band.  The per-pixel kernels take the band as launch parameters and their
-        // one-off scans cover the whole image, so every band of a rotated request shares one plan (and the fp64 / fp32
-        // kernels of the interleaved / planar paths flag different pixels: channels only matters as "one or several").
+        // one-off scans cover the whole image, so every band and every channel count of a rotated request shares one plan.
         aai::Geometry g0;
         std::string msg0;
         int rc0 = aai::make_geometry(rq, g0, msg0);
         if (rc0 != AAI_OK) return fail(rc0, msg0);
-        if (pick_kernel(rq, g0) != AAI_KERNEL_AXIS) { band0 = band1 = -1; channels = channels > 1 ? 2 : 1; }
+        if (pick_kernel(rq, g0) != AAI_KERNEL_AXIS) { band0 = band1 = -1; channels = 1; }
     }
     for (auto it = g_plans.begin(); it != g_plans.end(); ++it) {
         if (it->device == dev && it->band0 == band0 && it->band1 == band1 && it->channels == channels && same_request(it->key, rq)) {
@@ -272,7 +271,7 @@ int get_plan(const aai_request &rq, int band0, int band1, int channels, Plan **o
             if (e == hipSuccess) e = hipMalloc((void **)&dCount, sizeof(unsigned));
             if (e == hipSuccess) e = hipMemset(dCount, 0, sizeof(unsigned));
             if (e == hipSuccess) e = aai::launch_knife_scan(r, dMasks, dCount, nullptr);
-            if (e == hipSuccess && r.quad && channels == 1) e = aai::launch_quad_scan(r, dMasks, dCount, nullptr);
+            if (e == hipSuccess && r.quad) e = aai::launch_quad_scan(r, dMasks, dCount, nullptr);
             if (e == hipSuccess) e = hipMemcpy(&count, dCount, sizeof(unsigned), hipMemcpyDeviceToHost);
             if (e == hipSuccess && count > kMaxListedPixels) { p.dense = true; count = 0; }
             if (e == hipSuccess && count) {
@@ -282,7 +281,7 @@ int get_plan(const aai_request &rq, int band0, int band1, int channels, Plan **o
                 if (e == hipSuccess) e = hipDeviceSynchronize();
             }
             if (dCount) (void)hipFree(dCount);
-            if (e == hipSuccess && count && r.quad && channels == 1) {
+            if (e == hipSuccess && count && r.quad) {
                 // keep the masks: the quad kernel skips the flagged pixels and the fix-up pass runs beside it
                 p.dMasks = dMasks;
                 dMasks = nullptr;
@@ -340,7 +339,7 @@ int enqueue(const aai_request &rq, int batch, const void *dSrc, int srcType, int
             r.dyBase = band0; r.dyEnd = band1; r.srcRow0 = srcRow0;
         }
         r.chan = channels;
-        const aai::QuadMap qm = aai::make_quad_map(g, srcStride, r.srcRow0);
+        const aai::QuadMap qm = aai::make_quad_map(g, srcStride, r.srcRow0, channels);
         aai::RotFlags flags;
         flags.list = p->dList; flags.count = p->flaggedPixels; flags.dense = p->dense;
         flags.masks = p->dMasks; flags.side = p->side; flags.fork = p->fork; flags.join = p->join;

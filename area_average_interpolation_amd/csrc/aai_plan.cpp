@@ -172,17 +172,17 @@ RotLaunch make_rot_launch(const Geometry &g, int mode, int policy)
     return r;
 }
 
-QuadMap make_quad_map(const Geometry &g, int64_t rowStride, int srcRow0)
+QuadMap make_quad_map(const Geometry &g, int64_t rowStride, int srcRow0, int channels)
 {
     QuadMap m{};
     m.nX = g.mW / g.scale; m.nY = g.mH / g.scale;
     m.base = -(int64_t)srcRow0 * rowStride;
     switch (g.quadrant) {
     default:
-    case 0: m.strideX = 1;         m.flipX = 0; m.strideY = rowStride; m.flipY = 0; break;   // (X, Y)          -> (x, y) = (X, Y)
-    case 1: m.strideX = rowStride; m.flipX = 1; m.strideY = 1;         m.flipY = 0; break;   // (Y, mW-1-X)
-    case 2: m.strideX = 1;         m.flipX = 1; m.strideY = rowStride; m.flipY = 1; break;   // (mW-1-X, mH-1-Y)
-    case 3: m.strideX = rowStride; m.flipX = 0; m.strideY = 1;         m.flipY = 1; break;   // (mH-1-Y, X)
+    case 0: m.strideX = channels;  m.flipX = 0; m.strideY = rowStride; m.flipY = 0; break;   // (X, Y)          -> (x, y) = (X, Y)
+    case 1: m.strideX = rowStride; m.flipX = 1; m.strideY = channels;  m.flipY = 0; break;   // (Y, mW-1-X)
+    case 2: m.strideX = channels;  m.flipX = 1; m.strideY = rowStride; m.flipY = 1; break;   // (mW-1-X, mH-1-Y)
+    case 3: m.strideX = rowStride; m.flipX = 0; m.strideY = channels;  m.flipY = 1; break;   // (mH-1-Y, X)
     }
     m.scale = g.scale;
     m.invScale = (float)(1.0 / g.scale);

@@ -68,7 +68,7 @@ struct QuadMap {
     float invScale;
     double invScaleD;
 };
-QuadMap make_quad_map(const Geometry &g, int64_t rowStride, int srcRow0);
+QuadMap make_quad_map(const Geometry &g, int64_t rowStride, int srcRow0, int channels = 1);      // channels: elements per pixel (interleaved)
 
 // ---- K1: separable axis-aligned tables ---------------------------------------------------------------
 // One entry per output index along one axis: the source window [s0,s1] along the matching SOURCE axis

@@ -122,6 +122,12 @@ template <typename F> AAI_HD F qmin(F a, F b) { return a < b ? a : b; }
 template <typename F> AAI_HD F qmax(F a, F b) { return a < b ? b : a; }
 AAI_HD float qabs(float a) { return __builtin_fabsf(a); }       // a source modifier on the GPU, not an instruction
 AAI_HD double qabs(double a) { return __builtin_fabs(a); }
+// Every multiply-add of this header is an EXPLICIT fused multiply-add and its translation units are compiled without
+// contraction: the kernels' instantiations (plain / interleaved, scan / production) and the CPU replay of the test-suite
+// then execute the same IEEE operations and agree bit for bit, instead of differing in the last place wherever a
+// compiler chose to fuse differently.
+AAI_HD float qfma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+AAI_HD double qfma(double a, double b, double c) { return __builtin_fma(a, b, c); }
 
 // Area of the part of a unit pixel on the inner side of ONE edge line that has entered it by t (0 <= t <= c+s,
 // measured from the pixel's extreme corner along the line's normal).  substitute: the line is a left/right edge
@@ -130,9 +136,9 @@ template <typename F>
 AAI_HD F quad_cut_tp(const QuadConsts<F> &q, F tp, bool flip, bool substitute)
 {
     // tp = min(t, c + s - t): the line's distance from the NEARER extreme corner (the cases mirror at t = k); flip: t > k
-    const F trap = tp * q.rhi - q.trapOff;                // (tp - lo/2) / hi
-    const F triExact = tp * tp * q.r2cs;                  // legs tp/c, tp/s
-    const F triRef = (F(0.5) - q.hrc * tp) * (F(1) - q.rs * tp);
+    const F trap = qfma(tp, q.rhi, -q.trapOff);           // (tp - lo/2) / hi
+    const F triExact = (tp * tp) * q.r2cs;                // legs tp/c, tp/s
+    const F triRef = qfma(-q.hrc, tp, F(0.5)) * qfma(-q.rs, tp, F(1));
     const F tri = substitute ? triRef : triExact;
     const F g = tp <= q.lo ? tri : trap;
     return flip ? F(1) - g : g;
@@ -155,7 +161,7 @@ AAI_HD F quad_double(const QuadConsts<F> &q, F A, F B, F tpA, bool flipA, F tB, 
     const F u = sameSign ? A : B, v = sameSign ? B : A;
     // V relative to the pixel centre along the pixel's own axes, in the orientation where the square lies
     // towards -x, -y of V: edge 1 runs from V towards -y, edge 2 towards -x
-    const F cx = u * q.c + v * q.s, cy = v * q.c - u * q.s;
+    const F cx = qfma(u, q.c, v * q.s), cy = qfma(v, q.c, -(u * q.s));
     const bool r = cx >= F(0.5);
     const bool S1 = r || cy >= F(0.5);                    // edge 1 crosses the pixel (V beyond its +x or +y side)
     const bool S2 = r || cy <= F(-0.5);                   // edge 2 crosses the pixel (V beyond its +x or -y side)
@@ -188,11 +194,11 @@ AAI_HD F quad_vertex_area(const QuadConsts<F> &q, F fx, F fy, int vidx)
     }
     // vertex 0: the wedge opens towards +x between the rays (c,-s) and (s,c)
     const F dR = F(0.5) - x, dT = y + F(0.5), dB = F(0.5) - y;
-    const F y1 = y - dR * q.m1, y2 = y + dR * q.im1;      // where the two rays meet the line x = 1/2
+    const F y1 = qfma(-dR, q.m1, y), y2 = qfma(dR, q.im1, y);      // where the two rays meet the line x = 1/2
     const F lenR = qmin(y2, F(0.5)) - qmax(y1, F(-0.5));
-    const F lenT = qmax(F(0), F(0.5) - (x + dT * q.im1));  // ray 1 leaves through the top side
-    const F lenB = qmax(F(0), F(0.5) - (x + dB * q.m1));   // ray 2 leaves through the bottom side
-    return F(0.5) * (dR * lenR + dT * lenT + dB * lenB);
+    const F lenT = qmax(F(0), F(0.5) - qfma(dT, q.im1, x));  // ray 1 leaves through the top side
+    const F lenB = qmax(F(0), F(0.5) - qfma(dB, q.m1, x));   // ray 2 leaves through the bottom side
+    return F(0.5) * qfma(dR, lenR, qfma(dT, lenT, dB * lenB));
 }
 
 AAI_HD int quad_ctz(unsigned long long m)
@@ -222,19 +228,32 @@ template <int WIN> struct QuadMask<WIN, true> { typedef unsigned type; };
 //   src.issue(xg0, yg0, valid)  start fetching the values of the window whose position (0, 0) is virtual pixel
 //                               (xg0, yg0); `valid` has the bits of the positions inside the mW x mH lattice
 //   src.commit()                make them addressable (the GPU parks them in LDS, one column per lane)
-//   src.at(slot)                value of a position whose valid bit is set
+//   src.at(slot, vals)          the NC channel values of a position whose valid bit is set
 // so that the loads are in flight while the window is classified and every later pass reads at LDS latency.
-// Returns the sums; the dst value is sumVA / sumA, or 0 when sumA is 0 (Source.cpp:577).
+// Returns the sums; the dst value of channel c is sumVA[c] / sumA, or 0 when sumA is 0 (Source.cpp:577).  NC = 1 for
+// a plain image; interleaved channels share every area (NC = 4 accumulators, unused ones stay 0).
 // SCAN: src is never touched, every value counts as 1 and the return value says whether this pixel must be left to
 // the double-precision pass.
 // HP: QuadConsts::hiPrec as a compile-time switch (the double-precision code costs registers even where it never runs)
-template <typename F, int WIN, bool SCAN, bool HP, typename Src>
-AAI_HD bool quad_pixel(const QuadConsts<F> &q, int Xc, int Yc, double dfx, double dfy, int mW, int mH, Src &src, F &sumA, F &sumVA)
+template <typename F, int WIN, bool SCAN, bool HP, int NC, typename Src>
+AAI_HD bool quad_pixel(const QuadConsts<F> &q, int Xc, int Yc, double dfx, double dfy, int mW, int mH, Src &src, F &sumA, F (&sumVA)[NC])
 {
     typedef typename QuadMask<WIN>::type u64;
     const F fpx = (F)dfx, fpy = (F)dfy;          // (32 bits for windows up to 5 x 5)
     static_assert(WIN >= 2 && WIN <= kQuadMaxWin, "window size");
-    sumA = F(0); sumVA = F(0);
+    sumA = F(0);
+#pragma unroll
+    for (int c = 0; c < NC; ++c) sumVA[c] = F(0);
+    // sumVA += w * (the values of one window slot); SCAN counts every value as 1
+    auto accumulate = [&](F w, int slot) {
+        F vals[NC];
+        if (SCAN) {
+#pragma unroll
+            for (int c = 0; c < NC; ++c) vals[c] = F(1);
+        } else src.at(slot, vals);
+#pragma unroll
+        for (int c = 0; c < NC; ++c) sumVA[c] = qfma(w, vals[c], sumVA[c]);
+    };
     // window origin: first pixel centre the square's bounding box can reach
     const F fi0 = floor(fpx - q.hbm), fj0 = floor(fpy - q.hbm);
     const int i0 = (int)fi0, j0 = (int)fj0;
@@ -255,12 +274,12 @@ AAI_HD bool quad_pixel(const QuadConsts<F> &q, int Xc, int Yc, double dfx, doubl
     if (!SCAN) src.issue(xg0, yg0, valid);
 
     // dst-frame coordinates of pixel (Xc, Yc)'s centre: (ex, ey) = -(fpx, fpy)
-    const F ac = fpy * q.s - fpx * q.c, bc = -(fpx * q.s + fpy * q.c);
-    const double acD = dfy * q.sD - dfx * q.cD;               // hiPrec: the left/right coordinate in double precision
+    const F ac = qfma(fpy, q.s, -(fpx * q.c)), bc = -qfma(fpx, q.s, fpy * q.c);
+    const double acD = qfma(dfy, q.sD, -(dfx * q.cD));        // hiPrec: the left/right coordinate in double precision
     // the left/right edge's t = h + k - |a| for window position (fi, fj) in double precision, clamped to [0, c + s] and
     // mirrored about k there as well (near an axis both t and c + s - t can be tiny differences of numbers near 1)
     auto precise_tp = [&](F fi, F fj, bool &flip) -> F {
-        const double ad = (acD - (double)fj * q.sD) + (double)fi * q.cD;
+        const double ad = qfma((double)fi, q.cD, qfma(-(double)fj, q.sD, acD));
         double t = q.hpkD - (ad < 0.0 ? -ad : ad);
         const double k2 = q.cD + q.sD;
         t = t < 0.0 ? 0.0 : (t > k2 ? k2 : t);
@@ -275,11 +294,11 @@ AAI_HD bool quad_pixel(const QuadConsts<F> &q, int Xc, int Yc, double dfx, doubl
 #pragma unroll
     for (int j = 0; j < WIN; ++j) {
         const F fj = fj0 + (F)j;
-        const F rowA = ac - fj * q.s, rowB = bc + fj * q.c;
+        const F rowA = qfma(-fj, q.s, ac), rowB = qfma(fj, q.c, bc);
 #pragma unroll
         for (int i = 0; i < WIN; ++i) {
             const F fi = fi0 + (F)i;
-            const F a = qabs(rowA + fi * q.c), b = qabs(rowB + fi * q.s);
+            const F a = qabs(qfma(fi, q.c, rowA)), b = qabs(qfma(fi, q.s, rowB));
             const u64 bit = (u64)1 << (j * WIN + i);
             if (a <= q.hmk) pA |= bit;
             if (b <= q.hmk) pB |= bit;
@@ -315,9 +334,8 @@ AAI_HD bool quad_pixel(const QuadConsts<F> &q, int Xc, int Yc, double dfx, doubl
         mDouble &= ~bit;
         if (valid & bit) {
             const F area = quad_vertex_area(q, fx, fy, vtx);
-            const F val = SCAN ? F(1) : (F)src.at(slot);
             sumA += area;
-            sumVA += area * val;
+            accumulate(area, slot);
         }
     }
 
@@ -325,18 +343,16 @@ AAI_HD bool quad_pixel(const QuadConsts<F> &q, int Xc, int Yc, double dfx, doubl
     while (mIn) {
         const int slot = quad_ctz(mIn);
         mIn &= mIn - 1;
-        const F val = SCAN ? F(1) : (F)src.at(slot);
         sumA += F(1);
-        sumVA += val;
+        accumulate(F(1), slot);
     }
     // ---- pixels cut by one edge line ---------------------------------------------------------------------------------
     while (mSingle) {
         const int slot = quad_ctz(mSingle);
         mSingle &= mSingle - 1;
         const int j = slot / WIN, i = slot - j * WIN;
-        const F val = SCAN ? F(1) : (F)src.at(slot);
         const F fj = fj0 + (F)j, fi = fi0 + (F)i;
-        const F a = qabs((ac - fj * q.s) + fi * q.c), b = qabs((bc + fj * q.c) + fi * q.s);
+        const F a = qabs(qfma(fi, q.c, qfma(-fj, q.s, ac))), b = qabs(qfma(fi, q.s, qfma(fj, q.c, bc)));
         const bool isLR = a > b;                              // the line nearer the pixel centre is the cutting one
         const F t = qmin(qmax(q.hpk - qmax(a, b), F(0)), q.k2);      // its inside-distance + k
         F tp = qmin(t, q.k2 - t);
@@ -351,16 +367,15 @@ AAI_HD bool quad_pixel(const QuadConsts<F> &q, int Xc, int Yc, double dfx, doubl
         }
         const F area = quad_cut_tp(q, tp, flip, isLR && q.ref != 0);
         sumA += area;
-        sumVA += area * val;
+        accumulate(area, slot);
     }
     // ---- pixels cut by both near edge lines --------------------------------------------------------------------------
     while (mDouble) {
         const int slot = quad_ctz(mDouble);
         mDouble &= mDouble - 1;
         const int j = slot / WIN, i = slot - j * WIN;
-        const F val = SCAN ? F(1) : (F)src.at(slot);
         const F fj = fj0 + (F)j, fi = fi0 + (F)i;
-        const F a = (ac - fj * q.s) + fi * q.c, b = (bc + fj * q.c) + fi * q.s;
+        const F a = qfma(fi, q.c, qfma(-fj, q.s, ac)), b = qfma(fi, q.s, qfma(fj, q.c, bc));
         F nearS = F(1);
         const F A = q.h - qabs(a), B = q.h - qabs(b);
         const F tA = qmin(qmax(A + q.k, F(0)), q.k2), tB = qmin(qmax(B + q.k, F(0)), q.k2);
@@ -373,22 +388,22 @@ AAI_HD bool quad_pixel(const QuadConsts<F> &q, int Xc, int Yc, double dfx, doubl
         const F area = quad_double<F, SCAN>(q, A, B, tpA, flipA, tB, (a < F(0)) == (b < F(0)), nearS);
         if (SCAN && nearS < q.margin) uncertain = true;
         sumA += area;
-        sumVA += area * val;
+        accumulate(area, slot);
     }
     if (SCAN && sumA > F(0) && sumA < q.minArea) uncertain = true;
     return uncertain;
 }
 
 // run-time window size and precision switch -> the matching instantiation
-template <typename F, bool SCAN, typename Src>
-AAI_HD bool quad_pixel_any(const QuadConsts<F> &q, int Xc, int Yc, double fpx, double fpy, int mW, int mH, Src &src, F &sumA, F &sumVA)
+template <typename F, bool SCAN, int NC, typename Src>
+AAI_HD bool quad_pixel_any(const QuadConsts<F> &q, int Xc, int Yc, double fpx, double fpy, int mW, int mH, Src &src, F &sumA, F (&sumVA)[NC])
 {
-#define AAI_QUAD_CASE(W) case W: return q.hiPrec ? quad_pixel<F, W, SCAN, true>(q, Xc, Yc, fpx, fpy, mW, mH, src, sumA, sumVA) \
-                                                 : quad_pixel<F, W, SCAN, false>(q, Xc, Yc, fpx, fpy, mW, mH, src, sumA, sumVA);
+#define AAI_QUAD_CASE(W) case W: return q.hiPrec ? quad_pixel<F, W, SCAN, true, NC>(q, Xc, Yc, fpx, fpy, mW, mH, src, sumA, sumVA) \
+                                                 : quad_pixel<F, W, SCAN, false, NC>(q, Xc, Yc, fpx, fpy, mW, mH, src, sumA, sumVA);
     switch (q.win) {
     AAI_QUAD_CASE(3) AAI_QUAD_CASE(4) AAI_QUAD_CASE(5) AAI_QUAD_CASE(6) AAI_QUAD_CASE(7)
-    default: return q.hiPrec ? quad_pixel<F, 8, SCAN, true>(q, Xc, Yc, fpx, fpy, mW, mH, src, sumA, sumVA)
-                             : quad_pixel<F, 8, SCAN, false>(q, Xc, Yc, fpx, fpy, mW, mH, src, sumA, sumVA);
+    default: return q.hiPrec ? quad_pixel<F, 8, SCAN, true, NC>(q, Xc, Yc, fpx, fpy, mW, mH, src, sumA, sumVA)
+                             : quad_pixel<F, 8, SCAN, false, NC>(q, Xc, Yc, fpx, fpy, mW, mH, src, sumA, sumVA);
     }
 #undef AAI_QUAD_CASE
 }

@@ -327,7 +327,11 @@ static hipError_t launch_rotated_band(const RotLaunch &r, const QuadMap &m, cons
     }
     dim3 grid((r.dW + 15) / 16, (r.dyEnd - r.dyBase + 15) / 16, batch);
     const RotTune &tune = rot_tune();
-    if (r.chan > 1) {
+    if (r.chan > 1 && r.mode == AAI_MODE_AREA && r.quad && tune.quad != 0 && quad_can_address(r, srcType, sv)) {
+        // interleaved channels through the fp32 quad formulation: areas once per pair, applied to every channel
+        if (kernelName) *kernelName = "aai_quad_multi_kernel<area, channels>";
+        return launch_quad(r, m, src, srcType, sv, dst, dv, batch, flags.count ? flags.masks : nullptr, stream);
+    } else if (r.chan > 1) {
         // interleaved channels: the same kernels with the areas shared between the channels
         if (r.mode == AAI_MODE_AREA && r.runs) {
             if (kernelName) *kernelName = "aai_rotated_runs_kernel<area, channels>";
@@ -382,7 +386,7 @@ static hipError_t launch_rotated_typed(const RotLaunch &r, const QuadMap &m, con
     // pass on the same stream -- or, when the production kernel is the quad kernel and skips those pixels, beside it on
     // the plan's side stream: fork before, join after.
     const bool fixup = !sampler && flags.count != 0;
-    const bool beside = fixup && flags.masks && flags.side && r.mode == AAI_MODE_AREA && r.chan == 1 && r.quad && rot_tune().quad != 0 &&
+    const bool beside = fixup && flags.masks && flags.side && r.mode == AAI_MODE_AREA && r.quad && rot_tune().quad != 0 &&
                         quad_can_address(r, srcType, sv);
     hipError_t e = hipSuccess;
     if (beside) {

@@ -25,6 +25,19 @@ namespace aai {
 namespace {
 
 constexpr int kQuadBlock = 256;      // 16 x 16 dst pixels, the tiling of the scans
+constexpr int kQuadMaxChan = 4;
+
+// the `chan` (2..4) interleaved fp32 channels of one pixel in ONE load instruction (element-aligned)
+__device__ __forceinline__ void load_channels(const float *p, int chan, float (&v)[kQuadMaxChan])
+{
+    typedef float f2u __attribute__((ext_vector_type(2), aligned(4)));
+    typedef float f3u __attribute__((ext_vector_type(3), aligned(4)));
+    typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+    v[2] = 0.f; v[3] = 0.f;
+    if (chan == 3) { const f3u q = *reinterpret_cast<const f3u *>(p); v[0] = q.x; v[1] = q.y; v[2] = q.z; }
+    else if (chan == 4) { const f4u q = *reinterpret_cast<const f4u *>(p); v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w; }
+    else { const f2u q = *reinterpret_cast<const f2u *>(p); v[0] = q.x; v[1] = q.y; }
+}
 
 // The staged window of one lane.  Offsets are unsigned bytes from the image's first element (QuadMap: non-negative
 // strides), one table per axis; positions outside the lattice are clamped onto it -- their values are fetched but
@@ -76,13 +89,89 @@ struct QuadSrc {
 #pragma unroll
         for (int k = 0; k < WIN * WIN; ++k) lds[k][tid] = (float)v[k];
     }
-    __device__ __forceinline__ float at(int slot) const { return lds[slot][tid]; }
+    __device__ __forceinline__ void at(int slot, float (&vals)[1]) const { vals[0] = lds[slot][tid]; }
 };
 
 struct NoSrc {
     __device__ __forceinline__ void issue(int, int, unsigned long long) {}
     __device__ __forceinline__ void commit() {}
-    __device__ __forceinline__ float at(int) const { return 1.f; }
+    __device__ __forceinline__ void at(int, float (&vals)[1]) const { vals[0] = 1.f; }
+};
+
+// Interleaved channels (2..4 per pixel): the same window, every slot holding all channels of its pixel -- as raw
+// words, so that 8-bit RGB(A) costs one LDS word per slot like a plain image (16-bit: one or two, fp32: one per
+// channel).  The window is fetched slot by slot when the classification is done (no loads in flight across it: with
+// several words per slot they would not fit the register budget).
+template <typename T, int WIN, bool SCALED>
+struct QuadSrcMulti {
+    const char *img;
+    const QuadMap *m;
+    int mW, mH, chan, words;         // words = LDS words per slot
+    unsigned *lds;                   // [WIN * WIN * words][kQuadBlock]
+    int tid;
+    unsigned colOff[WIN], rowOff[WIN];
+
+    __device__ __forceinline__ void issue(int xg0, int yg0, unsigned long long)
+    {
+        const unsigned sxb = (unsigned)m->strideX * (unsigned)sizeof(T), syb = (unsigned)m->strideY * (unsigned)sizeof(T);
+        int qx0 = 0, qy0 = 0;
+        float remX = 0.f, remY = 0.f;
+        if (SCALED) {
+            const int scale = m->scale;
+            const int tx = xg0 + 8 * scale, ty = yg0 + 8 * scale;
+            qx0 = (int)(((double)tx + 0.5) * m->invScaleD); qy0 = (int)(((double)ty + 0.5) * m->invScaleD);
+            remX = (float)(tx - qx0 * scale) + 0.5f; remY = (float)(ty - qy0 * scale) + 0.5f;
+        }
+#pragma unroll
+        for (int i = 0; i < WIN; ++i) {
+            int qx = min(max(xg0 + i, 0), mW - 1), qy = min(max(yg0 + i, 0), mH - 1);
+            if (SCALED) {
+                qx = qx0 - 8 + (int)((remX + (float)(qx - xg0)) * m->invScale);
+                qy = qy0 - 8 + (int)((remY + (float)(qy - yg0)) * m->invScale);
+            }
+            colOff[i] = (unsigned)(m->flipX ? m->nX - 1 - qx : qx) * sxb;
+            rowOff[i] = (unsigned)(m->flipY ? m->nY - 1 - qy : qy) * syb;
+        }
+    }
+    __device__ __forceinline__ void commit()
+    {
+#pragma unroll
+        for (int j = 0; j < WIN; ++j)
+#pragma unroll
+            for (int i = 0; i < WIN; ++i) {
+                const T *p = reinterpret_cast<const T *>(img + (colOff[i] + rowOff[j]));
+                unsigned w[4] = {0u, 0u, 0u, 0u};
+                if (sizeof(T) == 4) {
+                    float v[kQuadMaxChan];
+                    load_channels(reinterpret_cast<const float *>(p), chan, v);
+#pragma unroll
+                    for (int c = 0; c < kQuadMaxChan; ++c) w[c] = __float_as_uint(v[c]);
+                } else if (sizeof(T) == 2) {
+                    w[0] = (unsigned)p[0] | ((unsigned)p[1] << 16);
+                    if (chan > 2) w[1] = (unsigned)p[2] | ((chan > 3 ? (unsigned)p[3] : 0u) << 16);
+                } else {
+                    w[0] = (unsigned)p[0] | ((unsigned)p[1] << 8) | ((chan > 2 ? (unsigned)p[2] : 0u) << 16) | ((chan > 3 ? (unsigned)p[3] : 0u) << 24);
+                }
+                unsigned *slot = lds + (size_t)((j * WIN + i) * words) * kQuadBlock + tid;
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (k < words) slot[(size_t)k * kQuadBlock] = w[k];
+            }
+    }
+    __device__ __forceinline__ void at(int slot, float (&vals)[kQuadMaxChan]) const
+    {
+        const unsigned *p = lds + (size_t)(slot * words) * kQuadBlock + tid;
+        if (sizeof(T) == 4) {
+#pragma unroll
+            for (int c = 0; c < kQuadMaxChan; ++c) vals[c] = c < chan ? __uint_as_float(p[(size_t)c * kQuadBlock]) : 0.f;
+        } else if (sizeof(T) == 2) {
+            const unsigned w0 = p[0], w1 = words > 1 ? p[kQuadBlock] : 0u;
+            vals[0] = (float)(w0 & 65535u); vals[1] = (float)(w0 >> 16); vals[2] = (float)(w1 & 65535u); vals[3] = (float)(w1 >> 16);
+        } else {
+            const unsigned w0 = p[0];
+            vals[0] = (float)(w0 & 255u); vals[1] = (float)((w0 >> 8) & 255u); vals[2] = (float)((w0 >> 16) & 255u); vals[3] = (float)(w0 >> 24);
+        }
+    }
 };
 
 // waves per SIMD that the staged windows leave room for (160 KiB of LDS per CU, WIN * WIN KiB per 256-lane block):
@@ -116,11 +205,50 @@ __global__ __launch_bounds__(kQuadBlock, quad_waves_per_simd(WIN) - (HP && quad_
         QuadSrc<T, WIN, SCALED> s;
         s.img = reinterpret_cast<const char *>(src + (int64_t)blockIdx.z * sv.imageStride + m.base);
         s.m = &m; s.mW = r.mW; s.mH = r.mH; s.lds = window; s.tid = tid;
-        float sumA, sumVA;
-        quad_pixel<float, WIN, false, HP>(q, (int)cx, (int)cy, px - cx, py - cy, r.mW, r.mH, s, sumA, sumVA);
-        value = sumA > 0.f ? sumVA / sumA : 0.f;                      // Source.cpp:577
+        float sumA, sumVA[1];
+        quad_pixel<float, WIN, false, HP, 1>(q, (int)cx, (int)cy, px - cx, py - cy, r.mW, r.mH, s, sumA, sumVA);
+        value = sumA > 0.f ? sumVA[0] / sumA : 0.f;                   // Source.cpp:577
     }
     *out = value;
+}
+
+// Interleaved channels: areas once per (dst, src) pair, applied to every channel (four accumulators).  Dynamic LDS:
+// WIN * WIN * words KiB per block.
+template <typename T, int WIN, bool SCALED>
+__global__ __launch_bounds__(kQuadBlock, 2) void aai_quad_multi_kernel(RotLaunch r, QuadConsts<float> q, QuadMap m, const T *__restrict__ src,
+                                                                      ImageView sv, float *__restrict__ dst, ImageView dv,
+                                                                      const unsigned long long *__restrict__ skipMasks, int words)
+{
+    extern __shared__ unsigned windowWords[];
+    const int tid = threadIdx.x;
+    const int dx = blockIdx.x * 16 + (tid & 15);
+    const int dy = r.dyBase + blockIdx.y * 16 + (tid >> 4);
+    if (!(dx < r.dW && dy < r.dyEnd)) return;
+    if (skipMasks) {
+        const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+        const unsigned long long mask = skipMasks[((size_t)(blockIdx.y + r.dyBase / 16) * gridDim.x + blockIdx.x) * (kQuadBlock / 64) + wave];
+        if ((mask >> (tid & 63)) & 1ull) return;
+    }
+    const int chan = r.chan;
+    float *out = dst + (int64_t)blockIdx.z * dv.imageStride + (int64_t)(dy - r.dyBase) * dv.rowStride + (int64_t)dx * chan;
+
+    double px, py;
+    pixel_centre(r, dx, dy, px, py);
+    const double cx = floor(px + 0.5), cy = floor(py + 0.5);
+    float value[kQuadMaxChan] = {0.f, 0.f, 0.f, 0.f};
+    if (cx > -16.0 && cx < (double)r.mW + 16.0 && cy > -16.0 && cy < (double)r.mH + 16.0) {
+        QuadSrcMulti<T, WIN, SCALED> s;
+        s.img = reinterpret_cast<const char *>(src + (int64_t)blockIdx.z * sv.imageStride + m.base);
+        s.m = &m; s.mW = r.mW; s.mH = r.mH; s.chan = chan; s.words = words; s.lds = windowWords; s.tid = tid;
+        float sumA, sumVA[kQuadMaxChan];
+        if (q.hiPrec) quad_pixel<float, WIN, false, true, kQuadMaxChan>(q, (int)cx, (int)cy, px - cx, py - cy, r.mW, r.mH, s, sumA, sumVA);
+        else quad_pixel<float, WIN, false, false, kQuadMaxChan>(q, (int)cx, (int)cy, px - cx, py - cy, r.mW, r.mH, s, sumA, sumVA);
+#pragma unroll
+        for (int c = 0; c < kQuadMaxChan; ++c) value[c] = sumA > 0.f ? sumVA[c] / sumA : 0.f;      // Source.cpp:577
+    }
+#pragma unroll
+    for (int c = 0; c < kQuadMaxChan; ++c)
+        if (c < chan) out[c] = value[c];
 }
 
 // Once per geometry: the same arithmetic without pixel loads.  Flags one bit per dst pixel in the 64-bit word of its
@@ -141,8 +269,8 @@ __global__ __launch_bounds__(kQuadBlock) void aai_quad_scan_kernel(RotLaunch r, 
         const double cx = floor(px + 0.5), cy = floor(py + 0.5);
         if (cx > -16.0 && cx < (double)r.mW + 16.0 && cy > -16.0 && cy < (double)r.mH + 16.0) {
             NoSrc s;
-            float sumA, sumVA;
-            uncertain = quad_pixel<float, WIN, true, HP>(q, (int)cx, (int)cy, px - cx, py - cy, r.mW, r.mH, s, sumA, sumVA);
+            float sumA, sumVA[1];
+            uncertain = quad_pixel<float, WIN, true, HP, 1>(q, (int)cx, (int)cy, px - cx, py - cy, r.mW, r.mH, s, sumA, sumVA);
         }
     }
     const unsigned long long any = __ballot(uncertain);
@@ -188,11 +316,43 @@ hipError_t launch_quad_win(const RotLaunch &r, const QuadConsts<float> &q, const
     return hipGetLastError();
 }
 
+// LDS words one window slot takes with `chan` interleaved channels of T
+template <typename T> int quad_slot_words(int chan) { return sizeof(T) == 4 ? chan : (sizeof(T) == 2 ? (chan + 1) / 2 : 1); }
+
+template <typename T, int WIN>
+hipError_t launch_quad_multi_win(const RotLaunch &r, const QuadConsts<float> &q, const QuadMap &m, const T *src, ImageView sv, float *dst, ImageView dv,
+                                 int batch, const unsigned long long *skipMasks, hipStream_t stream)
+{
+    const dim3 grid((r.dW + 15) / 16, (r.dyEnd - r.dyBase + 15) / 16, batch);
+    const int words = quad_slot_words<T>(r.chan);
+    const size_t lds = (size_t)WIN * WIN * words * kQuadBlock * sizeof(unsigned);
+    if (m.scale > 1) {
+        static const hipError_t once = hipFuncSetAttribute(reinterpret_cast<const void *>(&aai_quad_multi_kernel<T, WIN, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)once;
+        hipLaunchKernelGGL((aai_quad_multi_kernel<T, WIN, true>), grid, dim3(kQuadBlock), lds, stream, r, q, m, src, sv, dst, dv, skipMasks, words);
+    } else {
+        static const hipError_t once = hipFuncSetAttribute(reinterpret_cast<const void *>(&aai_quad_multi_kernel<T, WIN, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)once;
+        hipLaunchKernelGGL((aai_quad_multi_kernel<T, WIN, false>), grid, dim3(kQuadBlock), lds, stream, r, q, m, src, sv, dst, dv, skipMasks, words);
+    }
+    return hipGetLastError();
+}
+
 template <typename T>
 hipError_t launch_quad_typed(const RotLaunch &r, const QuadMap &m, const T *src, ImageView sv, float *dst, ImageView dv, int batch,
                              const unsigned long long *skipMasks, hipStream_t stream)
 {
     const QuadConsts<float> q = make_quad_consts<float>(r.side, r.c, r.s, r.policy);
+    if (r.chan > 1) {
+        switch (q.win) {
+        case 3: return launch_quad_multi_win<T, 3>(r, q, m, src, sv, dst, dv, batch, skipMasks, stream);
+        case 4: return launch_quad_multi_win<T, 4>(r, q, m, src, sv, dst, dv, batch, skipMasks, stream);
+        case 5: return launch_quad_multi_win<T, 5>(r, q, m, src, sv, dst, dv, batch, skipMasks, stream);
+        case 6: return launch_quad_multi_win<T, 6>(r, q, m, src, sv, dst, dv, batch, skipMasks, stream);
+        case 7: return launch_quad_multi_win<T, 7>(r, q, m, src, sv, dst, dv, batch, skipMasks, stream);
+        default: return launch_quad_multi_win<T, 8>(r, q, m, src, sv, dst, dv, batch, skipMasks, stream);
+        }
+    }
     switch (q.win) {
     case 3: return launch_quad_win<T, 3>(r, q, m, src, sv, dst, dv, batch, skipMasks, stream);
     case 4: return launch_quad_win<T, 4>(r, q, m, src, sv, dst, dv, batch, skipMasks, stream);
@@ -209,7 +369,15 @@ bool quad_can_address(const RotLaunch &r, int srcType, ImageView sv)
 {
     // lanes address their pixels with unsigned 32-bit byte offsets from the image's first element
     const int64_t esz = srcType == SRC_U8 ? 1 : srcType == SRC_U16 ? 2 : 4;
-    return (int64_t)r.H * sv.rowStride * esz < ((int64_t)1 << 32);
+    if ((int64_t)r.H * sv.rowStride * esz >= ((int64_t)1 << 32)) return false;
+    if (r.chan > 1) {
+        // interleaved channels: the staged window (win^2 slots of `words` LDS words per lane) must leave room for two
+        // workgroups per CU
+        const int win = (int)floor(2.0 * (r.h * (r.c + r.s) - 0.5 + 1e-5)) + 3;
+        const int words = esz == 4 ? r.chan : (esz == 2 ? (r.chan + 1) / 2 : 1);
+        if (win * win * words > 80) return false;
+    }
+    return true;
 }
 
 hipError_t launch_quad(const RotLaunch &r, const QuadMap &m, const void *src, int srcType, ImageView sv, float *dst, ImageView dv,

@@ -251,7 +251,7 @@ struct EmuQuadSrc {
                 v[j * WIN + i] = ((valid >> (j * WIN + i)) & 1) ? img[virt_offset(*r, xg0 + i, yg0 + j, stride)] : -1e30f;   // poison: must never be read
     }
     void commit() {}
-    float at(int slot) const { return v[slot]; }
+    void at(int slot, float (&vals)[1]) const { vals[0] = v[slot]; }
 };
 
 template <int WIN>
@@ -262,15 +262,15 @@ static bool emu_quad_pixel(const QuadConsts<float> &qc, const RotLaunch &r, cons
     const int Xc = (int)cxr, Yc = (int)cyr;
     const double fpx = px - cxr, fpy = py - cyr;
     EmuQuadSrc<WIN> qs{&r, img, stride, {}};
-    float sA, sVA;
+    float sA, sVA[1];
     if (qc.hiPrec) {
-        if (quad_pixel<float, WIN, true, true>(qc, Xc, Yc, fpx, fpy, r.mW, r.mH, qs, sA, sVA)) return false;      // the scan leaves it to double precision
-        quad_pixel<float, WIN, false, true>(qc, Xc, Yc, fpx, fpy, r.mW, r.mH, qs, sA, sVA);
+        if (quad_pixel<float, WIN, true, true, 1>(qc, Xc, Yc, fpx, fpy, r.mW, r.mH, qs, sA, sVA)) return false;      // the scan leaves it to double precision
+        quad_pixel<float, WIN, false, true, 1>(qc, Xc, Yc, fpx, fpy, r.mW, r.mH, qs, sA, sVA);
     } else {
-        if (quad_pixel<float, WIN, true, false>(qc, Xc, Yc, fpx, fpy, r.mW, r.mH, qs, sA, sVA)) return false;
-        quad_pixel<float, WIN, false, false>(qc, Xc, Yc, fpx, fpy, r.mW, r.mH, qs, sA, sVA);
+        if (quad_pixel<float, WIN, true, false, 1>(qc, Xc, Yc, fpx, fpy, r.mW, r.mH, qs, sA, sVA)) return false;
+        quad_pixel<float, WIN, false, false, 1>(qc, Xc, Yc, fpx, fpy, r.mW, r.mH, qs, sA, sVA);
     }
-    value = sA > 0.f ? sVA / sA : 0.f;
+    value = sA > 0.f ? sVA[0] / sA : 0.f;
     return true;
 }
 
@@ -434,28 +434,28 @@ static void emu_quad_sums(const RotLaunch &r, const float *img, double px, doubl
         const RotLaunch *r; const float *img; int64_t stride; float v[WIN * WIN];
         void issue(int xg0, int yg0, unsigned long long valid) { for (int j = 0; j < WIN; ++j) for (int i = 0; i < WIN; ++i) v[j * WIN + i] = ((valid >> (j * WIN + i)) & 1) ? img[virt_offset(*r, xg0 + i, yg0 + j, stride)] : 0.f; }
         void commit() {}
-        float at(int slot) const { return v[slot]; }
+        void at(int slot, F (&vals)[1]) const { vals[0] = (F)v[slot]; }
     } qs{&r, img, r.W, {}};
     const QuadConsts<F> q = make_quad_consts<F>(r.side, r.c, r.s, r.policy);
     const double cxr = std::floor(px + 0.5), cyr = std::floor(py + 0.5);
-    F a, va;
-    if (q.hiPrec) quad_pixel<F, WIN, false, true>(q, (int)cxr, (int)cyr, px - cxr, py - cyr, r.mW, r.mH, qs, a, va);
-    else quad_pixel<F, WIN, false, false>(q, (int)cxr, (int)cyr, px - cxr, py - cyr, r.mW, r.mH, qs, a, va);
-    *sumA = a; *sumVA = va;
+    F a, va[1];
+    if (q.hiPrec) quad_pixel<F, WIN, false, true, 1>(q, (int)cxr, (int)cyr, px - cxr, py - cyr, r.mW, r.mH, qs, a, va);
+    else quad_pixel<F, WIN, false, false, 1>(q, (int)cxr, (int)cyr, px - cxr, py - cyr, r.mW, r.mH, qs, a, va);
+    *sumA = a; *sumVA = va[0];
 }
 // per-slot areas of one dst pixel: the value source is 1 at one slot and 0 elsewhere
 template <typename F, int WIN>
 static void emu_quad_slot_areas(const RotLaunch &r, double px, double py, double *areas)
 {
-    struct Src { int hot; void issue(int, int, unsigned long long) {} void commit() {} float at(int slot) const { return slot == hot ? 1.f : 0.f; } };
+    struct Src { int hot; void issue(int, int, unsigned long long) {} void commit() {} void at(int slot, F (&vals)[1]) const { vals[0] = slot == hot ? F(1) : F(0); } };
     const QuadConsts<F> q = make_quad_consts<F>(r.side, r.c, r.s, r.policy);
     const double cxr = std::floor(px + 0.5), cyr = std::floor(py + 0.5);
     for (int k = 0; k < WIN * WIN; ++k) {
         Src qs{k};
-        F a, va;
-        if (q.hiPrec) quad_pixel<F, WIN, false, true>(q, (int)cxr, (int)cyr, px - cxr, py - cyr, r.mW, r.mH, qs, a, va);
-    else quad_pixel<F, WIN, false, false>(q, (int)cxr, (int)cyr, px - cxr, py - cyr, r.mW, r.mH, qs, a, va);
-        areas[k] = va;
+        F a, va[1];
+        if (q.hiPrec) quad_pixel<F, WIN, false, true, 1>(q, (int)cxr, (int)cyr, px - cxr, py - cyr, r.mW, r.mH, qs, a, va);
+        else quad_pixel<F, WIN, false, false, 1>(q, (int)cxr, (int)cyr, px - cxr, py - cyr, r.mW, r.mH, qs, a, va);
+        areas[k] = va[0];
     }
 }
 extern "C" {

@@ -516,6 +516,7 @@ def test_interleaved_channels_equal_planar_calls(gpu, po):
     area / fast kernels (incl. a knife-edge angle and the large-footprint regime), the samplers, 8-/16-bit sources --
     and one case is checked against the oracle directly."""
     rng = np.random.default_rng(41)
+    kernels = set()
     cases = [  # W, H, srcRes, dstRes, angle, mode
         (517, 40, 4, 1, 0.0, 1), (517, 40, 4, 1, 180.0, 1), (300, 33, 3, 1, 90.0, 1), (301, 21, 2, 1, 270.0, 2),
         (259, 17, 1, 1, 0.0, 1), (70, 50, 1, 2, 90.0, 1), (40, 30, 1, 4, 180.0, 1), (1030, 9, 8, 1, 0.0, 2),
@@ -534,6 +535,8 @@ def test_interleaved_channels_equal_planar_calls(gpu, po):
         rc, msg, dst, lay = gpu.resample_interleaved_host(src, sr, dr, iso, ang, mode=mode)
         assert rc == 0, (k, msg)
         assert dst.shape == (lay.dst_height, lay.dst_width, C)
+        kern_interleaved = gpu.last_kernel()
+        kernels.add(kern_interleaved)
         for c in range(C):
             rc, msg, planar, giso, _ = gpu.resample_host(np.ascontiguousarray(src[:, :, c]), sr, dr, iso, ang, mode=mode)
             assert rc == 0, msg
@@ -541,13 +544,14 @@ def test_interleaved_channels_equal_planar_calls(gpu, po):
                 # the planar image is too narrow for the strip kernel (per-pixel fallback), the interleaved one is not:
                 # same weights, different summation order
                 assert rel_err(dst[:, :, c], planar, floor=1e-3 * float(src.max())).max() <= 1e-6, (k, c)
-            elif "aai_quad_kernel" in gpu.last_kernel():
-                # the planar call takes the fp32 quad formulation, the interleaved one the double-precision per-pixel
-                # kernel (areas shared between the channels): same areas to ~1e-7
+            elif ("aai_quad" in gpu.last_kernel()) != ("aai_quad" in kern_interleaved):
+                # one of the two calls takes the fp32 quad formulation, the other a double-precision kernel (an interleaved
+                # window too large to stage: areas shared between the channels in fp64): same areas to ~1e-7
                 assert rel_err(dst[:, :, c], planar, floor=1e-3 * float(src.max())).max() <= 2e-6, (k, c)
                 assert np.array_equal(dst[:, :, c] == 0, planar == 0), (k, c)
             else:
                 assert np.array_equal(dst[:, :, c], planar), (k, W, H, sr, dr, ang, mode, C, c, dt, gpu.last_kernel())
+    assert any("aai_quad_multi_kernel" in k for k in kernels), kernels
     # against the oracle itself
     src = rng.random((90, 120, 3)).astype(np.float32)
     rc, msg, dst, lay = gpu.resample_interleaved_host(src, 3.0, 1.0, (59.5, 44.5), 17.5)
@@ -691,3 +695,28 @@ def test_pinned_array_views_outlive_close(gpu):
     assert p.array is None and float(view.sum()) == 3.5 * 10 * 64
     del view
     gc.collect()
+
+
+def test_quad_kernel_equals_its_cpu_replay_bit_for_bit(gpu, hostemu, po):
+    """The fp32 quad kernel spells out its fused multiply-adds and is compiled without contraction, and so is the CPU
+    replay of the same header (tests/emulation/host_emulation.cpp): outside the pixels the scans hand to the
+    double-precision pass both execute the same IEEE operations, so the GPU's output equals the replay's bit for bit --
+    which makes the CPU suite's golden-vector checks of the replay checks of the device arithmetic itself."""
+    rng = np.random.default_rng(77)
+    hostemu.aai_emu_use_quad(1)
+    try:
+        for (W, H, sr, dr, ang, policy) in ((200, 160, 8192.0, 2731.0, 17.5, 0), (96, 96, 1.0, 4.0, 45.0, 0), (180, 140, 4.0, 1.0, 0.5, 0),
+                                            (150, 150, 2.0, 1.0, 117.3, 1), (120, 90, 1.0, 1.0, 200.0, 0), (128, 128, 3.0, 2.0, 300.0, 0)):
+            iso = (float(rng.uniform(0, W)), float(rng.uniform(0, H)))
+            src = rng.random((H, W)).astype(np.float32)
+            rq = gpu.make_request(W, H, sr, dr, iso, ang, mode=1, policy=policy)
+            ref, axis = hostemu.resample(rq, src)
+            quad, flagged = hostemu.quad_stats()
+            rc, msg, dst, _, lay = gpu.resample_host(src, sr, dr, iso, ang, mode=1, policy=policy)
+            assert rc == 0 and "aai_quad_kernel" in gpu.last_kernel(), (msg, gpu.last_kernel())
+            differ = int((dst != ref).sum())
+            # flagged pixels go through the double-precision kernels, whose summation order differs from the replay's
+            assert differ <= flagged, (W, H, sr, dr, ang, differ, flagged, quad)
+            assert rel_err(dst, ref).max() <= 3e-7
+    finally:
+        hostemu.aai_emu_use_quad(0)
