@@ -339,7 +339,7 @@ int enqueue(const aai_request &rq, int batch, const void *dSrc, int srcType, int
             r.dyBase = band0; r.dyEnd = band1; r.srcRow0 = srcRow0;
         }
         r.chan = channels;
-        const aai::QuadMap qm = aai::make_quad_map(g, srcStride, r.srcRow0, channels);
+        const aai::QuadMap qm = aai::make_quad_map(g, srcStride, r.srcRow0, channels, srcType == aai::SRC_U8 ? 1 : srcType == aai::SRC_U16 ? 2 : 4);
         aai::RotFlags flags;
         flags.list = p->dList; flags.count = p->flaggedPixels; flags.dense = p->dense;
         flags.masks = p->dMasks; flags.side = p->side; flags.fork = p->fork; flags.join = p->join;

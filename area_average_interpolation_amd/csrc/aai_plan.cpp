@@ -172,7 +172,7 @@ RotLaunch make_rot_launch(const Geometry &g, int mode, int policy)
     return r;
 }
 
-QuadMap make_quad_map(const Geometry &g, int64_t rowStride, int srcRow0, int channels)
+QuadMap make_quad_map(const Geometry &g, int64_t rowStride, int srcRow0, int channels, int elementBytes)
 {
     QuadMap m{};
     m.nX = g.mW / g.scale; m.nY = g.mH / g.scale;
@@ -187,6 +187,9 @@ QuadMap make_quad_map(const Geometry &g, int64_t rowStride, int srcRow0, int cha
     m.scale = g.scale;
     m.invScale = (float)(1.0 / g.scale);
     m.invScaleD = 1.0 / g.scale;
+    const int64_t bytes = ((int64_t)(g.H - 1) * rowStride + (int64_t)g.W * channels) * elementBytes;      // of the whole image
+    m.lastLoad4 = (uint32_t)std::max<int64_t>(0, std::min<int64_t>(bytes - 4, 0xffffffffll));
+    m.lastLoad8 = (uint32_t)std::max<int64_t>(0, std::min<int64_t>(bytes - 8, 0xffffffffll));
     return m;
 }
 

@@ -67,8 +67,11 @@ struct QuadMap {
     int scale;
     float invScale;
     double invScaleD;
+    // interleaved 8- / 16-bit pixels are fetched with one 4- / 8-byte load each, which may reach past the pixel: loads start
+    // no later than lastLoad4 / lastLoad8 (byte offsets of the last 4 / 8 bytes of the image) and shift the rest away
+    uint32_t lastLoad4, lastLoad8;
 };
-QuadMap make_quad_map(const Geometry &g, int64_t rowStride, int srcRow0, int channels = 1);      // channels: elements per pixel (interleaved)
+QuadMap make_quad_map(const Geometry &g, int64_t rowStride, int srcRow0, int channels = 1, int elementBytes = 4);      // channels: elements per pixel (interleaved)
 
 // ---- K1: separable axis-aligned tables ---------------------------------------------------------------
 // One entry per output index along one axis: the source window [s0,s1] along the matching SOURCE axis

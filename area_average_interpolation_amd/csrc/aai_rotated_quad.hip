@@ -98,21 +98,21 @@ struct NoSrc {
     __device__ __forceinline__ void at(int, float (&vals)[1]) const { vals[0] = 1.f; }
 };
 
-// Interleaved channels (2..4 per pixel): the same window, every slot holding all channels of its pixel -- as raw
+// Interleaved channels (2..4 per pixel): the same window, every slot holding all channels of its pixel -- as WORDS raw
 // words, so that 8-bit RGB(A) costs one LDS word per slot like a plain image (16-bit: one or two, fp32: one per
-// channel).  The window is fetched slot by slot when the classification is done (no loads in flight across it: with
-// several words per slot they would not fit the register budget).
-template <typename T, int WIN, bool SCALED>
+// channel).  Like the plain window it is fetched up front into registers and parked in LDS after the classification.
+template <typename T, int WIN, bool SCALED, int WORDS>
 struct QuadSrcMulti {
     const char *img;
     const QuadMap *m;
-    int mW, mH, chan, words;         // words = LDS words per slot
-    unsigned *lds;                   // [WIN * WIN * words][kQuadBlock]
+    int mW, mH, chan;
+    unsigned *lds;                   // [WIN * WIN * WORDS][kQuadBlock]
     int tid;
-    unsigned colOff[WIN], rowOff[WIN];
+    unsigned v[WIN * WIN * WORDS];
 
     __device__ __forceinline__ void issue(int xg0, int yg0, unsigned long long)
     {
+        unsigned colOff[WIN], rowOff[WIN];
         const unsigned sxb = (unsigned)m->strideX * (unsigned)sizeof(T), syb = (unsigned)m->strideY * (unsigned)sizeof(T);
         int qx0 = 0, qy0 = 0;
         float remX = 0.f, remY = 0.f;
@@ -132,40 +132,57 @@ struct QuadSrcMulti {
             colOff[i] = (unsigned)(m->flipX ? m->nX - 1 - qx : qx) * sxb;
             rowOff[i] = (unsigned)(m->flipY ? m->nY - 1 - qy : qy) * syb;
         }
-    }
-    __device__ __forceinline__ void commit()
-    {
 #pragma unroll
         for (int j = 0; j < WIN; ++j)
 #pragma unroll
             for (int i = 0; i < WIN; ++i) {
                 const T *p = reinterpret_cast<const T *>(img + (colOff[i] + rowOff[j]));
-                unsigned w[4] = {0u, 0u, 0u, 0u};
+                unsigned *w = v + (j * WIN + i) * WORDS;
                 if (sizeof(T) == 4) {
-                    float v[kQuadMaxChan];
-                    load_channels(reinterpret_cast<const float *>(p), chan, v);
+                    float f[kQuadMaxChan];
+                    load_channels(reinterpret_cast<const float *>(p), chan, f);
 #pragma unroll
-                    for (int c = 0; c < kQuadMaxChan; ++c) w[c] = __float_as_uint(v[c]);
+                    for (int c = 0; c < WORDS; ++c) w[c] = __float_as_uint(f[c]);
                 } else if (sizeof(T) == 2) {
-                    w[0] = (unsigned)p[0] | ((unsigned)p[1] << 16);
-                    if (chan > 2) w[1] = (unsigned)p[2] | ((chan > 3 ? (unsigned)p[3] : 0u) << 16);
+                    // 2..4 sixteen-bit channels = 4..8 bytes: ONE load (the number of load instructions, each touching ~64
+                    // cache lines, is what bounds these kernels), started early enough to stay inside the image
+                    typedef unsigned u1w __attribute__((aligned(2)));
+                    typedef unsigned u2w __attribute__((ext_vector_type(2), aligned(2)));
+                    const unsigned want = colOff[i] + rowOff[j];
+                    if (WORDS == 1) w[0] = *reinterpret_cast<const u1w *>(img + want);
+                    else {
+                        const unsigned from = min(want, m->lastLoad8);
+                        const u2w q2 = *reinterpret_cast<const u2w *>(img + from);
+                        const unsigned long long both = (((unsigned long long)q2.y << 32) | q2.x) >> (8u * (want - from));
+                        w[0] = (unsigned)both;
+                        w[WORDS - 1] = chan > 3 ? (unsigned)(both >> 32) : (unsigned)(both >> 32) & 65535u;
+                    }
                 } else {
-                    w[0] = (unsigned)p[0] | ((unsigned)p[1] << 8) | ((chan > 2 ? (unsigned)p[2] : 0u) << 16) | ((chan > 3 ? (unsigned)p[3] : 0u) << 24);
+                    typedef unsigned u1b __attribute__((aligned(1)));
+                    typedef unsigned short u1s __attribute__((aligned(1)));
+                    const unsigned want = colOff[i] + rowOff[j];
+                    if (chan == 2) w[0] = *reinterpret_cast<const u1s *>(img + want);
+                    else {
+                        const unsigned from = min(want, m->lastLoad4);
+                        const unsigned q1 = *reinterpret_cast<const u1b *>(img + from) >> (8u * (want - from));
+                        w[0] = chan > 3 ? q1 : q1 & 0xffffffu;
+                    }
                 }
-                unsigned *slot = lds + (size_t)((j * WIN + i) * words) * kQuadBlock + tid;
-#pragma unroll
-                for (int k = 0; k < 4; ++k)
-                    if (k < words) slot[(size_t)k * kQuadBlock] = w[k];
             }
+    }
+    __device__ __forceinline__ void commit()
+    {
+#pragma unroll
+        for (int k = 0; k < WIN * WIN * WORDS; ++k) lds[(size_t)k * kQuadBlock + tid] = v[k];
     }
     __device__ __forceinline__ void at(int slot, float (&vals)[kQuadMaxChan]) const
     {
-        const unsigned *p = lds + (size_t)(slot * words) * kQuadBlock + tid;
+        const unsigned *p = lds + (size_t)(slot * WORDS) * kQuadBlock + tid;
         if (sizeof(T) == 4) {
 #pragma unroll
-            for (int c = 0; c < kQuadMaxChan; ++c) vals[c] = c < chan ? __uint_as_float(p[(size_t)c * kQuadBlock]) : 0.f;
+            for (int c = 0; c < kQuadMaxChan; ++c) vals[c] = c < WORDS ? __uint_as_float(p[(size_t)c * kQuadBlock]) : 0.f;
         } else if (sizeof(T) == 2) {
-            const unsigned w0 = p[0], w1 = words > 1 ? p[kQuadBlock] : 0u;
+            const unsigned w0 = p[0], w1 = WORDS > 1 ? p[kQuadBlock] : 0u;
             vals[0] = (float)(w0 & 65535u); vals[1] = (float)(w0 >> 16); vals[2] = (float)(w1 & 65535u); vals[3] = (float)(w1 >> 16);
         } else {
             const unsigned w0 = p[0];
@@ -214,10 +231,10 @@ __global__ __launch_bounds__(kQuadBlock, quad_waves_per_simd(WIN) - (HP && quad_
 
 // Interleaved channels: areas once per (dst, src) pair, applied to every channel (four accumulators).  Dynamic LDS:
 // WIN * WIN * words KiB per block.
-template <typename T, int WIN, bool SCALED>
-__global__ __launch_bounds__(kQuadBlock, 2) void aai_quad_multi_kernel(RotLaunch r, QuadConsts<float> q, QuadMap m, const T *__restrict__ src,
-                                                                      ImageView sv, float *__restrict__ dst, ImageView dv,
-                                                                      const unsigned long long *__restrict__ skipMasks, int words)
+template <typename T, int WIN, bool SCALED, int WORDS>
+__global__ __launch_bounds__(kQuadBlock, 160 / (WIN * WIN * WORDS) >= 6 ? 6 : (160 / (WIN * WIN * WORDS) >= 2 ? 160 / (WIN * WIN * WORDS) : 2))
+void aai_quad_multi_kernel(RotLaunch r, QuadConsts<float> q, QuadMap m, const T *__restrict__ src, ImageView sv, float *__restrict__ dst, ImageView dv,
+                           const unsigned long long *__restrict__ skipMasks)
 {
     extern __shared__ unsigned windowWords[];
     const int tid = threadIdx.x;
@@ -237,9 +254,9 @@ __global__ __launch_bounds__(kQuadBlock, 2) void aai_quad_multi_kernel(RotLaunch
     const double cx = floor(px + 0.5), cy = floor(py + 0.5);
     float value[kQuadMaxChan] = {0.f, 0.f, 0.f, 0.f};
     if (cx > -16.0 && cx < (double)r.mW + 16.0 && cy > -16.0 && cy < (double)r.mH + 16.0) {
-        QuadSrcMulti<T, WIN, SCALED> s;
+        QuadSrcMulti<T, WIN, SCALED, WORDS> s;
         s.img = reinterpret_cast<const char *>(src + (int64_t)blockIdx.z * sv.imageStride + m.base);
-        s.m = &m; s.mW = r.mW; s.mH = r.mH; s.chan = chan; s.words = words; s.lds = windowWords; s.tid = tid;
+        s.m = &m; s.mW = r.mW; s.mH = r.mH; s.chan = chan; s.lds = windowWords; s.tid = tid;
         float sumA, sumVA[kQuadMaxChan];
         if (q.hiPrec) quad_pixel<float, WIN, false, true, kQuadMaxChan>(q, (int)cx, (int)cy, px - cx, py - cy, r.mW, r.mH, s, sumA, sumVA);
         else quad_pixel<float, WIN, false, false, kQuadMaxChan>(q, (int)cx, (int)cy, px - cx, py - cy, r.mW, r.mH, s, sumA, sumVA);
@@ -319,23 +336,39 @@ hipError_t launch_quad_win(const RotLaunch &r, const QuadConsts<float> &q, const
 // LDS words one window slot takes with `chan` interleaved channels of T
 template <typename T> int quad_slot_words(int chan) { return sizeof(T) == 4 ? chan : (sizeof(T) == 2 ? (chan + 1) / 2 : 1); }
 
+template <typename T, int WIN, int WORDS>
+hipError_t launch_quad_multi_words(const RotLaunch &r, const QuadConsts<float> &q, const QuadMap &m, const T *src, ImageView sv, float *dst, ImageView dv,
+                                   int batch, const unsigned long long *skipMasks, hipStream_t stream)
+{
+    const dim3 grid((r.dW + 15) / 16, (r.dyEnd - r.dyBase + 15) / 16, batch);
+    const size_t lds = (size_t)WIN * WIN * WORDS * kQuadBlock * sizeof(unsigned);
+    if (m.scale > 1) {
+        static const hipError_t once = hipFuncSetAttribute(reinterpret_cast<const void *>(&aai_quad_multi_kernel<T, WIN, true, WORDS>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)once;
+        hipLaunchKernelGGL((aai_quad_multi_kernel<T, WIN, true, WORDS>), grid, dim3(kQuadBlock), lds, stream, r, q, m, src, sv, dst, dv, skipMasks);
+    } else {
+        static const hipError_t once = hipFuncSetAttribute(reinterpret_cast<const void *>(&aai_quad_multi_kernel<T, WIN, false, WORDS>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)once;
+        hipLaunchKernelGGL((aai_quad_multi_kernel<T, WIN, false, WORDS>), grid, dim3(kQuadBlock), lds, stream, r, q, m, src, sv, dst, dv, skipMasks);
+    }
+    return hipGetLastError();
+}
+
 template <typename T, int WIN>
 hipError_t launch_quad_multi_win(const RotLaunch &r, const QuadConsts<float> &q, const QuadMap &m, const T *src, ImageView sv, float *dst, ImageView dv,
                                  int batch, const unsigned long long *skipMasks, hipStream_t stream)
 {
-    const dim3 grid((r.dW + 15) / 16, (r.dyEnd - r.dyBase + 15) / 16, batch);
+    // quad_can_address() keeps WIN * WIN * words <= 80 KiB of LDS per block
     const int words = quad_slot_words<T>(r.chan);
-    const size_t lds = (size_t)WIN * WIN * words * kQuadBlock * sizeof(unsigned);
-    if (m.scale > 1) {
-        static const hipError_t once = hipFuncSetAttribute(reinterpret_cast<const void *>(&aai_quad_multi_kernel<T, WIN, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)once;
-        hipLaunchKernelGGL((aai_quad_multi_kernel<T, WIN, true>), grid, dim3(kQuadBlock), lds, stream, r, q, m, src, sv, dst, dv, skipMasks, words);
-    } else {
-        static const hipError_t once = hipFuncSetAttribute(reinterpret_cast<const void *>(&aai_quad_multi_kernel<T, WIN, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)once;
-        hipLaunchKernelGGL((aai_quad_multi_kernel<T, WIN, false>), grid, dim3(kQuadBlock), lds, stream, r, q, m, src, sv, dst, dv, skipMasks, words);
+    if (sizeof(T) == 1) return launch_quad_multi_words<T, WIN, 1>(r, q, m, src, sv, dst, dv, batch, skipMasks, stream);
+    if (sizeof(T) == 2) {
+        if (words == 1) return launch_quad_multi_words<T, WIN, 1>(r, q, m, src, sv, dst, dv, batch, skipMasks, stream);
+        return launch_quad_multi_words<T, WIN, (sizeof(T) == 2 ? 2 : 1)>(r, q, m, src, sv, dst, dv, batch, skipMasks, stream);
     }
-    return hipGetLastError();
+    if (WIN * WIN * words > 80) return hipErrorInvalidValue;
+    if (words == 2) return launch_quad_multi_words<T, WIN, (sizeof(T) == 4 && WIN * WIN * 2 <= 80 ? 2 : 1)>(r, q, m, src, sv, dst, dv, batch, skipMasks, stream);
+    if (words == 3) return launch_quad_multi_words<T, WIN, (sizeof(T) == 4 && WIN * WIN * 3 <= 80 ? 3 : 1)>(r, q, m, src, sv, dst, dv, batch, skipMasks, stream);
+    return launch_quad_multi_words<T, WIN, (sizeof(T) == 4 && WIN * WIN * 4 <= 80 ? 4 : 1)>(r, q, m, src, sv, dst, dv, batch, skipMasks, stream);
 }
 
 template <typename T>
