@@ -39,6 +39,21 @@ __device__ __forceinline__ void load_channels(const float *p, int chan, float (&
     else { const f2u q = *reinterpret_cast<const f2u *>(p); v[0] = q.x; v[1] = q.y; }
 }
 
+// N consecutive fp32 elements from an element-aligned address in as few load instructions as possible
+template <int N>
+__device__ __forceinline__ void load_line(const float *p, float (&seg)[N])
+{
+    typedef float f2u __attribute__((ext_vector_type(2), aligned(4)));
+    typedef float f3u __attribute__((ext_vector_type(3), aligned(4)));
+    typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+    int at = 0;
+    if (N >= 4) { const f4u q = *reinterpret_cast<const f4u *>(p); seg[0] = q.x; seg[1] = q.y; seg[2] = q.z; seg[3] = q.w; at = 4; }
+    if (N - at == 4) { const f4u q = *reinterpret_cast<const f4u *>(p + at); seg[at] = q.x; seg[at + 1] = q.y; seg[at + 2] = q.z; seg[at + 3] = q.w; }
+    else if (N - at == 3) { const f3u q = *reinterpret_cast<const f3u *>(p + at); seg[at] = q.x; seg[at + 1] = q.y; seg[at + 2] = q.z; }
+    else if (N - at == 2) { const f2u q = *reinterpret_cast<const f2u *>(p + at); seg[at] = q.x; seg[at + 1] = q.y; }
+    else if (N - at == 1) seg[at] = p[at];
+}
+
 // The staged window of one lane.  Offsets are unsigned bytes from the image's first element (QuadMap: non-negative
 // strides), one table per axis; positions outside the lattice are clamped onto it -- their values are fetched but
 // never read (quad_pixel only reads slots whose valid bit is set).
@@ -77,6 +92,28 @@ struct QuadSrc {
                 colOff[i] = (unsigned)(m->flipX ? m->nX - 1 - qx : qx) * sxb;
                 rowOff[i] = (unsigned)(m->flipY ? m->nY - 1 - qy : qy) * syb;
             }
+        }
+        // Without replication one axis of the window is contiguous in memory (virtual X along source x in quadrants 0 / 2,
+        // virtual Y in 1 / 3): fetch each of its WIN lines with one or two vector loads instead of WIN scalar ones -- lanes
+        // are L source pixels apart, so every load instruction touches a dozen cache lines and their NUMBER is what the
+        // texture path charges for.  Only where no lane of the wave has a clamped (off-image) column or row.
+        const bool inside = xg0 >= 0 && xg0 + WIN <= mW && yg0 >= 0 && yg0 + WIN <= mH;
+        if (!SCALED && sizeof(T) == 4 && __all(inside)) {
+            const bool alongX = sxb == (unsigned)sizeof(T);               // wave-uniform
+#pragma unroll
+            for (int k = 0; k < WIN; ++k) {
+                // line k: fixed row (alongX) or fixed column, its WIN elements ascending in memory from `first`
+                const unsigned first = alongX ? rowOff[k] + min(colOff[0], colOff[WIN - 1]) : colOff[k] + min(rowOff[0], rowOff[WIN - 1]);
+                const bool rev = alongX ? colOff[0] > colOff[WIN - 1] : rowOff[0] > rowOff[WIN - 1];
+                float seg[WIN];
+                load_line<WIN>(reinterpret_cast<const float *>(img + first), seg);
+#pragma unroll
+                for (int e = 0; e < WIN; ++e) {
+                    const float val = rev ? seg[WIN - 1 - e] : seg[e];
+                    if (alongX) v[k * WIN + e] = (T)val; else v[e * WIN + k] = (T)val;
+                }
+            }
+            return;
         }
 #pragma unroll
         for (int j = 0; j < WIN; ++j)
