@@ -273,7 +273,9 @@ int get_plan(const aai_request &rq, int band0, int band1, int channels, Plan **o
             if (e == hipSuccess) e = aai::launch_knife_scan(r, dMasks, dCount, nullptr);
             if (e == hipSuccess && r.quad) e = aai::launch_quad_scan(r, dMasks, dCount, nullptr);
             if (e == hipSuccess) e = hipMemcpy(&count, dCount, sizeof(unsigned), hipMemcpyDeviceToHost);
-            if (e == hipSuccess && count > kMaxListedPixels) { p.dense = true; count = 0; }
+            // (AAI_MAX_LISTED_PIXELS: test hook, lowers the threshold so that small geometries exercise the dense form)
+            static const unsigned maxListed = [] { const char *v = getenv("AAI_MAX_LISTED_PIXELS"); return v ? (unsigned)strtoul(v, nullptr, 10) : kMaxListedPixels; }();
+            if (e == hipSuccess && count > maxListed) { p.dense = true; count = 0; }
             if (e == hipSuccess && count) {
                 e = hipMalloc(&p.dList, (size_t)count * 2 * sizeof(unsigned));
                 if (e == hipSuccess) e = hipMemset(dCount, 0, sizeof(unsigned));

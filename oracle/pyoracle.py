@@ -141,6 +141,24 @@ def oracle_run(mode, src, src_res, dst_res, iso, angle, policy=POLICY_REFERENCE)
     return _run(lib.aai_oracle_run, lib.aai_oracle_free, (int(mode), int(policy)), src, src_res, dst_res, iso, angle)
 
 
+def oracle_rows(mode, src_f32, src_res, dst_res, iso, angle, row0, row1, dst_width, policy=POLICY_REFERENCE):
+    """Rows [row0, row1) of the output only (aai_oracle_rows): for images too large for a full CPU run.  src_f32 is an
+    [H, W] float32 array; returns a float64 array [row1 - row0, dst_width]."""
+    lib = _load_oracle()
+    lib.aai_oracle_rows.restype = ctypes.c_int
+    lib.aai_oracle_rows.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int] + \
+        [ctypes.c_double] * 7 + [ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int]
+    a = np.ascontiguousarray(src_f32, dtype=np.float32)
+    H, W = a.shape
+    out = np.empty((row1 - row0, dst_width), np.float64)
+    err = ctypes.create_string_buffer(256)
+    ok = lib.aai_oracle_rows(int(mode), int(policy), a.ctypes.data, 1, W, H, float(src_res), float(src_res), float(dst_res), float(dst_res),
+                             float(iso[0]), float(iso[1]), float(angle), int(row0), int(row1), out.ctypes.data, err, 256)
+    if not ok:
+        raise RuntimeError(err.value.decode())
+    return out
+
+
 def synth_image(W, H, seed=1):
     """SURVEY.md Appendix C.1 generator, vectorised numpy (uint64 wraparound arithmetic)."""
     with np.errstate(over="ignore"):

@@ -6,11 +6,12 @@ Comparisons are against (a) the committed golden vectors produced by the unmodif
 (BASELINE.json north_star), exact zeros must stay exact.  Nothing here reads /root/reference.
 """
 import ctypes
+import os
 
 import numpy as np
 import pytest
 
-from conftest import KNIFE_EDGE, KNIFE_EDGE_CASES, RUNS_CASES, TOL, load_full, rel_err, sample_points
+from conftest import KNIFE_EDGE, KNIFE_EDGE_CASES, ROOT, RUNS_CASES, TOL, load_full, rel_err, sample_points
 
 pytestmark = pytest.mark.gpu
 
@@ -720,3 +721,60 @@ def test_quad_kernel_equals_its_cpu_replay_bit_for_bit(gpu, hostemu, po):
             assert rel_err(dst, ref).max() <= 3e-7
     finally:
         hostemu.aai_emu_use_quad(0)
+
+
+def test_outputs_taller_than_one_grid(gpu, po):
+    """More than 1,048,560 output rows (65,535 tiles of 16: the most one launch's grid.y can carry): the rotated kernels,
+    their one-off scans and the samplers go band by band (aai_rotated.hip: launch_rotated_typed), K1 doubles its rows per
+    workgroup.  A 40 x 1,100,000 image; sampled row bands against the CPU oracle's rows."""
+    import torch
+    W, H = 40, 1_100_000
+    src = torch.empty((H, W), dtype=torch.float32, device="cuda")
+    gpu.synth_device(src.data_ptr(), W, H, W, 3)
+    host = src.cpu().numpy()
+    for (sr, dr, ang, mode, omode) in ((1.0, 1.0, 0.05, 1, po.MODE_EXACT), (1.0, 1.0, 0.0, 1, po.MODE_EXACT), (1.0, 1.0, 0.05, 2, po.MODE_FAST),
+                                        (1.0, 1.0, 0.05, 3, 3)):
+        iso = ((W - 1) / 2, (H - 1) / 2)
+        rq = gpu.make_request(W, H, sr, dr, iso, ang, mode=mode)
+        rc, msg, lay = gpu.query(rq)
+        assert rc == 0 and lay.dst_height > 65535 * 16, (msg, lay.dst_height)
+        out = _device_run(gpu, rq, src)
+        dH, dW = lay.dst_height, lay.dst_width
+        for r0 in (0, 65535 * 16 - 8, 65535 * 16 + 40, dH - 24):
+            gold = po.oracle_rows(omode, host, sr, dr, iso, ang, r0, r0 + 16, dW)
+            got = out[r0:r0 + 16].cpu().numpy()
+            if mode == 3:
+                assert np.abs(got - gold).max() <= 2e-5, (ang, mode, r0)
+            else:
+                assert rel_err(got, gold).max() <= TOL, (ang, mode, r0, gpu.last_kernel())
+                assert np.array_equal(gold == 0, got == 0), (ang, mode, r0)
+        del out
+
+
+def test_dense_knife_geometry_takes_the_strict_pass_for_the_whole_image(po):
+    """When (nearly) every dst pixel is flagged the plan keeps no list and the double-precision pass computes the whole image
+    (threshold 16 M pixels; lowered to 10 through the test hook AAI_MAX_LISTED_PIXELS, in a child process because the
+    hook is read once)."""
+    import subprocess
+    import sys
+    code = r"""
+import sys, numpy as np
+sys.path.insert(0, %r)
+import area_average_interpolation_amd as aai
+from oracle import pyoracle as po
+aai.set_device(0)
+for (W, H, sr, dr, ang, mode, omode) in ((96, 80, 2.0, 1.0, 45.0, 1, po.MODE_EXACT), (96, 80, 2.0, 1.0, 30.0, 1, po.MODE_EXACT), (96, 80, 2.0, 1.0, 45.0, 2, po.MODE_FAST)):
+    src = po.synth_image(W, H, 5)
+    iso = ((W - 1) / 2, (H - 1) / 2)
+    rc, msg, dst, giso, lay = aai.resample_host(src, sr, dr, iso, ang, mode=mode)
+    assert rc == 0, msg
+    if mode == 1:
+        assert "strict" in aai.last_kernel(), aai.last_kernel()
+    gold = po.oracle_run(omode, src.astype(np.float64), sr, dr, iso, ang).dst
+    err = np.abs(dst - gold) / np.maximum(np.abs(gold), 1e-3)
+    assert err.max() <= 1e-5 and np.array_equal(gold == 0, dst == 0), (W, H, ang, mode, float(err.max()))
+print("dense ok")
+""" % ROOT
+    env = dict(os.environ, AAI_MAX_LISTED_PIXELS="10")
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=600)
+    assert p.returncode == 0 and "dense ok" in p.stdout, (p.stdout[-2000:], p.stderr[-3000:])
