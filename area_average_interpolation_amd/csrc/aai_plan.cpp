@@ -150,7 +150,7 @@ RotLaunch make_rot_launch(const Geometry &g, int mode, int policy)
     // Footprints whose window of source pixels fits 8 x 8 take the fp32 quad formulation (aai_rot_quad.hpp), unless the
     // reduced angle is so close to an axis that the reference's own corner-triangle rule amplifies fp32 coordinates
     // beyond the parity bar (quad_supported).
-    r.quad = (mode == AAI_MODE_AREA && c > 0.0 && s > 0.0 && quad_supported(g.side, c, s)) ? 1 : 0;
+    r.quad = ((mode == AAI_MODE_AREA || mode == AAI_MODE_FAST) && c > 0.0 && s > 0.0 && quad_supported(g.side, c, s)) ? 1 : 0;
     {
         // virtual centre: X = dx (side cs) + dy (side sn) + X0, Y = -dx (side sn) + dy (side cs) + Y0   (pixel_centre)
         const double u0 = g.fracX * g.side - g.isoX + g.offX, v0 = g.fracY * g.side - g.isoY + g.offY;

@@ -45,7 +45,7 @@ struct RotLaunch {
     double rc, rs, rhi, r2cs;       // 1/c, 1/s, 1/hi, 1/(2 c s)
     // the reference's edge-line parametrisation (Source.cpp:229-240), for the strict replay only
     int runs;                       // area mode: walk each source row as boundary / interior / boundary runs (large footprints)
-    int quad;                       // area mode: the fp32 quad formulation serves this geometry (aai_rot_quad.hpp)
+    int quad;                       // area / fast mode: the fp32 quad formulation serves this geometry (aai_rot_quad.hpp)
     int chan;                       // interleaved channels per pixel (1 = a plain image): element = pixel offset * chan + channel
     int lt45;                       // reduced angle < 45 degrees
     double tsn, tcs, ttn;           // tmpSin, tmpCos, tmpTan (tan snapped to 0 below DBL_EPSILON)

@@ -394,6 +394,64 @@ AAI_HD bool quad_pixel(const QuadConsts<F> &q, int Xc, int Yc, double dfx, doubl
     return uncertain;
 }
 
+// Fast mode (Source.cpp:868-907 + 837-864): the mean of the virtual pixels whose CENTRES lie in the closed dst square
+// (SURVEY.md B.3).  Same window and the same up-front fetch as quad_pixel; membership is two compares per position,
+// and the values are summed straight from the registers they were fetched into -- no LDS, no passes.
+//   src.issue(xg0, yg0, valid), src.reg(slot) = the fetched value of a (compile-time) slot.
+// Returns sum and count; the dst value is sum / count, or 0 when count is 0 (Source.cpp:905).
+// SCAN: nothing is fetched; the return value says whether a centre lies within QuadConsts::margin of an edge, in which
+// case the double-precision pass (with the reference's ray cast at knife edges) owns this pixel.
+template <typename F, int WIN, bool SCAN, typename Src>
+AAI_HD bool quad_fast_pixel(const QuadConsts<F> &q, int Xc, int Yc, double dfx, double dfy, int mW, int mH, Src &src, F &sum, int &count)
+{
+    typedef typename QuadMask<WIN>::type mask_t;
+    const F fpx = (F)dfx, fpy = (F)dfy;
+    sum = F(0); count = 0;
+    const F fi0 = floor(fpx - q.hbm), fj0 = floor(fpy - q.hbm);
+    const int i0 = (int)fi0, j0 = (int)fj0;
+    const int xg0 = Xc + i0, yg0 = Yc + j0;
+    // window columns ia..ib and rows ja..jb lie inside the lattice
+    const int ia = xg0 < 0 ? -xg0 : 0, ib = (mW - 1 - xg0 < WIN - 1) ? mW - 1 - xg0 : WIN - 1;
+    const int ja = yg0 < 0 ? -yg0 : 0, jb = (mH - 1 - yg0 < WIN - 1) ? mH - 1 - yg0 : WIN - 1;
+    if (ia > ib || ja > jb) return false;
+    if (!SCAN) {
+        const unsigned cols = (2u << ib) - (1u << ia);
+        mask_t valid = 0;
+#pragma unroll
+        for (int j = 0; j < WIN; ++j)
+            if (j >= ja && j <= jb) valid |= (mask_t)cols << (j * WIN);
+        src.issue(xg0, yg0, valid);
+    }
+    // Columns and rows off the lattice get a coordinate far away: a = far * c (or far * s, or far * (c - s) with
+    // b = far * (c + s) when both are off) fails the membership test by itself, c and s being > 1e-4 -- one select per
+    // column and row instead of a validity test per position.
+    const F far = F(1e30);
+    F fis[WIN], fjs[WIN];
+#pragma unroll
+    for (int i = 0; i < WIN; ++i) {
+        fis[i] = (i >= ia && i <= ib) ? fi0 + (F)i : far;
+        fjs[i] = (i >= ja && i <= jb) ? fj0 + (F)i : far;
+    }
+    const F ac = qfma(fpy, q.s, -(fpx * q.c)), bc = -qfma(fpx, q.s, fpy * q.c);
+    bool uncertain = false;
+#pragma unroll
+    for (int j = 0; j < WIN; ++j) {
+        const F rowA = qfma(-fjs[j], q.s, ac), rowB = qfma(fjs[j], q.c, bc);
+#pragma unroll
+        for (int i = 0; i < WIN; ++i) {
+            const F a = qabs(qfma(fis[i], q.c, rowA)), b = qabs(qfma(fis[i], q.s, rowB));
+            const bool in = a <= q.h && b <= q.h;
+            if (SCAN) {
+                if ((qabs(a - q.h) < q.margin && b < q.h + q.margin) || (qabs(b - q.h) < q.margin && a < q.h + q.margin)) uncertain = true;
+            } else {
+                sum += in ? (F)src.reg(j * WIN + i) : F(0);       // (a select, not a product: values outside the square may be anything)
+                count += in ? 1 : 0;
+            }
+        }
+    }
+    return uncertain;
+}
+
 // run-time window size and precision switch -> the matching instantiation
 template <typename F, bool SCAN, int NC, typename Src>
 AAI_HD bool quad_pixel_any(const QuadConsts<F> &q, int Xc, int Yc, double fpx, double fpy, int mW, int mH, Src &src, F &sumA, F (&sumVA)[NC])

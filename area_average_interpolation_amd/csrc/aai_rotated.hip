@@ -351,6 +351,12 @@ static const RotTune &rot_tune()
     return t;
 }
 
+// the fp32 quad kernels serve this launch (area mode: plain and interleaved images; fast mode: plain images)
+static bool quad_serves(const RotLaunch &r, int srcType, ImageView sv)
+{
+    return r.quad && rot_tune().quad != 0 && (r.mode == AAI_MODE_AREA || (r.mode == AAI_MODE_FAST && r.chan == 1)) && quad_can_address(r, srcType, sv);
+}
+
 // one launch of at most 65535 tile rows (sampler: 4-row tiles, the others 16-row tiles)
 template <typename T>
 static hipError_t launch_rotated_band(const RotLaunch &r, const QuadMap &m, const T *src, int srcType, ImageView sv, float *dst, ImageView dv,
@@ -369,7 +375,8 @@ static hipError_t launch_rotated_band(const RotLaunch &r, const QuadMap &m, cons
     }
     dim3 grid((r.dW + 15) / 16, (r.dyEnd - r.dyBase + 15) / 16, batch);
     const RotTune &tune = rot_tune();
-    if (r.chan > 1 && r.mode == AAI_MODE_AREA && r.quad && tune.quad != 0 && quad_can_address(r, srcType, sv)) {
+    const bool quad = quad_serves(r, srcType, sv);
+    if (r.chan > 1 && quad) {
         // interleaved channels through the fp32 quad formulation: areas once per pair, applied to every channel
         if (kernelName) *kernelName = "aai_quad_multi_kernel<area, channels>";
         return launch_quad(r, m, src, srcType, sv, dst, dv, batch, flags.count ? flags.masks : nullptr, stream);
@@ -385,10 +392,14 @@ static hipError_t launch_rotated_band(const RotLaunch &r, const QuadMap &m, cons
             if (kernelName) *kernelName = "aai_rotated_kernel<area, channels>";
             hipLaunchKernelGGL((aai_rotated_kernel<AAI_MODE_AREA, false, T, true>), grid, dim3(kRotBlock), 0, stream, r, src, sv, dst, dv, nullptr, 0u);
         }
+    } else if (r.mode == AAI_MODE_FAST && quad) {
+        // centres in the dst square, fp32 in the dst frame; flagged pixels belong to the fix-up pass as in area mode
+        if (kernelName) *kernelName = "aai_quad_fast_kernel";
+        return launch_quad(r, m, src, srcType, sv, dst, dv, batch, flags.count ? flags.masks : nullptr, stream);
     } else if (r.mode == AAI_MODE_FAST) {
         if (kernelName) *kernelName = "aai_rotated_kernel<fast>";
         hipLaunchKernelGGL((aai_rotated_kernel<AAI_MODE_FAST, false, T>), grid, dim3(kRotBlock), 0, stream, r, src, sv, dst, dv, nullptr, 0u);
-    } else if (r.quad && tune.quad != 0 && quad_can_address(r, srcType, sv)) {
+    } else if (quad) {
         // the fp32 quad formulation; the pixels flagged by the plan's scans are recomputed by the fix-up pass
         if (kernelName) *kernelName = "aai_quad_kernel<area>";
         return launch_quad(r, m, src, srcType, sv, dst, dv, batch, flags.count ? flags.masks : nullptr, stream);
@@ -428,8 +439,7 @@ static hipError_t launch_rotated_typed(const RotLaunch &r, const QuadMap &m, con
     // pass on the same stream -- or, when the production kernel is the quad kernel and skips those pixels, beside it on
     // the plan's side stream: fork before, join after.
     const bool fixup = !sampler && flags.count != 0;
-    const bool beside = fixup && flags.masks && flags.side && r.mode == AAI_MODE_AREA && r.quad && rot_tune().quad != 0 &&
-                        quad_can_address(r, srcType, sv);
+    const bool beside = fixup && flags.masks && flags.side && quad_serves(r, srcType, sv);
     hipError_t e = hipSuccess;
     if (beside) {
         e = hipEventRecord(flags.fork, stream);

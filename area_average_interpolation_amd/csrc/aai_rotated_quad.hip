@@ -127,9 +127,11 @@ struct QuadSrc {
         for (int k = 0; k < WIN * WIN; ++k) lds[k][tid] = (float)v[k];
     }
     __device__ __forceinline__ void at(int slot, float (&vals)[1]) const { vals[0] = lds[slot][tid]; }
+    __device__ __forceinline__ float reg(int slot) const { return (float)v[slot]; }
 };
 
 struct NoSrc {
+    __device__ __forceinline__ float reg(int) const { return 1.f; }
     __device__ __forceinline__ void issue(int, int, unsigned long long) {}
     __device__ __forceinline__ void commit() {}
     __device__ __forceinline__ void at(int, float (&vals)[1]) const { vals[0] = 1.f; }
@@ -228,6 +230,11 @@ struct QuadSrcMulti {
     }
 };
 
+// Tile order: launch order (x fastest).  Workgroups are dealt round-robin over the 8 XCDs, so neighbouring tiles sit on
+// different L2s and the fast kernel fetches 1.75 x the source at config 3 -- yet giving each XCD contiguous bands, or
+// cyclically dealt 8 x 8 super-tiles, made every kernel SLOWER (profiles/r02_xcd_tile_order.txt): these kernels are bound
+// by instruction issue, and the empty corners of a rotated output are spread evenly only in launch order.
+
 // waves per SIMD that the staged windows leave room for (160 KiB of LDS per CU, WIN * WIN KiB per 256-lane block):
 // the register budget follows it
 constexpr int quad_waves_per_simd(int win) { return 160 / (win * win) >= 8 ? 8 : 160 / (win * win); }
@@ -239,13 +246,14 @@ __global__ __launch_bounds__(kQuadBlock, quad_waves_per_simd(WIN) - (HP && quad_
 {
     __shared__ float window[WIN * WIN][kQuadBlock];
     const int tid = threadIdx.x;
-    const int dx = blockIdx.x * 16 + (tid & 15);
-    const int dy = r.dyBase + blockIdx.y * 16 + (tid >> 4);
+    const int tx = blockIdx.x, ty = blockIdx.y;
+    const int dx = tx * 16 + (tid & 15);
+    const int dy = r.dyBase + ty * 16 + (tid >> 4);
     if (!(dx < r.dW && dy < r.dyEnd)) return;
     if (skipMasks) {
         // pixels the plan's scans flagged belong to the double-precision pass, which runs beside this kernel
         const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-        const unsigned long long mask = skipMasks[((size_t)(blockIdx.y + r.dyBase / 16) * gridDim.x + blockIdx.x) * (kQuadBlock / 64) + wave];
+        const unsigned long long mask = skipMasks[((size_t)(ty + r.dyBase / 16) * gridDim.x + tx) * (kQuadBlock / 64) + wave];
         if ((mask >> (tid & 63)) & 1ull) return;
     }
     float *out = dst + (int64_t)blockIdx.z * dv.imageStride + (int64_t)(dy - r.dyBase) * dv.rowStride + dx;
@@ -266,6 +274,40 @@ __global__ __launch_bounds__(kQuadBlock, quad_waves_per_simd(WIN) - (HP && quad_
     *out = value;
 }
 
+// K3 in the same frame: fast mode (Source.cpp:868-907), the mean of the virtual pixels whose centres lie in the dst
+// square.  The window stays in the registers it was fetched into; no LDS.
+template <typename T, int WIN, bool SCALED>
+__global__ __launch_bounds__(kQuadBlock) void aai_quad_fast_kernel(RotLaunch r, QuadConsts<float> q, QuadMap m, const T *__restrict__ src, ImageView sv,
+                                                                  float *__restrict__ dst, ImageView dv, const unsigned long long *__restrict__ skipMasks)
+{
+    const int tid = threadIdx.x;
+    const int tx = blockIdx.x, ty = blockIdx.y;
+    const int dx = tx * 16 + (tid & 15);
+    const int dy = r.dyBase + ty * 16 + (tid >> 4);
+    if (!(dx < r.dW && dy < r.dyEnd)) return;
+    if (skipMasks) {
+        const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+        const unsigned long long mask = skipMasks[((size_t)(ty + r.dyBase / 16) * gridDim.x + tx) * (kQuadBlock / 64) + wave];
+        if ((mask >> (tid & 63)) & 1ull) return;
+    }
+    float *out = dst + (int64_t)blockIdx.z * dv.imageStride + (int64_t)(dy - r.dyBase) * dv.rowStride + dx;
+
+    double px, py;
+    pixel_centre(r, dx, dy, px, py);
+    const double cx = floor(px + 0.5), cy = floor(py + 0.5);
+    float value = 0.f;
+    if (cx > -16.0 && cx < (double)r.mW + 16.0 && cy > -16.0 && cy < (double)r.mH + 16.0) {
+        QuadSrc<T, WIN, SCALED> s;
+        s.img = reinterpret_cast<const char *>(src + (int64_t)blockIdx.z * sv.imageStride + m.base);
+        s.m = &m; s.mW = r.mW; s.mH = r.mH; s.lds = nullptr; s.tid = tid;
+        float sum;
+        int count;
+        quad_fast_pixel<float, WIN, false>(q, (int)cx, (int)cy, px - cx, py - cy, r.mW, r.mH, s, sum, count);
+        value = count > 0 ? sum / (float)count : 0.f;                 // Source.cpp:905
+    }
+    *out = value;
+}
+
 // Interleaved channels: areas once per (dst, src) pair, applied to every channel (four accumulators).  Dynamic LDS:
 // WIN * WIN * words KiB per block.
 template <typename T, int WIN, bool SCALED, int WORDS>
@@ -275,12 +317,13 @@ void aai_quad_multi_kernel(RotLaunch r, QuadConsts<float> q, QuadMap m, const T 
 {
     extern __shared__ unsigned windowWords[];
     const int tid = threadIdx.x;
-    const int dx = blockIdx.x * 16 + (tid & 15);
-    const int dy = r.dyBase + blockIdx.y * 16 + (tid >> 4);
+    const int tx = blockIdx.x, ty = blockIdx.y;
+    const int dx = tx * 16 + (tid & 15);
+    const int dy = r.dyBase + ty * 16 + (tid >> 4);
     if (!(dx < r.dW && dy < r.dyEnd)) return;
     if (skipMasks) {
         const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-        const unsigned long long mask = skipMasks[((size_t)(blockIdx.y + r.dyBase / 16) * gridDim.x + blockIdx.x) * (kQuadBlock / 64) + wave];
+        const unsigned long long mask = skipMasks[((size_t)(ty + r.dyBase / 16) * gridDim.x + tx) * (kQuadBlock / 64) + wave];
         if ((mask >> (tid & 63)) & 1ull) return;
     }
     const int chan = r.chan;
@@ -308,7 +351,8 @@ void aai_quad_multi_kernel(RotLaunch r, QuadConsts<float> q, QuadMap m, const T 
 // Once per geometry: the same arithmetic without pixel loads.  Flags one bit per dst pixel in the 64-bit word of its
 // wave (the 16 x 16 tiling of aai_knife_scan_kernel, whose bits this kernel adds to) and counts the newly flagged
 // pixels in counter[0].
-template <int WIN, bool HP>
+// FAST: the scan of aai_quad_fast_kernel (HP unused)
+template <int WIN, bool HP, bool FAST = false>
 __global__ __launch_bounds__(kQuadBlock) void aai_quad_scan_kernel(RotLaunch r, QuadConsts<float> q, unsigned long long *__restrict__ laneMasks,
                                                                   unsigned *__restrict__ counter, int tileRow0)
 {
@@ -324,7 +368,9 @@ __global__ __launch_bounds__(kQuadBlock) void aai_quad_scan_kernel(RotLaunch r, 
         if (cx > -16.0 && cx < (double)r.mW + 16.0 && cy > -16.0 && cy < (double)r.mH + 16.0) {
             NoSrc s;
             float sumA, sumVA[1];
-            uncertain = quad_pixel<float, WIN, true, HP, 1>(q, (int)cx, (int)cy, px - cx, py - cy, r.mW, r.mH, s, sumA, sumVA);
+            int count;
+            if (FAST) uncertain = quad_fast_pixel<float, WIN, true>(q, (int)cx, (int)cy, px - cx, py - cy, r.mW, r.mH, s, sumA, count);
+            else uncertain = quad_pixel<float, WIN, true, HP, 1>(q, (int)cx, (int)cy, px - cx, py - cy, r.mW, r.mH, s, sumA, sumVA);
         }
     }
     const unsigned long long any = __ballot(uncertain);
@@ -360,6 +406,11 @@ hipError_t launch_quad_win(const RotLaunch &r, const QuadConsts<float> &q, const
                            int batch, const unsigned long long *skipMasks, hipStream_t stream)
 {
     const dim3 grid((r.dW + 15) / 16, (r.dyEnd - r.dyBase + 15) / 16, batch);      // at most 65535 tile rows: the caller bands taller outputs
+    if (r.mode == AAI_MODE_FAST) {
+        if (m.scale > 1) hipLaunchKernelGGL((aai_quad_fast_kernel<T, WIN, true>), grid, dim3(kQuadBlock), 0, stream, r, q, m, src, sv, dst, dv, skipMasks);
+        else hipLaunchKernelGGL((aai_quad_fast_kernel<T, WIN, false>), grid, dim3(kQuadBlock), 0, stream, r, q, m, src, sv, dst, dv, skipMasks);
+        return hipGetLastError();
+    }
     if (m.scale > 1) {
         if (q.hiPrec) hipLaunchKernelGGL((aai_quad_kernel<T, WIN, true, true>), grid, dim3(kQuadBlock), 0, stream, r, q, m, src, sv, dst, dv, skipMasks);
         else hipLaunchKernelGGL((aai_quad_kernel<T, WIN, true, false>), grid, dim3(kQuadBlock), 0, stream, r, q, m, src, sv, dst, dv, skipMasks);
@@ -468,14 +519,16 @@ hipError_t launch_quad_scan(const RotLaunch &r, unsigned long long *laneMasks, u
     const int tileRows = (r.dH + 15) / 16;
     for (int t0 = 0; t0 < tileRows; t0 += 65535) {         // grid.y carries at most 65535 tiles
         const dim3 grid((r.dW + 15) / 16, tileRows - t0 < 65535 ? tileRows - t0 : 65535, 1);
-        switch (q.win) {
-        case 3: if (q.hiPrec) hipLaunchKernelGGL((aai_quad_scan_kernel<3, true>), grid, dim3(kQuadBlock), 0, stream, r, q, laneMasks, counter, t0); else hipLaunchKernelGGL((aai_quad_scan_kernel<3, false>), grid, dim3(kQuadBlock), 0, stream, r, q, laneMasks, counter, t0); break;
-        case 4: if (q.hiPrec) hipLaunchKernelGGL((aai_quad_scan_kernel<4, true>), grid, dim3(kQuadBlock), 0, stream, r, q, laneMasks, counter, t0); else hipLaunchKernelGGL((aai_quad_scan_kernel<4, false>), grid, dim3(kQuadBlock), 0, stream, r, q, laneMasks, counter, t0); break;
-        case 5: if (q.hiPrec) hipLaunchKernelGGL((aai_quad_scan_kernel<5, true>), grid, dim3(kQuadBlock), 0, stream, r, q, laneMasks, counter, t0); else hipLaunchKernelGGL((aai_quad_scan_kernel<5, false>), grid, dim3(kQuadBlock), 0, stream, r, q, laneMasks, counter, t0); break;
-        case 6: if (q.hiPrec) hipLaunchKernelGGL((aai_quad_scan_kernel<6, true>), grid, dim3(kQuadBlock), 0, stream, r, q, laneMasks, counter, t0); else hipLaunchKernelGGL((aai_quad_scan_kernel<6, false>), grid, dim3(kQuadBlock), 0, stream, r, q, laneMasks, counter, t0); break;
-        case 7: if (q.hiPrec) hipLaunchKernelGGL((aai_quad_scan_kernel<7, true>), grid, dim3(kQuadBlock), 0, stream, r, q, laneMasks, counter, t0); else hipLaunchKernelGGL((aai_quad_scan_kernel<7, false>), grid, dim3(kQuadBlock), 0, stream, r, q, laneMasks, counter, t0); break;
-        default: if (q.hiPrec) hipLaunchKernelGGL((aai_quad_scan_kernel<8, true>), grid, dim3(kQuadBlock), 0, stream, r, q, laneMasks, counter, t0); else hipLaunchKernelGGL((aai_quad_scan_kernel<8, false>), grid, dim3(kQuadBlock), 0, stream, r, q, laneMasks, counter, t0); break;
+#define AAI_SCAN_WIN(W)                                                                                                                        \
+    case W:                                                                                                                                    \
+        if (r.mode == AAI_MODE_FAST) hipLaunchKernelGGL((aai_quad_scan_kernel<W, false, true>), grid, dim3(kQuadBlock), 0, stream, r, q, laneMasks, counter, t0); \
+        else if (q.hiPrec) hipLaunchKernelGGL((aai_quad_scan_kernel<W, true>), grid, dim3(kQuadBlock), 0, stream, r, q, laneMasks, counter, t0); \
+        else hipLaunchKernelGGL((aai_quad_scan_kernel<W, false>), grid, dim3(kQuadBlock), 0, stream, r, q, laneMasks, counter, t0);            \
+        break;
+        switch (q.win < 3 ? 3 : (q.win > 8 ? 8 : q.win)) {
+            AAI_SCAN_WIN(3) AAI_SCAN_WIN(4) AAI_SCAN_WIN(5) AAI_SCAN_WIN(6) AAI_SCAN_WIN(7) AAI_SCAN_WIN(8)
         }
+#undef AAI_SCAN_WIN
         const hipError_t e = hipGetLastError();
         if (e != hipSuccess) return e;
     }

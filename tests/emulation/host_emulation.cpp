@@ -252,6 +252,7 @@ struct EmuQuadSrc {
     }
     void commit() {}
     void at(int slot, float (&vals)[1]) const { vals[0] = v[slot]; }
+    float reg(int slot) const { return v[slot]; }
 };
 
 template <int WIN>
@@ -274,12 +275,28 @@ static bool emu_quad_pixel(const QuadConsts<float> &qc, const RotLaunch &r, cons
     return true;
 }
 
+// fast mode through the fp32 formulation (aai_quad_fast_kernel)
+template <int WIN>
+static bool emu_quad_fast_pixel(const QuadConsts<float> &qc, const RotLaunch &r, const float *img, int64_t stride, double px, double py, float &value)
+{
+    const double cxr = std::floor(px + 0.5), cyr = std::floor(py + 0.5);
+    if (!(std::fabs(cxr) < 1e9 && std::fabs(cyr) < 1e9)) return false;
+    EmuQuadSrc<WIN> qs{&r, img, stride, {}};
+    float sum;
+    int count;
+    if (quad_fast_pixel<float, WIN, true>(qc, (int)cxr, (int)cyr, px - cxr, py - cyr, r.mW, r.mH, qs, sum, count)) return false;
+    quad_fast_pixel<float, WIN, false>(qc, (int)cxr, (int)cyr, px - cxr, py - cyr, r.mW, r.mH, qs, sum, count);
+    value = count > 0 ? sum / (float)count : 0.f;
+    return true;
+}
+
 static void emu_rotated(const Geometry &g, const aai_request &rq, const float *img, int64_t srcStride, float *dst, int64_t dstStride)
 {
     const RotLaunch r = make_rot_launch(g, rq.mode, rq.policy);
     g_knifePairs = g_knifePixels = g_missedPairs = 0;
     g_quadPixels = g_quadUncertain = 0;
-    const bool quad = g_useQuad && rq.mode == AAI_MODE_AREA && quad_supported(r.side, r.c, r.s);
+    const bool quad = g_useQuad && r.quad;
+    const bool fastQuad = rq.mode == AAI_MODE_FAST;
     const QuadConsts<float> qc = make_quad_consts<float>(r.side, r.c, r.s, r.policy);
     for (int dy = 0; dy < r.dH; ++dy)
         for (int dx = 0; dx < r.dW; ++dx) {
@@ -299,12 +316,12 @@ static void emu_rotated(const Geometry &g, const aai_request &rq, const float *i
                 float value = 0.f;
                 bool done;
                 switch (qc.win) {
-                case 3: done = emu_quad_pixel<3>(qc, r, img, srcStride, px, py, value); break;
-                case 4: done = emu_quad_pixel<4>(qc, r, img, srcStride, px, py, value); break;
-                case 5: done = emu_quad_pixel<5>(qc, r, img, srcStride, px, py, value); break;
-                case 6: done = emu_quad_pixel<6>(qc, r, img, srcStride, px, py, value); break;
-                case 7: done = emu_quad_pixel<7>(qc, r, img, srcStride, px, py, value); break;
-                default: done = emu_quad_pixel<8>(qc, r, img, srcStride, px, py, value); break;
+                case 3: done = fastQuad ? emu_quad_fast_pixel<3>(qc, r, img, srcStride, px, py, value) : emu_quad_pixel<3>(qc, r, img, srcStride, px, py, value); break;
+                case 4: done = fastQuad ? emu_quad_fast_pixel<4>(qc, r, img, srcStride, px, py, value) : emu_quad_pixel<4>(qc, r, img, srcStride, px, py, value); break;
+                case 5: done = fastQuad ? emu_quad_fast_pixel<5>(qc, r, img, srcStride, px, py, value) : emu_quad_pixel<5>(qc, r, img, srcStride, px, py, value); break;
+                case 6: done = fastQuad ? emu_quad_fast_pixel<6>(qc, r, img, srcStride, px, py, value) : emu_quad_pixel<6>(qc, r, img, srcStride, px, py, value); break;
+                case 7: done = fastQuad ? emu_quad_fast_pixel<7>(qc, r, img, srcStride, px, py, value) : emu_quad_pixel<7>(qc, r, img, srcStride, px, py, value); break;
+                default: done = fastQuad ? emu_quad_fast_pixel<8>(qc, r, img, srcStride, px, py, value) : emu_quad_pixel<8>(qc, r, img, srcStride, px, py, value); break;
                 }
                 if (done) { *out = value; ++g_quadPixels; continue; }
                 ++g_quadUncertain;

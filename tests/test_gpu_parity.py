@@ -710,15 +710,16 @@ def test_quad_kernel_equals_its_cpu_replay_bit_for_bit(gpu, hostemu, po):
                                             (150, 150, 2.0, 1.0, 117.3, 1), (120, 90, 1.0, 1.0, 200.0, 0), (128, 128, 3.0, 2.0, 300.0, 0)):
             iso = (float(rng.uniform(0, W)), float(rng.uniform(0, H)))
             src = rng.random((H, W)).astype(np.float32)
-            rq = gpu.make_request(W, H, sr, dr, iso, ang, mode=1, policy=policy)
-            ref, axis = hostemu.resample(rq, src)
-            quad, flagged = hostemu.quad_stats()
-            rc, msg, dst, _, lay = gpu.resample_host(src, sr, dr, iso, ang, mode=1, policy=policy)
-            assert rc == 0 and "aai_quad_kernel" in gpu.last_kernel(), (msg, gpu.last_kernel())
-            differ = int((dst != ref).sum())
-            # flagged pixels go through the double-precision kernels, whose summation order differs from the replay's
-            assert differ <= flagged, (W, H, sr, dr, ang, differ, flagged, quad)
-            assert rel_err(dst, ref).max() <= 3e-7
+            for mode, kernel in ((1, "aai_quad_kernel"), (2, "aai_quad_fast_kernel")):
+                rq = gpu.make_request(W, H, sr, dr, iso, ang, mode=mode, policy=policy)
+                ref, axis = hostemu.resample(rq, src)
+                quad, flagged = hostemu.quad_stats()
+                rc, msg, dst, _, lay = gpu.resample_host(src, sr, dr, iso, ang, mode=mode, policy=policy)
+                assert rc == 0 and kernel in gpu.last_kernel(), (msg, gpu.last_kernel())
+                differ = int((dst != ref).sum())
+                # flagged pixels go through the double-precision kernels, whose summation order differs from the replay's
+                assert differ <= flagged, (W, H, sr, dr, ang, mode, differ, flagged, quad)
+                assert rel_err(dst, ref).max() <= 3e-7
     finally:
         hostemu.aai_emu_use_quad(0)
 

@@ -458,15 +458,16 @@ def test_quad_fp32_replay_matches_small_golden(aai, hostemu, po, small_golden):
         quad = flagged = 0
         for i, c in enumerate(manifest):
             src = po.synth_image(c["W"], c["H"], c["seed"])
-            rq = aai.make_request(c["W"], c["H"], c["src_res"], c["dst_res"], c["iso"], c["angle"], mode=1)
-            out, axis = hostemu.resample(rq, src)
-            gold = z["c%03d_exact" % i]
-            q, u = hostemu.quad_stats()
-            quad += q
-            flagged += u
-            assert rel_err(out, gold).max() <= 0.3 * TOL, (i, c, float(rel_err(out, gold).max()))
-            assert np.array_equal(gold == 0, out == 0), i
-        assert quad > 30000 and flagged < 0.08 * quad, (quad, flagged)      # small images: many border pixels
+            for mode, tag in ((1, "exact"), (2, "fast")):       # fast mode: centres in the square, same frame (quad_fast_pixel)
+                rq = aai.make_request(c["W"], c["H"], c["src_res"], c["dst_res"], c["iso"], c["angle"], mode=mode)
+                out, axis = hostemu.resample(rq, src)
+                gold = z["c%03d_%s" % (i, tag)]
+                q, u = hostemu.quad_stats()
+                quad += q
+                flagged += u
+                assert rel_err(out, gold).max() <= 0.3 * TOL, (i, c, tag, float(rel_err(out, gold).max()))
+                assert np.array_equal(gold == 0, out == 0), (i, tag)
+        assert quad > 60000 and flagged < 0.08 * quad, (quad, flagged)      # small images: many border pixels
     finally:
         hostemu.aai_emu_use_quad(0)
 
@@ -490,6 +491,13 @@ def test_quad_fp32_replay_against_oracle_at_larger_sizes(aai, hostemu, po):
             gold = po.oracle_run(po.MODE_EXACT, src.astype(np.float64), sr, dr, iso, ang, policy=policy).dst
             assert not axis and q > 0 and u < 0.01 * q, (W, sr, dr, ang, q, u)
             assert rel_err(out, gold).max() <= 0.5 * TOL, (W, sr, dr, ang, float(rel_err(out, gold).max()))
+            assert np.array_equal(gold == 0, out == 0)
+            # fast mode in the same frame: a mean of pixel values, fp32 rounding only
+            out, axis = hostemu.resample(aai.make_request(W, W, sr, dr, iso, ang, mode=2, policy=policy), src)
+            q, u = hostemu.quad_stats()
+            gold = po.oracle_run(po.MODE_FAST, src.astype(np.float64), sr, dr, iso, ang, policy=policy).dst
+            assert not axis and q > 0 and u < 0.01 * q, (W, sr, dr, ang, q, u)
+            assert rel_err(out, gold).max() <= 0.1 * TOL, (W, sr, dr, ang, float(rel_err(out, gold).max()))
             assert np.array_equal(gold == 0, out == 0)
     finally:
         hostemu.aai_emu_use_quad(0)
