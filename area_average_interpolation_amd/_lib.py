@@ -24,6 +24,7 @@ ERR_EMPTY_OUTPUT = 10
 
 MODE_AREA, MODE_FAST, MODE_BILINEAR, MODE_BICUBIC = 1, 2, 3, 4
 POLICY_REFERENCE, POLICY_EXACT = 0, 1
+POLICY_DOUBLE_PRECISION = 0x100      # OR into a policy: general rotations in double precision throughout (include/aai.h)
 DTYPE_F32, DTYPE_U8, DTYPE_U16 = 0, 1, 2
 KERNEL_AXIS, KERNEL_ROTATED, KERNEL_FAST, KERNEL_SAMPLE, KERNEL_AXIS_WIDE = 1, 2, 3, 4, 5
 

@@ -99,7 +99,8 @@ int check_request(const aai_request *rq)
 {
     if (!rq) return fail(AAI_ERR_BAD_ARGUMENT, "Null request.");
     if (rq->mode < AAI_MODE_AREA || rq->mode > AAI_MODE_BICUBIC) return fail(AAI_ERR_BAD_ARGUMENT, "Unknown interpolation mode.");
-    if (rq->policy != AAI_POLICY_REFERENCE && rq->policy != AAI_POLICY_EXACT) return fail(AAI_ERR_BAD_ARGUMENT, "Unknown weight policy.");
+    const int rule = rq->policy & ~AAI_POLICY_DOUBLE_PRECISION;
+    if (rule != AAI_POLICY_REFERENCE && rule != AAI_POLICY_EXACT) return fail(AAI_ERR_BAD_ARGUMENT, "Unknown weight policy.");
     return AAI_OK;
 }
 

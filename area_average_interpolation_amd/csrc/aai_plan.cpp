@@ -127,7 +127,7 @@ RotLaunch make_rot_launch(const Geometry &g, int mode, int policy)
     r.offX = g.offX; r.offY = g.offY; r.sn = g.sn; r.cs = g.cs;
     r.reach = g.side * std::sqrt(2.0) / 2 + 1;
     r.dW = g.dW; r.dH = g.dH; r.mW = g.mW; r.mH = g.mH; r.W = g.W; r.H = g.H;
-    r.scale = g.scale; r.quadrant = g.quadrant; r.mode = mode; r.policy = policy;
+    r.scale = g.scale; r.quadrant = g.quadrant; r.mode = mode; r.policy = policy & ~AAI_POLICY_DOUBLE_PRECISION;
     r.dyBase = 0; r.dyEnd = g.dH; r.srcRow0 = 0; r.chan = 1;
     r.invScale = 1.0 / g.scale;
     const double c = g.cs, s = g.sn, h = 0.5 * g.side;
@@ -150,7 +150,8 @@ RotLaunch make_rot_launch(const Geometry &g, int mode, int policy)
     // Footprints whose window of source pixels fits 8 x 8 take the fp32 quad formulation (aai_rot_quad.hpp), unless the
     // reduced angle is so close to an axis that the reference's own corner-triangle rule amplifies fp32 coordinates
     // beyond the parity bar (quad_supported).
-    r.quad = ((mode == AAI_MODE_AREA || mode == AAI_MODE_FAST) && c > 0.0 && s > 0.0 && quad_supported(g.side, c, s)) ? 1 : 0;
+    r.quad = ((mode == AAI_MODE_AREA || mode == AAI_MODE_FAST) && !(policy & AAI_POLICY_DOUBLE_PRECISION) && c > 0.0 && s > 0.0 &&
+              quad_supported(g.side, c, s)) ? 1 : 0;
     {
         // virtual centre: X = dx (side cs) + dy (side sn) + X0, Y = -dx (side sn) + dy (side cs) + Y0   (pixel_centre)
         const double u0 = g.fracX * g.side - g.isoX + g.offX, v0 = g.fracY * g.side - g.isoY + g.offY;

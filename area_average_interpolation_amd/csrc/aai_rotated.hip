@@ -241,7 +241,9 @@ __global__ __launch_bounds__(kBlock) void aai_sample_kernel(RotLaunch r, const T
     const double sx = fma(ddx, r.sAx, fma(ddy, r.sBx, r.sCx)), sy = fma(ddx, r.sAy, fma(ddy, r.sBy, r.sCy));
     const int chan = r.chan > 1 ? r.chan : 1;          // interleaved channels share the taps' positions and weights
     float *out = dst + (int64_t)blockIdx.z * dv.imageStride + (int64_t)(dy - r.dyBase) * dv.rowStride + (int64_t)dx * chan;
-    const bool outside = sx < -0.5 || sx > r.W - 0.5 || sy < -0.5 || sy > r.H - 0.5;
+    // (a guard of 1e-9 pixels on the extent: points exactly on its edge are inside however the map was rounded)
+    const double guard = 1e-9;
+    const bool outside = sx < -0.5 - guard || sx > r.W - 0.5 + guard || sy < -0.5 - guard || sy > r.H - 0.5 + guard;
     const double fx = floor(sx), fy = floor(sy);
     const int ix = outside ? 0 : (int)fx, iy = outside ? 0 : (int)fy;
     const float tx = (float)(sx - fx), ty = (float)(sy - fy);

@@ -44,7 +44,7 @@ using dP = std::pair<double, double>;
 class AreaAverageInterpolation {
 public:
     bool verbose = false;                 // print the reference's parameter banner
-    int policy = AAI_POLICY_REFERENCE;    // AAI_POLICY_EXACT for geometrically exact areas
+    int policy = AAI_POLICY_REFERENCE;    // AAI_POLICY_EXACT for geometrically exact areas; | AAI_POLICY_DOUBLE_PRECISION: see aai.h
 
     std::pair<bool, std::string> areaAverageInterpolation(IMG src, IMG &dst, dP srcResolution, dP dstResolution,
                                                           dP srcIsocenter, dP &dstIsocenter, double rotationAngle)

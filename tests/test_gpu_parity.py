@@ -453,7 +453,7 @@ def test_samplers_at_full_size(gpu, cfg):
         for rows in bands:
             rows = list(rows)
             sx, sy = sample_points(rq, lay, rows, "cuda")
-            inside = (sx >= -0.5) & (sx <= W - 0.5) & (sy >= -0.5) & (sy <= H - 0.5)
+            inside = (sx >= -0.5 - 1e-9) & (sx <= W - 0.5 + 1e-9) & (sy >= -0.5 - 1e-9) & (sy <= H - 0.5 + 1e-9)      # the samplers' extent guard
             got = out[rows, :].double()
             assert float(got[~inside].abs().max()) == 0.0 if (~inside).any() else True          # exact 0 outside the image extent
             inside_total += int(inside.sum())
@@ -722,6 +722,30 @@ def test_quad_kernel_equals_its_cpu_replay_bit_for_bit(gpu, hostemu, po):
                 assert rel_err(dst, ref).max() <= 3e-7
     finally:
         hostemu.aai_emu_use_quad(0)
+
+
+def test_double_precision_policy(gpu, po):
+    """AAI_POLICY_DOUBLE_PRECISION routes general rotations to the double-precision kernels: exact to fp32 rounding on
+    the geometry class where the fp32 formulation has its tail (dst values far below their neighbours: slight
+    up-sampling within a degree of an axis), both modes, plain and interleaved."""
+    W, H, sr, dr, ang, iso = 203, 367, 2.6611805249461478, 2.9963661425245225, 90.69816691569076, (101.0, 183.0)
+    rng = np.random.default_rng(5)
+    src = rng.random((H, W)).astype(np.float32)
+    isrc = rng.random((H, W, 3)).astype(np.float32)
+    flag = gpu.POLICY_DOUBLE_PRECISION
+    for mode, omode in ((1, po.MODE_EXACT), (2, po.MODE_FAST)):
+        for policy in (0, 1):
+            gold = po.oracle_run(omode, src.astype(np.float64), sr, dr, iso, ang, policy=policy).dst
+            rc, msg, dst, _, lay = gpu.resample_host(src, sr, dr, iso, ang, mode=mode, policy=policy)
+            assert rc == 0 and "quad" in gpu.last_kernel() and rel_err(dst, gold).max() <= TOL
+            rc, msg, dst, _, lay = gpu.resample_host(src, sr, dr, iso, ang, mode=mode, policy=policy | flag)
+            assert rc == 0 and "quad" not in gpu.last_kernel(), gpu.last_kernel()
+            assert rel_err(dst, gold).max() <= 1.5e-7 and np.array_equal(gold == 0, dst == 0)
+        rc, msg, idst, ilay = gpu.resample_interleaved_host(isrc, sr, dr, iso, ang, mode=mode, policy=1 | flag)
+        assert rc == 0 and "quad" not in gpu.last_kernel()
+        for c in range(3):
+            g = po.oracle_run(omode, isrc[:, :, c].astype(np.float64), sr, dr, iso, ang, policy=1).dst
+            assert rel_err(idst[:, :, c], g).max() <= 1.5e-7
 
 
 def test_outputs_taller_than_one_grid(gpu, po):

@@ -503,6 +503,28 @@ def test_quad_fp32_replay_against_oracle_at_larger_sizes(aai, hostemu, po):
         hostemu.aai_emu_use_quad(0)
 
 
+def test_double_precision_policy_keeps_requests_off_the_fp32_formulation(aai, hostemu, po):
+    """AAI_POLICY_DOUBLE_PRECISION (include/aai.h): the plan never marks such a request for the fp32 quad kernels, and the
+    double-precision replay is exact to fp32 rounding even where the fp32 formulation has its worst tail (slight up-sampling
+    within a degree of an axis: dst values far below their neighbours)."""
+    W, H, sr, dr, ang, iso = 203, 367, 2.6611805249461478, 2.9963661425245225, 90.69816691569076, (101.0, 183.0)
+    src = np.random.default_rng(5).random((H, W)).astype(np.float32)
+    hostemu.aai_emu_use_quad(1)
+    try:
+        for mode, omode in ((1, po.MODE_EXACT), (2, po.MODE_FAST)):
+            gold = po.oracle_run(omode, src.astype(np.float64), sr, dr, iso, ang, policy=1).dst
+            out, _ = hostemu.resample(aai.make_request(W, H, sr, dr, iso, ang, mode=mode, policy=1), src)
+            assert hostemu.quad_stats()[0] > 0 and rel_err(out, gold).max() <= TOL
+            out, _ = hostemu.resample(aai.make_request(W, H, sr, dr, iso, ang, mode=mode, policy=1 | aai.POLICY_DOUBLE_PRECISION), src)
+            assert hostemu.quad_stats()[0] == 0 and rel_err(out, gold).max() <= 1e-7
+    finally:
+        hostemu.aai_emu_use_quad(0)
+    # the flag is part of the policy word: anything else in it is rejected
+    bad = aai.make_request(W, H, sr, dr, iso, ang, mode=1, policy=2 | aai.POLICY_DOUBLE_PRECISION)
+    rc, msg, lay = aai.query(bad)
+    assert rc == 6 and "policy" in msg        # AAI_ERR_BAD_ARGUMENT
+
+
 def test_quad_serves_the_baseline_rotated_configs(aai, hostemu):
     """configs 3 and 5 take the quad kernel, and so do rotations close to an axis (with the left/right edge's t in double
     precision); wide footprints and angles within ~0.006 degrees of an axis stay on the double-precision kernels"""

@@ -162,7 +162,7 @@ def test_bilinear_restatement_equals_torch_grid_sample(po):
         assert rc == 0, msg
         gold = po.oracle_run(3, src.astype(np.float64), sr, dr, iso, ang).dst
         sx, sy = sample_points(rq, lay, list(range(lay.dst_height)), "cpu")
-        inside = (sx >= -0.5) & (sx <= W - 0.5) & (sy >= -0.5) & (sy <= H - 0.5)
+        inside = (sx >= -0.5 - 1e-9) & (sx <= W - 0.5 + 1e-9) & (sy >= -0.5 - 1e-9) & (sy <= H - 0.5 + 1e-9)      # the samplers' extent guard
         grid = torch.stack(((2 * sx + 1) / W - 1, (2 * sy + 1) / H - 1), dim=-1)[None]
         ref = torch.nn.functional.grid_sample(torch.from_numpy(src).double()[None, None], grid, mode="bilinear", padding_mode="border", align_corners=False)[0, 0]
         ref = torch.where(inside, ref, torch.zeros_like(ref)).numpy()
