@@ -104,6 +104,13 @@ int check_request(const aai_request *rq)
     return AAI_OK;
 }
 
+// K1 row bands keep one more source row on either side where the fix-up pass behind K1 may run (get_plan: verifyAxis):
+// its window includes rows that only touch the dst pixel
+int axis_band_margin(const aai_request &rq)
+{
+    return rq.mode == AAI_MODE_AREA && (rq.policy & ~AAI_POLICY_DOUBLE_PRECISION) == AAI_POLICY_REFERENCE ? 1 : 0;
+}
+
 int pick_kernel(const aai_request &rq, const aai::Geometry &g)
 {
     if (rq.mode == AAI_MODE_BILINEAR || rq.mode == AAI_MODE_BICUBIC) return AAI_KERNEL_SAMPLE;
@@ -244,7 +251,7 @@ int get_plan(const aai_request &rq, int band0, int band1, int channels, Plan **o
     p.srcRow0 = 0; p.srcRow1 = g.H;
     if (p.kernel == AAI_KERNEL_AXIS) {
         aai::build_axis_tables(g, rq.mode, p.tabs, channels);
-        if (band0 >= 0) aai::restrict_axis_tables_to_band(g, p.tabs, band0, band1, p.srcRow0, p.srcRow1);
+        if (band0 >= 0) aai::restrict_axis_tables_to_band(g, p.tabs, band0, band1, p.srcRow0, p.srcRow1, axis_band_margin(rq));
         if (p.tabs.wide) p.kernel = AAI_KERNEL_AXIS_WIDE;
         auto upload = [&](const void *h, size_t bytes, void **d) -> hipError_t {
             if (!bytes) { *d = nullptr; return hipSuccess; }
@@ -258,9 +265,12 @@ int get_plan(const aai_request &rq, int band0, int band1, int channels, Plan **o
         if (e != hipSuccess) { g_plans.pop_front(); return hip_fail(e, "uploading axis tables"); }
         if (p.kernel == AAI_KERNEL_AXIS) tune_axis_plan(p, channels, band0);
     }
-    if (p.kernel == AAI_KERNEL_ROTATED || p.kernel == AAI_KERNEL_FAST) {
-        // one-off scans of this geometry (aai_knife_scan_kernel, and aai_quad_scan_kernel where the fp32 quad kernel
-        // serves it); keeps the flags and the list of flagged waves only if there are any
+    const bool axisKernel = p.kernel == AAI_KERNEL_AXIS || p.kernel == AAI_KERNEL_AXIS_WIDE;
+    // K1's separable weights against the reference's classifier (aai_axis_verify.hpp): area mode under policy REFERENCE
+    const bool verifyAxis = axisKernel && rq.mode == AAI_MODE_AREA && (rq.policy & ~AAI_POLICY_DOUBLE_PRECISION) == AAI_POLICY_REFERENCE;
+    if (p.kernel == AAI_KERNEL_ROTATED || p.kernel == AAI_KERNEL_FAST || verifyAxis) {
+        // one-off scans of this geometry (rotated: aai_knife_scan_kernel, and aai_quad_scan_kernel where the fp32 quad
+        // kernels serve it; axis-aligned: aai_axis_verify_kernel); keeps the list of flagged pixels only if there are any
         const aai::RotLaunch r = aai::make_rot_launch(g, rq.mode, rq.policy);
         const size_t waves = aai::rotated_flag_words(r);
         unsigned long long *dMasks = nullptr;
@@ -271,7 +281,7 @@ int get_plan(const aai_request &rq, int band0, int band1, int channels, Plan **o
             e = hipMalloc((void **)&dMasks, waves * sizeof(unsigned long long));
             if (e == hipSuccess) e = hipMalloc((void **)&dCount, sizeof(unsigned));
             if (e == hipSuccess) e = hipMemset(dCount, 0, sizeof(unsigned));
-            if (e == hipSuccess) e = aai::launch_knife_scan(r, dMasks, dCount, nullptr);
+            if (e == hipSuccess) e = verifyAxis ? aai::launch_axis_verify(r, dMasks, dCount, nullptr) : aai::launch_knife_scan(r, dMasks, dCount, nullptr);
             if (e == hipSuccess && r.quad) e = aai::launch_quad_scan(r, dMasks, dCount, nullptr);
             if (e == hipSuccess) e = hipMemcpy(&count, dCount, sizeof(unsigned), hipMemcpyDeviceToHost);
             // (AAI_MAX_LISTED_PIXELS: test hook, lowers the threshold so that small geometries exercise the dense form)
@@ -294,7 +304,7 @@ int get_plan(const aai_request &rq, int band0, int band1, int channels, Plan **o
             }
             if (dMasks) (void)hipFree(dMasks);
         }
-        if (e != hipSuccess) { g_plans.pop_front(); return hip_fail(e, "knife-edge scan"); }
+        if (e != hipSuccess) { g_plans.pop_front(); return hip_fail(e, verifyAxis ? "axis model scan" : "knife-edge scan"); }
         p.flaggedPixels = count;
     }
     while (g_plans.size() > kMaxPlans) g_plans.pop_back();
@@ -328,20 +338,31 @@ int enqueue(const aai_request &rq, int batch, const void *dSrc, int srcType, int
     aai::ImageView sv{srcStride, srcImageStride}, dv{dstStride, dstImageStride};
     const char *name = "";
     hipError_t e;
-    if (p->kernel == AAI_KERNEL_AXIS || p->kernel == AAI_KERNEL_AXIS_WIDE) {
+    const bool axisKernel = p->kernel == AAI_KERNEL_AXIS || p->kernel == AAI_KERNEL_AXIS_WIDE;
+    // per-pixel launch description: the rotated kernels, and the fix-up pass behind K1
+    aai::RotLaunch r = aai::make_rot_launch(g, rq.mode, rq.policy);
+    if (band0 >= 0) {
+        int srcRow0 = p->srcRow0, srcRow1 = p->srcRow1;
+        if (!axisKernel) aai::rotated_band_source_rows(g, band0, band1, p->kernel == AAI_KERNEL_SAMPLE, srcRow0, srcRow1);
+        r.dyBase = band0; r.dyEnd = band1; r.srcRow0 = srcRow0;
+    }
+    r.chan = channels;
+    if (axisKernel && !p->dense) {
         const aai::AxisLaunch a = make_axis_launch(*p, channels, dstStride);
         e = hipSuccess;
-        for (int b0 = 0; b0 < batch && e == hipSuccess; b0 += kMaxGridZ)       // grid.z carries the batch
-            e = aai::launch_axis(a, src_at(dSrc, srcType, (int64_t)b0 * srcImageStride), srcType, sv, dDst + (int64_t)b0 * dstImageStride, dv,
-                                 std::min(batch - b0, kMaxGridZ), stream, &name);
-    } else {
-        aai::RotLaunch r = aai::make_rot_launch(g, rq.mode, rq.policy);
-        if (band0 >= 0) {
-            int srcRow0 = 0, srcRow1 = g.H;
-            aai::rotated_band_source_rows(g, band0, band1, p->kernel == AAI_KERNEL_SAMPLE, srcRow0, srcRow1);
-            r.dyBase = band0; r.dyEnd = band1; r.srcRow0 = srcRow0;
+        for (int b0 = 0; b0 < batch && e == hipSuccess; b0 += kMaxGridZ) {      // grid.z carries the batch
+            const void *s0 = src_at(dSrc, srcType, (int64_t)b0 * srcImageStride);
+            float *d0 = dDst + (int64_t)b0 * dstImageStride;
+            const int nb = std::min(batch - b0, kMaxGridZ);
+            e = aai::launch_axis(a, s0, srcType, sv, d0, dv, nb, stream, &name);
+            // dst pixels where the reference's classifier departs from the separable model (aai_axis_verify.hpp)
+            if (e == hipSuccess && p->flaggedPixels) {
+                aai::launch_rotated_fixup(r, nb, s0, srcType, sv, d0, dv, static_cast<const uint2 *>(p->dList), p->flaggedPixels, stream);
+                e = hipGetLastError();
+            }
         }
-        r.chan = channels;
+    } else {
+        // (an axis-aligned geometry lands here when the separable model fails for most of its pixels: `dense`)
         const aai::QuadMap qm = aai::make_quad_map(g, srcStride, r.srcRow0, channels, srcType == aai::SRC_U8 ? 1 : srcType == aai::SRC_U16 ? 2 : 4);
         aai::RotFlags flags;
         flags.list = p->dList; flags.count = p->flaggedPixels; flags.dense = p->dense;
@@ -584,7 +605,7 @@ int aai_band_source_rows(const aai_request *req, int32_t dst_row0, int32_t dst_r
     if (kernel == AAI_KERNEL_AXIS) {
         aai::AxisTables t;
         aai::build_axis_tables(g, req->mode, t);
-        aai::restrict_axis_tables_to_band(g, t, dst_row0, dst_row1, a, b);
+        aai::restrict_axis_tables_to_band(g, t, dst_row0, dst_row1, a, b, axis_band_margin(*req));
     } else {
         if (dst_row0 % 16 != 0) return fail(AAI_ERR_BAD_ARGUMENT, "Band start must be a multiple of 16 rows for rotated requests.");
         aai::rotated_band_source_rows(g, dst_row0, dst_row1, kernel == AAI_KERNEL_SAMPLE, a, b);

@@ -61,6 +61,12 @@ struct RotFlags {
 };
 size_t rotated_flag_words(const RotLaunch &r);      // waves of the tiling = 64-bit words of the mask array
 hipError_t launch_knife_scan(const RotLaunch &r, unsigned long long *laneMasks, unsigned *counter, hipStream_t stream);
+// the double-precision fix-up pass over a list of dst pixels (defined in aai_rotated_strict.hip);
+// pixelList == NULL: the whole image (grid as for the production pass, at most 65535 tile rows)
+void launch_rotated_fixup(const RotLaunch &r, int batch, const void *src, int srcType, ImageView sv, float *dst, ImageView dv,
+                          const uint2 *pixelList, unsigned nList, hipStream_t stream);
+// axis-aligned geometries (K1): dst pixels whose weights the separable model gets wrong (aai_axis_verify.hpp), same layout
+hipError_t launch_axis_verify(const RotLaunch &r, unsigned long long *laneMasks, unsigned *counter, hipStream_t stream);
 hipError_t launch_quad_scan(const RotLaunch &r, unsigned long long *laneMasks, unsigned *counter, hipStream_t stream);
 hipError_t launch_flag_list(const unsigned long long *laneMasks, size_t waves, unsigned tilesX, void *list, unsigned *cursor, unsigned capacity,
                             hipStream_t stream);

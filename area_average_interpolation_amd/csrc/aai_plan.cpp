@@ -439,7 +439,7 @@ void build_axis_tables(const Geometry &g, int mode, AxisTables &t, int channels)
 // image larger than device memory).  dst rows run along the row table (quadrants 0, 2) or along the lane table
 // (quadrants 1, 3); the other table is kept whole.  Source rows are re-based to srcRow0 = the first source row any
 // remaining window touches, which is returned together with the row after the last one.
-void restrict_axis_tables_to_band(const Geometry &g, AxisTables &t, int row0, int row1, int &srcRow0, int &srcRow1)
+void restrict_axis_tables_to_band(const Geometry &g, AxisTables &t, int row0, int row1, int &srcRow0, int &srcRow1, int extraRows)
 {
     std::vector<AxisEntry> &rowsOfDst = t.transposed ? t.lane : t.row;     // table indexed by (possibly flipped) dst row
     const bool flip = t.transposed ? t.flipA : t.flipB;
@@ -451,6 +451,8 @@ void restrict_axis_tables_to_band(const Geometry &g, AxisTables &t, int row0, in
     for (const auto &e : t.row)
         if (e.wFirst != 0.f || e.wMid != 0.f || e.wLast != 0.f) { lo = std::min(lo, e.s0); hi = std::max(hi, e.s1); }
     if (hi < lo) { lo = 0; hi = 0; }
+    // (extraRows: the fix-up pass behind K1 may read a source row that only TOUCHES the band's footprint)
+    lo = std::max(0, lo - extraRows); hi = std::min(g.H - 1, hi + extraRows);
     for (auto &e : t.row) { e.s0 = std::max(e.s0, lo) - lo; e.s1 = std::max(e.s1, lo) - lo; }
     srcRow0 = lo; srcRow1 = hi + 1;
     finalize_axis_tables(g, t);

@@ -109,7 +109,7 @@ struct AxisTables {
 
 // mode: AAI_MODE_AREA (overlap lengths) or AAI_MODE_FAST (centre counts).  Only for g.axisAligned.
 void build_axis_tables(const Geometry &g, int mode, AxisTables &t, int channels = 1);
-void restrict_axis_tables_to_band(const Geometry &g, AxisTables &t, int row0, int row1, int &srcRow0, int &srcRow1);
+void restrict_axis_tables_to_band(const Geometry &g, AxisTables &t, int row0, int row1, int &srcRow0, int &srcRow1, int extraRows = 0);
 
 // Source rows [srcRow0, srcRow1) that dst rows [row0,row1) of a rotated-lattice request can touch (conservative).
 void rotated_band_source_rows(const Geometry &g, int row0, int row1, bool sampler, int &srcRow0, int &srcRow1);

@@ -273,9 +273,5 @@ __global__ __launch_bounds__(kRotBlock) void aai_rotated_kernel(RotLaunch r, con
     }
 }
 
-// launches the fix-up pass (defined in aai_rotated_strict.hip)
-// pixelList == NULL: the whole image (grid as for the production pass)
-void launch_rotated_fixup(const RotLaunch &r, int batch, const void *src, int srcType, ImageView sv, float *dst, ImageView dv,
-                          const uint2 *pixelList, unsigned nList, hipStream_t stream);
 
 }  // namespace aai

@@ -115,6 +115,8 @@ def hostemu(aai):
     lib.aai_emu_missed_knife_pairs.restype = ctypes.c_long
     lib.aai_emu_missed_knife_pairs.argtypes = []
     # the fp32 quad formulation of the rotated area kernel (csrc/aai_rot_quad.hpp)
+    lib.aai_emu_axis_fixups.restype = ctypes.c_long
+    lib.aai_emu_skip_axis_fixup.argtypes = [ctypes.c_int]
     lib.aai_emu_use_quad.restype = None
     lib.aai_emu_use_quad.argtypes = [ctypes.c_int]
     lib.aai_emu_quad_stats.restype = None
@@ -150,6 +152,15 @@ def small_golden():
 def knife_golden():
     """outputs of the UNMODIFIED reference on the structured knife-edge geometries (tests/golden/make_golden.py knife)"""
     z = np.load(os.path.join(GOLDEN, "knife_cases.npz"))
+    manifest = json.loads(bytes(z["manifest"]).decode())
+    return z, manifest
+
+
+@pytest.fixture(scope="session")
+def axis_knife_golden():
+    """outputs of the UNMODIFIED reference at rotations 0/90/180/270 with edges on pixel boundaries / through pixel centres
+    (tests/golden/make_golden.py axisknife)"""
+    z = np.load(os.path.join(GOLDEN, "axis_knife_cases.npz"))
     manifest = json.loads(bytes(z["manifest"]).decode())
     return z, manifest
 

@@ -15,6 +15,7 @@
 #include "../../area_average_interpolation_amd/csrc/aai_rot_math.hpp"
 #include "../../area_average_interpolation_amd/csrc/aai_strict.hpp"
 #include "../../area_average_interpolation_amd/csrc/aai_rot_quad.hpp"
+#include "../../area_average_interpolation_amd/csrc/aai_axis_verify.hpp"
 
 using namespace aai;
 
@@ -236,6 +237,8 @@ static int emu_axis_channels(const Geometry &g, int mode, int C, const float *sr
 static int g_forceGeneral = 0;   // test hook: route every cut pair through pair_area (cross-checks the closed form)
 static int g_strict = 1;         // test hook: 0 = production pass only, 1 = production + knife-edge fix-up pass
 static long g_knifePairs = 0, g_knifePixels = 0, g_missedPairs = 0;
+static int g_skipAxisFixup = 0;  // test hook: K1's separable weights alone, without the fix-up pass behind them
+static int g_forceRotated = 0;   // test hook: axis-aligned requests take the per-pixel path (production pass + knife-edge fix-up) too
 static int g_useQuad = 0;        // test hook: 1 = unflagged area-mode pixels take the fp32 quad formulation (aai_rot_quad.hpp) like the GPU does
 static long g_quadPixels = 0, g_quadUncertain = 0;   // pixels answered by the quad path / left to the double-precision path by its scan
 
@@ -290,7 +293,11 @@ static bool emu_quad_fast_pixel(const QuadConsts<float> &qc, const RotLaunch &r,
     return true;
 }
 
-static void emu_rotated(const Geometry &g, const aai_request &rq, const float *img, int64_t srcStride, float *dst, int64_t dstStride)
+static long g_axisFixups = 0;      // dst pixels of the last axis-aligned request recomputed by the fix-up pass
+// onlyAxisDiffering: the fix-up pass behind K1 -- only the dst pixels where the separable model departs from the
+// reference's classifier (aai_axis_verify.hpp) are computed, the others keep what K1 wrote
+static void emu_rotated(const Geometry &g, const aai_request &rq, const float *img, int64_t srcStride, float *dst, int64_t dstStride,
+                        bool onlyAxisDiffering = false)
 {
     const RotLaunch r = make_rot_launch(g, rq.mode, rq.policy);
     g_knifePairs = g_knifePixels = g_missedPairs = 0;
@@ -305,6 +312,10 @@ static void emu_rotated(const Geometry &g, const aai_request &rq, const float *i
             const double hb = r.h * (r.c + r.s);
             const int x0 = std::max(0, (int)std::floor(px - hb + 0.5 - AAI_KNIFE_GUARD)), x1 = std::min(r.mW - 1, (int)std::ceil(px + hb - 0.5 + AAI_KNIFE_GUARD));
             const int y0 = std::max(0, (int)std::floor(py - hb + 0.5 - AAI_KNIFE_GUARD)), y1 = std::min(r.mH - 1, (int)std::ceil(py + hb - 0.5 + AAI_KNIFE_GUARD));
+            if (onlyAxisDiffering) {
+                if (!axis_pixel_differs(r, dx, dy)) continue;
+                ++g_axisFixups;
+            }
             float *out = dst + (int64_t)dy * dstStride + dx;
             SVec sv4[4];
             bool haveVertices = false;
@@ -500,11 +511,16 @@ int aai_emu_resample(const aai_request *rq, const float *src, float *dst, int *d
     int rc = make_geometry(*rq, g, msg);
     if (rc != AAI_OK) return rc;
     *dW = g.dW; *dH = g.dH;
-    const bool axis = g.axisAligned && (rq->mode == AAI_MODE_AREA || rq->mode == AAI_MODE_FAST);
+    const bool axis = g.axisAligned && !g_forceRotated && (rq->mode == AAI_MODE_AREA || rq->mode == AAI_MODE_FAST);
     if (usedAxisPath) *usedAxisPath = axis ? 1 : 0;
     if (!dst || !g.dW || !g.dH) return AAI_OK;
-    if (axis) emu_axis(g, rq->mode, src, g.W, dst, g.dW);
-    else emu_rotated(g, *rq, src, g.W, dst, g.dW);
+    g_axisFixups = 0;
+    if (axis) {
+        emu_axis(g, rq->mode, src, g.W, dst, g.dW);
+        // (mirrors get_plan / enqueue in aai_capi.cpp: area mode under policy REFERENCE)
+        if (rq->mode == AAI_MODE_AREA && (rq->policy & ~AAI_POLICY_DOUBLE_PRECISION) == AAI_POLICY_REFERENCE && !g_skipAxisFixup)
+            emu_rotated(g, *rq, src, g.W, dst, g.dW, true);
+    } else emu_rotated(g, *rq, src, g.W, dst, g.dW);
     return AAI_OK;
 }
 
@@ -569,6 +585,9 @@ int aai_emu_resample_channels(const aai_request *rq, int C, const float *src, fl
 
 void aai_emu_force_general(int on) { g_forceGeneral = on; }
 void aai_emu_use_quad(int on) { g_useQuad = on; }
+void aai_emu_force_rotated(int on) { g_forceRotated = on; }
+void aai_emu_skip_axis_fixup(int on) { g_skipAxisFixup = on; }
+long aai_emu_axis_fixups() { return g_axisFixups; }
 
 int aai_emu_quad_pixel_debug(const aai_request *rq, int dx, int dy, const float *img, double *out4)
 {

@@ -9,6 +9,7 @@ source text.  Run from the repo root in the build container (the reference is ab
     python tests/golden/make_golden.py small          # tests/golden/small_cases.npz      (seconds)
     python tests/golden/make_golden.py errors         # tests/golden/error_paths.json
     python tests/golden/make_golden.py knife          # tests/golden/knife_cases.npz      (structured knife-edge geometries)
+    python tests/golden/make_golden.py axisknife      # tests/golden/axis_knife_cases.npz (the same at rotations 0/90/180/270)
     python tests/golden/make_golden.py full cfg2      # tests/golden/full_cfg2.npz         (minutes, 1 core)
     python tests/golden/make_golden.py full all       # every BASELINE.json config that is CPU-feasible
     python tests/golden/make_golden.py oraclefull cfg5  # full-size config 5 through the CPU oracle (8 processes, minutes)
@@ -121,6 +122,40 @@ def gen_knife():
         manifest.append(entry)
     store["manifest"] = np.frombuffer(json.dumps(manifest).encode(), dtype=np.uint8)
     path = os.path.join(HERE, "knife_cases.npz")
+    np.savez_compressed(path, **store)
+    print("wrote", path, os.path.getsize(path), "bytes,", len(cases), "cases")
+
+
+def axis_knife_case_list():
+    """Axis-aligned rotations with edges exactly on pixel boundaries or through pixel centres (integer and half-integer
+    ratios, isocenters on centres / corners / quarter pixels, odd and even sizes): there the reference's classifier
+    (Source.cpp:986-1431) departs from the product of the two clipped extents in a few places -- a dst vertex on the
+    midpoint of a pixel side returns the whole pixel -- which is what the scan behind the separable kernel must find."""
+    cases = []
+    for (W, H) in ((120, 7), (24, 13), (16, 16), (27, 27), (40, 9), (23, 7), (31, 30)):
+        for (sr, dr) in ((5, 1), (3, 1), (7, 1), (2, 1), (5, 2)):
+            for kind in range(3):
+                iso = [((W - 1) / 2, (H - 1) / 2), (W / 3 + 0.25, H / 4), (float(W // 3), float(H // 2))][kind]
+                for ang in (0.0, 90.0, 180.0, 270.0):
+                    cases.append(dict(W=W, H=H, seed=2000 + len(cases), src_res=float(sr), dst_res=float(dr),
+                                      iso=[float(iso[0]), float(iso[1])], angle=ang))
+    return cases
+
+
+def gen_axis_knife():
+    cases = axis_knife_case_list()
+    store, manifest = {}, []
+    for i, c in enumerate(cases):
+        src = po.synth_image(c["W"], c["H"], c["seed"]).astype(np.float64)
+        r = po.ref_run(po.MODE_EXACT, src, c["src_res"], c["dst_res"], c["iso"], c["angle"])        # the UNMODIFIED reference
+        assert r.ok, r.msg
+        entry = dict(c)
+        store["a%03d_exact" % i] = r.dst
+        entry["dst_iso"] = list(r.dst_iso)
+        entry["shape"] = list(r.dst.shape)
+        manifest.append(entry)
+    store["manifest"] = np.frombuffer(json.dumps(manifest).encode(), dtype=np.uint8)
+    path = os.path.join(HERE, "axis_knife_cases.npz")
     np.savez_compressed(path, **store)
     print("wrote", path, os.path.getsize(path), "bytes,", len(cases), "cases")
 
@@ -252,6 +287,8 @@ if __name__ == "__main__":
         gen_small()
     elif what == "errors":
         gen_errors()
+    elif what == "axisknife":
+        gen_axis_knife()
     elif what == "knife":
         gen_knife()
     elif what == "oraclefull":

@@ -308,6 +308,58 @@ def test_knife_edge_geometries_against_reference_goldens(gpu, po, knife_golden):
             assert np.array_equal(gold == 0, dst == 0), (i, tag, c)
 
 
+def test_axis_aligned_knife_geometries_against_reference_goldens(gpu, po, axis_knife_golden):
+    """Rotations 0/90/180/270 with edges on pixel boundaries / through pixel centres against outputs of the UNMODIFIED
+    reference (tests/golden/axis_knife_cases.npz): K1 plus the fix-up pass over the dst pixels the plan's model scan
+    flags (csrc/aai_axis_verify.hpp) -- no pixel excepted.  Also as 16-bit and as interleaved images (same plan family,
+    fix-up with channels), in a batch with padded strides, and as row bands from footprint-only buffers."""
+    import torch
+    z, manifest = axis_knife_golden
+    st = torch.cuda.current_stream().cuda_stream
+    for i, c in enumerate(manifest):
+        src = po.synth_image(c["W"], c["H"], c["seed"])
+        dst, iso, lay = _host(gpu, src, c, 1)
+        gold = z["a%03d_exact" % i]
+        assert dst.shape == gold.shape and list(iso) == c["dst_iso"], i
+        assert "axis" in gpu.last_kernel()
+        assert rel_err(dst, gold).max() <= 1e-6 and np.array_equal(gold == 0, dst == 0), (i, c, float(rel_err(dst, gold).max()))
+        if i % 7:
+            continue
+        # interleaved: channel 1 = the image, channels 0 / 2 = something else
+        inter = np.stack([src[::-1, ::-1], src, 1.0 - src], axis=2).astype(np.float32)
+        rc, msg, idst, ilay = gpu.resample_interleaved_host(inter, c["src_res"], c["dst_res"], tuple(c["iso"]), c["angle"], mode=1)
+        assert rc == 0 and rel_err(idst[:, :, 1], gold).max() <= 1e-6, (i, c)
+        # a batch of two with padded strides
+        H, W = src.shape
+        rq = gpu.make_request(W, H, c["src_res"], c["dst_res"], tuple(c["iso"]), c["angle"], mode=1)
+        dH, dW = gold.shape
+        bsrc = torch.zeros((2, H + 1, W + 5), dtype=torch.float32, device="cuda")
+        bsrc[0, :H, :W] = torch.from_numpy(src).cuda()
+        bsrc[1, :H, :W] = torch.from_numpy(src[::-1].copy()).cuda()
+        bdst = torch.full((2, dH + 2, dW + 3), -1.0, dtype=torch.float32, device="cuda")
+        gpu.resample_device(rq, bsrc.data_ptr(), W + 5, bdst.data_ptr(), dW + 3, st, batch=2,
+                            src_image_stride=(H + 1) * (W + 5), dst_image_stride=(dH + 2) * (dW + 3))
+        torch.cuda.synchronize()
+        assert np.array_equal(bdst[0, :dH, :dW].cpu().numpy(), dst)
+        # row bands from buffers that hold only their footprint
+        if dH >= 2:
+            r0 = dH // 2
+            for (b0, b1) in ((0, r0), (r0, dH)):
+                a, b = gpu.band_source_rows(rq, b0, b1)
+                band_src = torch.from_numpy(src[a:b].copy()).cuda()
+                band_dst = torch.empty((b1 - b0, dW), dtype=torch.float32, device="cuda")
+                gpu.resample_band_device(rq, b0, b1, band_src.data_ptr(), W, band_dst.data_ptr(), dW, st)
+                torch.cuda.synchronize()
+                assert np.array_equal(band_dst.cpu().numpy(), dst[b0:b1]), (i, c, b0, b1, a, b)
+    # 16-bit sources through the same plans
+    for i in (0, 61, 122, 183):
+        c = manifest[i]
+        src16 = (po.synth_image(c["W"], c["H"], c["seed"]) * 65535).astype(np.uint16)
+        gold = po.oracle_run(po.MODE_EXACT, src16.astype(np.float64), c["src_res"], c["dst_res"], tuple(c["iso"]), c["angle"]).dst
+        rc, msg, dst, _, lay = gpu.resample_host(src16, c["src_res"], c["dst_res"], tuple(c["iso"]), c["angle"], mode=1)
+        assert rc == 0 and rel_err(dst, gold, floor=65.5).max() <= 1e-6, (i, c)
+
+
 # ---- (c) properties at full BASELINE sizes -------------------------------------------------------------------
 def _device_run(gpu, rq, src, batch=None):
     import torch
