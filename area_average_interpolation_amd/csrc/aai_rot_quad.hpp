@@ -56,8 +56,10 @@ struct QuadConsts {
     int ref;                          // 1 = AAI_POLICY_REFERENCE
     int win;                          // window positions per axis, <= kQuadMaxWin
     // Close to an axis (min(c,s) small) the reference's corner-triangle rule has slope ~1/(2 min(c,s)) in t, far too
-    // steep for fp32 coordinates: hiPrec evaluates the left/right edge's t = h + k - |a| in double precision from the
-    // centre's double-precision fraction (three fp64 operations per pair) and only then rounds it to F.
+    // steep for fp32 coordinates, and under either policy the thin corner triangles (area t^2 / (2 c s), t tiny) need t to
+    // a RELATIVE accuracy fp32 differences of numbers near 1 do not have: hiPrec evaluates both edges' t = h + k - |a|,
+    // h + k - |b| in double precision from the centre's double-precision fraction (three fp64 operations each per pair)
+    // and only then rounds them to F.
     int hiPrec;
     F marginT;                        // SCAN, hiPrec: margin of the t thresholds lo / hi taken on the precise t
     double cD, sD, hpkD;
@@ -67,7 +69,7 @@ struct QuadConsts {
 // most the window size, two fused multiply-adds on magnitudes <= hb + 1, the centre's own fraction (see quad_pixel)
 AAI_HD double quad_coord_eps(double side, double c, double s) { return 1.1920929e-7 * (2.0 + 0.5 * side * (c + s)); }
 
-// Does fp32 carry the left/right edge's t?  The steepest area formula -- the reference's corner-triangle rule, slope
+// Does fp32 carry the edges' t?  The steepest area formula -- the reference's corner-triangle rule, slope
 // (1/c + 1/s)/2 in t -- must keep a coordinate error of quad_coord_eps below ~1.5e-7 of the dst value (weights sum to about
 // L^2; pixel values differ from their mean by a few tenths).  Closer to the axes than that (reduced angle within a few
 // degrees of 0 or 90) t is taken in double precision (QuadConsts::hiPrec).
@@ -112,7 +114,7 @@ AAI_HD QuadConsts<F> make_quad_consts(double side, double c, double s, int polic
     q.minArea = (F)(side * side < 4.0 ? 0.25 * side * side : 1.0);
     q.ref = policy == AAI_POLICY_REFERENCE ? 1 : 0;
     q.win = (int)floor(2.0 * (hb - 0.5 + 1e-5)) + 3;
-    q.hiPrec = (q.ref && quad_needs_hiprec(side, c, s)) ? 1 : 0;
+    q.hiPrec = quad_needs_hiprec(side, c, s) ? 1 : 0;
     q.marginT = (F)(1e-6 * lo);
     q.cD = c; q.sD = s; q.hpkD = h + k;
     return q;
@@ -154,10 +156,10 @@ AAI_HD F quad_cut(const QuadConsts<F> &q, F t, bool substitute)
 // canonical orientation (u, v) the left/right edge.  nearS (SCAN): distance of the closest live sign test from
 // its threshold.
 template <typename F, bool SCAN>
-AAI_HD F quad_double(const QuadConsts<F> &q, F A, F B, F tpA, bool flipA, F tB, bool sameSign, F &nearS)
+AAI_HD F quad_double(const QuadConsts<F> &q, F A, F B, F tpA, bool flipA, F tpB, bool flipB, bool sameSign, F &nearS)
 {
-    // (tpA, flipA) = the left/right edge's t = A + k in mirrored form (quad_cut_tp; from double precision under hiPrec);
-    // tB = B + k clamped to [0, c + s]
+    // (tpA, flipA), (tpB, flipB) = the left/right and the top/bottom edge's t = A + k, B + k in mirrored form
+    // (quad_cut_tp; from double precision under hiPrec)
     const F u = sameSign ? A : B, v = sameSign ? B : A;
     // V relative to the pixel centre along the pixel's own axes, in the orientation where the square lies
     // towards -x, -y of V: edge 1 runs from V towards -y, edge 2 towards -x
@@ -172,7 +174,7 @@ AAI_HD F quad_double(const QuadConsts<F> &q, F A, F B, F tpA, bool flipA, F tB, 
     }
     // the reference's corner rule applies to a left/right edge that crosses the pixel ALONE (edge 1 iff sameSign)
     const F gA = quad_cut_tp(q, tpA, flipA, q.ref != 0 && (sameSign ? !S2 : !S1));
-    const F gB = quad_cut(q, tB, false);
+    const F gB = quad_cut_tp(q, tpB, flipB, false);
     const F g1 = sameSign ? gA : gB, g2 = sameSign ? gB : gA;
     const F both = qmax(g1 + g2 - F(1), F(0));
     return S1 ? (S2 ? both : g1) : (S2 ? g2 : F(0));
@@ -275,11 +277,14 @@ AAI_HD bool quad_pixel(const QuadConsts<F> &q, int Xc, int Yc, double dfx, doubl
 
     // dst-frame coordinates of pixel (Xc, Yc)'s centre: (ex, ey) = -(fpx, fpy)
     const F ac = qfma(fpy, q.s, -(fpx * q.c)), bc = -qfma(fpx, q.s, fpy * q.c);
-    const double acD = qfma(dfy, q.sD, -(dfx * q.cD));        // hiPrec: the left/right coordinate in double precision
-    // the left/right edge's t = h + k - |a| for window position (fi, fj) in double precision, clamped to [0, c + s] and
-    // mirrored about k there as well (near an axis both t and c + s - t can be tiny differences of numbers near 1)
-    auto precise_tp = [&](F fi, F fj, bool &flip) -> F {
-        const double ad = qfma((double)fi, q.cD, qfma(-(double)fj, q.sD, acD));
+    // hiPrec: both dst-frame coordinates of (Xc, Yc) in double precision
+    const double acD = qfma(dfy, q.sD, -(dfx * q.cD)), bcD = -qfma(dfx, q.sD, dfy * q.cD);
+    // an edge's t = h + k - |coordinate| for window position (fi, fj) in double precision (lr: the left/right edge, else
+    // the top/bottom edge), clamped to [0, c + s] and mirrored about k there as well -- near an axis both t and c + s - t
+    // can be tiny differences of numbers near 1, and the thin corner triangles they describe (area t^2 / (2 c s)) are
+    // where a dst value far below its neighbours gets its relative accuracy from
+    auto precise_tp = [&](F fi, F fj, bool lr, bool &flip) -> F {
+        const double ad = lr ? qfma((double)fi, q.cD, qfma(-(double)fj, q.sD, acD)) : qfma((double)fi, q.sD, qfma((double)fj, q.cD, bcD));
         double t = q.hpkD - (ad < 0.0 ? -ad : ad);
         const double k2 = q.cD + q.sD;
         t = t < 0.0 ? 0.0 : (t > k2 ? k2 : t);
@@ -358,12 +363,8 @@ AAI_HD bool quad_pixel(const QuadConsts<F> &q, int Xc, int Yc, double dfx, doubl
         F tp = qmin(t, q.k2 - t);
         bool flip = t > q.k;
         if (HP) {
-            bool pf;
-            const F pt = precise_tp(fi, fj, pf);
-            if (isLR) {
-                tp = pt; flip = pf;
-                if (SCAN && qabs(pt - q.lo) < q.marginT) uncertain = true;
-            }
+            tp = precise_tp(fi, fj, isLR, flip);
+            if (SCAN && isLR && q.ref != 0 && qabs(tp - q.lo) < q.marginT) uncertain = true;
         }
         const F area = quad_cut_tp(q, tp, flip, isLR && q.ref != 0);
         sumA += area;
@@ -379,13 +380,14 @@ AAI_HD bool quad_pixel(const QuadConsts<F> &q, int Xc, int Yc, double dfx, doubl
         F nearS = F(1);
         const F A = q.h - qabs(a), B = q.h - qabs(b);
         const F tA = qmin(qmax(A + q.k, F(0)), q.k2), tB = qmin(qmax(B + q.k, F(0)), q.k2);
-        F tpA = qmin(tA, q.k2 - tA);
-        bool flipA = tA > q.k;
+        F tpA = qmin(tA, q.k2 - tA), tpB = qmin(tB, q.k2 - tB);
+        bool flipA = tA > q.k, flipB = tB > q.k;
         if (HP) {
-            tpA = precise_tp(fi, fj, flipA);
-            if (SCAN && qabs(tpA - q.lo) < q.marginT) uncertain = true;
+            tpA = precise_tp(fi, fj, true, flipA);
+            tpB = precise_tp(fi, fj, false, flipB);
+            if (SCAN && q.ref != 0 && qabs(tpA - q.lo) < q.marginT) uncertain = true;
         }
-        const F area = quad_double<F, SCAN>(q, A, B, tpA, flipA, tB, (a < F(0)) == (b < F(0)), nearS);
+        const F area = quad_double<F, SCAN>(q, A, B, tpA, flipA, tpB, flipB, (a < F(0)) == (b < F(0)), nearS);
         if (SCAN && nearS < q.margin) uncertain = true;
         sumA += area;
         accumulate(area, slot);

@@ -661,7 +661,7 @@ long aai_emu_quad_pair_check(const aai_request *rq, double *maxOld, double *maxS
                     else {
                         double nearS;
                         const double tA = std::min(std::max(A + q.k, 0.0), q.k2), tB = std::min(std::max(B + q.k, 0.0), q.k2);
-                        area = quad_double<double, false>(q, A, B, std::min(tA, q.k2 - tA), tA > q.k, tB, (a < 0) == (b < 0), nearS);
+                        area = quad_double<double, false>(q, A, B, std::min(tA, q.k2 - tA), tA > q.k, std::min(tB, q.k2 - tB), tB > q.k, (a < 0) == (b < 0), nearS);
                     }
                     *maxOld = std::max(*maxOld, std::fabs(area - old));
                     if (!flagged) *maxStrict = std::max(*maxStrict, std::fabs(area - strict_pair_area(sv4, X, Y, r.policy)));
