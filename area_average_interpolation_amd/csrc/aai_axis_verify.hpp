@@ -7,8 +7,11 @@
 // makes it return the whole pixel where half of it is covered.  Such pixels cannot be written as a product and
 // change the normalisation of every weight of their dst pixel.
 //
+// Fast mode has the same problem with centres exactly ON a dst edge or vertex: the reference's ray cast is not the product
+// of two closed intervals there.
+//
 // So, once per geometry, the plan compares the two models pair by pair for every dst pixel that has a knife edge at all
-// (policy REFERENCE, area mode): the reference's side is exactly what the fix-up pass (aai_rotated_kernel<AREA, STRICT>)
+// (area mode under either policy -- they differ in the corner-triangle rule of a slanted edge only -- and fast mode): the reference's side is exactly what the fix-up pass (aai_rotated_kernel<AREA, STRICT>)
 // computes, the other side is the product of the two clipped extents.  Dst pixels where any pair differs are recomputed by
 // that fix-up pass behind K1; at 8192^2 -> 2048^2 (every edge on a pixel boundary, every vertex on a pixel corner)
 // none differs.  Shared by the plan-time scan kernel and the CPU replay of the test-suite.
@@ -18,6 +21,32 @@
 
 namespace aai {
 
+// K1's fast-mode membership along one axis: is the centre of virtual pixel X inside the closed interval [lo, hi] of a
+// dst pixel?  The reference decides with ray / edge parameters compared against +-DBL_EPSILON (Source.cpp:857): the
+// parameter along a dst edge is s = (X - lo) / (hi - lo) and must satisfy -eps < s < 1 + eps; the ray parameter
+// r = distance / 100 must satisfy r > -eps.  (Used by the table builder in aai_plan.cpp and by the scan below.)
+AAI_HD bool axis_centre_inside(double lo, double hi, int X)
+{
+    const double s = (-100.0 * (lo - X)) / (100.0 * (hi - lo));
+    if (!(-DBL_EPSILON < s && s < 1 + DBL_EPSILON)) return false;
+    return (X - lo) / 100.0 > -DBL_EPSILON && (hi - X) / 100.0 > -DBL_EPSILON;
+}
+
+// the edges K1's tables give dst pixel (dx, dy) (aai_plan.cpp: edge_along_x / edge_along_y)
+AAI_HD void axis_pixel_edges(const RotLaunch &r, int dx, int dy, double &lox, double &hix, double &loy, double &hiy)
+{
+    double px, py, qx, qy;
+    pixel_centre(r, dx, 0, px, py);
+    lox = px - r.h * (r.tcs + r.tsn);
+    if (dx + 1 < r.dW) { pixel_centre(r, dx + 1, 0, qx, qy); hix = qx - r.h * (r.tcs + r.tsn); }
+    else hix = px + r.h * (r.tcs - r.tsn);
+    pixel_centre(r, 0, dy, px, py);
+    loy = py - r.h * (r.tcs - r.tsn);
+    if (dy + 1 < r.dH) { pixel_centre(r, 0, dy + 1, qx, qy); hiy = qy - r.h * (r.tcs - r.tsn); }
+    else hiy = py + r.h * (r.tcs + r.tsn);
+}
+
+// area mode
 AAI_HD bool axis_pixel_differs(const RotLaunch &r, int dx, int dy)
 {
     double px, py;
@@ -28,6 +57,7 @@ AAI_HD bool axis_pixel_differs(const RotLaunch &r, int dx, int dy)
     const int y0 = (int)fmax(0.0, floor(py - hb + 0.5 - AAI_KNIFE_GUARD)), y1 = (int)fmin((double)(r.mH - 1), ceil(py + hb - 0.5 + AAI_KNIFE_GUARD));
     SVec sv4[4];
     bool haveVertices = false;
+    double sumStrict = 0.0, sumProduct = 0.0;
     for (int Y = y0; Y <= y1; ++Y) {
         const double oy = fmax(0.0, fmin(py + r.h, Y + 0.5) - fmax(py - r.h, Y - 0.5));
         for (int X = x0; X <= x1; ++X) {
@@ -48,8 +78,44 @@ AAI_HD bool axis_pixel_differs(const RotLaunch &r, int dx, int dy)
             }
             const double ox = fmax(0.0, fmin(px + r.h, X + 0.5) - fmax(px - r.h, X - 0.5));
             if (fabs(area - ox * oy) > 1e-9) return true;
+            sumStrict += area; sumProduct += ox * oy;
         }
     }
+    // A dst pixel that only grazes the lattice (total area ~1e-14 from an extent that should be zero): the reference still
+    // divides one rounding residue by another (Source.cpp:577 asks for DBL_EPSILON < sum only) -- leave it to the replay.
+    return (sumStrict > 0.0 || sumProduct > 0.0) && (sumStrict < 1e-6 || sumProduct < 1e-6);
+}
+
+// fast mode: the membership of every centre in the window, replay of the reference's ray cast (aai_rotated_kernel<fast,
+// STRICT>) against the per-axis rule of K1's tables
+AAI_HD bool axis_pixel_differs_fast(const RotLaunch &r, int dx, int dy)
+{
+    double px, py;
+    pixel_centre(r, dx, dy, px, py);
+    if (!pixel_on_knife_edge(r, px, py, false)) return false;
+    double lox, hix, loy, hiy;
+    axis_pixel_edges(r, dx, dy, lox, hix, loy, hiy);
+    const bool span = hix > lox && hiy > loy;
+    const double hb = r.h * (r.c + r.s);
+    const int x0 = (int)fmax(0.0, floor(px - hb + 0.5 - AAI_KNIFE_GUARD)), x1 = (int)fmin((double)(r.mW - 1), ceil(px + hb - 0.5 + AAI_KNIFE_GUARD));
+    const int y0 = (int)fmax(0.0, floor(py - hb + 0.5 - AAI_KNIFE_GUARD)), y1 = (int)fmin((double)(r.mH - 1), ceil(py + hb - 0.5 + AAI_KNIFE_GUARD));
+    const double lim = r.h + DBL_EPSILON * r.side;
+    SVec sv4[4];
+    bool haveVertices = false;
+    for (int Y = y0; Y <= y1; ++Y)
+        for (int X = x0; X <= x1; ++X) {
+            const double ex = X - px, ey = Y - py;
+            const double a = fabs(ex * r.c - ey * r.s), b = fabs(ex * r.s + ey * r.c);
+            bool in = a <= lim && b <= lim;
+            const bool edgy = (fabs(a - r.h) < AAI_KNIFE_GUARD && b <= r.h + AAI_KNIFE_GUARD) || (fabs(b - r.h) < AAI_KNIFE_GUARD && a <= r.h + AAI_KNIFE_GUARD);
+            if (edgy) {
+                if (!haveVertices) { strict_vertices(r, dx, dy, sv4); haveVertices = true; }
+                SVec pc; pc.x = X; pc.y = Y;
+                in = strict_centre_inside(pc, sv4);
+            }
+            const bool model = span && axis_centre_inside(lox, hix, X) && axis_centre_inside(loy, hiy, Y);
+            if (in != model) return true;
+        }
     return false;
 }
 

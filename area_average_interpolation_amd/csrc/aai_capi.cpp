@@ -108,7 +108,7 @@ int check_request(const aai_request *rq)
 // its window includes rows that only touch the dst pixel
 int axis_band_margin(const aai_request &rq)
 {
-    return rq.mode == AAI_MODE_AREA && (rq.policy & ~AAI_POLICY_DOUBLE_PRECISION) == AAI_POLICY_REFERENCE ? 1 : 0;
+    return rq.mode == AAI_MODE_AREA || rq.mode == AAI_MODE_FAST ? 1 : 0;
 }
 
 int pick_kernel(const aai_request &rq, const aai::Geometry &g)
@@ -266,8 +266,9 @@ int get_plan(const aai_request &rq, int band0, int band1, int channels, Plan **o
         if (p.kernel == AAI_KERNEL_AXIS) tune_axis_plan(p, channels, band0);
     }
     const bool axisKernel = p.kernel == AAI_KERNEL_AXIS || p.kernel == AAI_KERNEL_AXIS_WIDE;
-    // K1's separable weights against the reference's classifier (aai_axis_verify.hpp): area mode under policy REFERENCE
-    const bool verifyAxis = axisKernel && rq.mode == AAI_MODE_AREA && (rq.policy & ~AAI_POLICY_DOUBLE_PRECISION) == AAI_POLICY_REFERENCE;
+    // K1's separable model against the reference's classifier (aai_axis_verify.hpp).  Both policies: they differ in the
+    // corner-triangle rule of a slanted left/right edge only, which does not exist at multiples of 90 degrees.
+    const bool verifyAxis = axisKernel && axis_band_margin(rq) != 0;
     if (p.kernel == AAI_KERNEL_ROTATED || p.kernel == AAI_KERNEL_FAST || verifyAxis) {
         // one-off scans of this geometry (rotated: aai_knife_scan_kernel, and aai_quad_scan_kernel where the fp32 quad
         // kernels serve it; axis-aligned: aai_axis_verify_kernel); keeps the list of flagged pixels only if there are any
@@ -654,15 +655,17 @@ void aai_debug_axis_tune(const char *spec) { aai::set_axis_tune(spec); }
 
 const char *aai_debug_plan_shape(const aai_request *req)
 {
-    // "rows=R nt=N swap=S" of the cached K1 plan of this request on the current device ("" when there is none)
+    // "kernel=K rows=R nt=N swap=S flagged=F dense=D" of the cached whole-image plan of this request on the current device
+    // ("" when there is none)
     static thread_local std::string text;
     text.clear();
     int dev = -1;
     if (!req || hipGetDevice(&dev) != hipSuccess) return text.c_str();
     std::lock_guard<std::mutex> lock(g_planMutex);
     for (const Plan &p : g_plans)
-        if (p.device == dev && p.band0 < 0 && p.channels == 1 && same_request(p.key, *req) && p.kernel == AAI_KERNEL_AXIS)
-            text = "rows=" + std::to_string(p.tuneRows) + " nt=" + std::to_string(p.tuneNt) + " swap=" + std::to_string(p.tuneSwap);
+        if (p.device == dev && p.band0 < 0 && p.channels == 1 && same_request(p.key, *req))
+            text = "kernel=" + std::to_string(p.kernel) + " rows=" + std::to_string(p.tuneRows) + " nt=" + std::to_string(p.tuneNt) + " swap=" + std::to_string(p.tuneSwap) +
+                   " flagged=" + std::to_string(p.flaggedPixels) + " dense=" + std::to_string(p.dense ? 1 : 0);
     return text.c_str();
 }
 

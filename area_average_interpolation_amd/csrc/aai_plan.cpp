@@ -2,6 +2,7 @@
 // kernel.  Double precision throughout; mirrors Source.cpp:112-305 of the reference.
 #include "aai_plan.hpp"
 #include "aai_rot_quad.hpp"
+#include "aai_axis_verify.hpp"
 
 #include <algorithm>
 #include <cfloat>
@@ -274,11 +275,7 @@ VirtRange fast_range(double lo, double hi, int m)
 {
     VirtRange r;
     if (!(hi > lo)) return r;
-    auto inside = [&](int X) {
-        const double s = (-100.0 * (lo - X)) / (100.0 * (hi - lo));
-        if (!(-kEps < s && s < 1 + kEps)) return false;
-        return (X - lo) / 100.0 > -kEps && (hi - X) / 100.0 > -kEps;
-    };
+    auto inside = [&](int X) { return axis_centre_inside(lo, hi, X); };
     int a = (int)std::ceil(lo) - 1, b = (int)std::floor(hi) + 1;
     a = std::max(a, 0); b = std::min(b, m - 1);
     while (a <= b && !inside(a)) ++a;

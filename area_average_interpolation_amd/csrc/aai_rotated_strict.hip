@@ -11,13 +11,14 @@ namespace aai {
 
 // Plan-time scan of an axis-aligned geometry (K1): one bit per dst pixel whose weights the separable model gets wrong
 // (aai_axis_verify.hpp), in the 16 x 16 tiling and mask layout of aai_knife_scan_kernel; counter[0] counts them.
+template <bool FAST>
 __global__ __launch_bounds__(kRotBlock) void aai_axis_verify_kernel(RotLaunch r, unsigned long long *__restrict__ laneMasks, unsigned *__restrict__ counter, int tileRow0)
 {
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int dx = blockIdx.x * 16 + (tid & 15);
     const int dy = (tileRow0 + blockIdx.y) * 16 + (tid >> 4);
-    const bool differs = dx < r.dW && dy < r.dH && axis_pixel_differs(r, dx, dy);
+    const bool differs = dx < r.dW && dy < r.dH && (FAST ? axis_pixel_differs_fast(r, dx, dy) : axis_pixel_differs(r, dx, dy));
     const unsigned long long any = __ballot(differs);
     if ((tid & 63) == 0) {
         laneMasks[((size_t)(tileRow0 + blockIdx.y) * gridDim.x + blockIdx.x) * (kRotBlock / 64) + wave] = any;
@@ -31,7 +32,8 @@ hipError_t launch_axis_verify(const RotLaunch &r, unsigned long long *laneMasks,
     const int tileRows = (r.dH + 15) / 16;
     for (int t0 = 0; t0 < tileRows; t0 += 65535) {         // grid.y carries at most 65535 tiles
         const dim3 grid((r.dW + 15) / 16, tileRows - t0 < 65535 ? tileRows - t0 : 65535, 1);
-        hipLaunchKernelGGL(aai_axis_verify_kernel, grid, dim3(kRotBlock), 0, stream, r, laneMasks, counter, t0);
+        if (r.mode == AAI_MODE_FAST) hipLaunchKernelGGL(aai_axis_verify_kernel<true>, grid, dim3(kRotBlock), 0, stream, r, laneMasks, counter, t0);
+        else hipLaunchKernelGGL(aai_axis_verify_kernel<false>, grid, dim3(kRotBlock), 0, stream, r, laneMasks, counter, t0);
         const hipError_t e = hipGetLastError();
         if (e != hipSuccess) return e;
     }

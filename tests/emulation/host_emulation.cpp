@@ -313,7 +313,7 @@ static void emu_rotated(const Geometry &g, const aai_request &rq, const float *i
             const int x0 = std::max(0, (int)std::floor(px - hb + 0.5 - AAI_KNIFE_GUARD)), x1 = std::min(r.mW - 1, (int)std::ceil(px + hb - 0.5 + AAI_KNIFE_GUARD));
             const int y0 = std::max(0, (int)std::floor(py - hb + 0.5 - AAI_KNIFE_GUARD)), y1 = std::min(r.mH - 1, (int)std::ceil(py + hb - 0.5 + AAI_KNIFE_GUARD));
             if (onlyAxisDiffering) {
-                if (!axis_pixel_differs(r, dx, dy)) continue;
+                if (!(rq.mode == AAI_MODE_FAST ? axis_pixel_differs_fast(r, dx, dy) : axis_pixel_differs(r, dx, dy))) continue;
                 ++g_axisFixups;
             }
             float *out = dst + (int64_t)dy * dstStride + dx;
@@ -517,8 +517,8 @@ int aai_emu_resample(const aai_request *rq, const float *src, float *dst, int *d
     g_axisFixups = 0;
     if (axis) {
         emu_axis(g, rq->mode, src, g.W, dst, g.dW);
-        // (mirrors get_plan / enqueue in aai_capi.cpp: area mode under policy REFERENCE)
-        if (rq->mode == AAI_MODE_AREA && (rq->policy & ~AAI_POLICY_DOUBLE_PRECISION) == AAI_POLICY_REFERENCE && !g_skipAxisFixup)
+        // (mirrors get_plan / enqueue in aai_capi.cpp)
+        if (!g_skipAxisFixup)
             emu_rotated(g, *rq, src, g.W, dst, g.dW, true);
     } else emu_rotated(g, *rq, src, g.W, dst, g.dW);
     return AAI_OK;

@@ -318,6 +318,10 @@ def test_axis_aligned_knife_geometries_against_reference_goldens(gpu, po, axis_k
     st = torch.cuda.current_stream().cuda_stream
     for i, c in enumerate(manifest):
         src = po.synth_image(c["W"], c["H"], c["seed"])
+        fast, iso, lay = _host(gpu, src, c, 2)
+        gold = z["a%03d_fast" % i]
+        assert "axis" in gpu.last_kernel() and fast.shape == gold.shape
+        assert rel_err(fast, gold).max() <= 1e-6 and np.array_equal(gold == 0, fast == 0), (i, c, float(rel_err(fast, gold).max()))
         dst, iso, lay = _host(gpu, src, c, 1)
         gold = z["a%03d_exact" % i]
         assert dst.shape == gold.shape and list(iso) == c["dst_iso"], i
@@ -352,7 +356,7 @@ def test_axis_aligned_knife_geometries_against_reference_goldens(gpu, po, axis_k
                 torch.cuda.synchronize()
                 assert np.array_equal(band_dst.cpu().numpy(), dst[b0:b1]), (i, c, b0, b1, a, b)
     # 16-bit sources through the same plans
-    for i in (0, 61, 122, 183):
+    for i in (0, 61, 122, 183, 300, 500):
         c = manifest[i]
         src16 = (po.synth_image(c["W"], c["H"], c["seed"]) * 65535).astype(np.uint16)
         gold = po.oracle_run(po.MODE_EXACT, src16.astype(np.float64), c["src_res"], c["dst_res"], tuple(c["iso"]), c["angle"]).dst

@@ -47,12 +47,13 @@ def test_oracle_matches_axis_knife_golden_bit_exact(po, axis_knife_golden):
     """Rotations 0/90/180/270 with dst edges on pixel boundaries or through pixel centres (outputs of the unmodified
     reference): its classifier is not the product of two clipped extents everywhere there (Source.cpp:986-1431)."""
     z, manifest = axis_knife_golden
-    assert len(manifest) == 420
+    assert len(manifest) == 576
     for i, c in enumerate(manifest):
-        r = po.oracle_run(po.MODE_EXACT, _case_src(po, c), c["src_res"], c["dst_res"], c["iso"], c["angle"])
-        gold = z["a%03d_exact" % i]
-        assert r.ok and r.dst.shape == gold.shape == tuple(c["shape"]) and list(r.dst_iso) == c["dst_iso"]
-        assert np.array_equal(r.dst, gold), (i, c, float(np.abs(r.dst - gold).max()))
+        for mode, tag in ((po.MODE_EXACT, "exact"), (po.MODE_FAST, "fast")):
+            r = po.oracle_run(mode, _case_src(po, c), c["src_res"], c["dst_res"], c["iso"], c["angle"])
+            gold = z["a%03d_%s" % (i, tag)]
+            assert r.ok and r.dst.shape == gold.shape == tuple(c["shape"]) and list(r.dst_iso) == c["dst_iso"]
+            assert np.array_equal(r.dst, gold), (i, tag, c, float(np.abs(r.dst - gold).max()))
 
 def test_oracle_error_paths_match_reference_text(po):
     probes = json.load(open(os.path.join(GOLDEN, "error_paths.json")))
