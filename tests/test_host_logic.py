@@ -361,6 +361,23 @@ def test_axis_aligned_knife_geometries_take_the_model_scan(aai, hostemu, axis_kn
     assert hostemu.aai_emu_axis_fixups() > 0 and rel_err(a, z["a000_exact"]).max() <= 1e-6
 
 
+def test_structured_sweeps_of_the_replay_against_the_oracle(aai, hostemu):
+    """tools/replay_sweep.py, bounded: randomised structured geometries (integer / rational ratios, isocenters on centres,
+    corners, half and quarter pixels) at multiples of 90 degrees and at atan(p/q) / 15-degree / hair-breadth rotations, both
+    modes, both policies -- the K1 tables with their model scan and the fp32 quad formulation with its scans, each followed by
+    the strict fix-up, against the CPU oracle.  (Round 2 ran 22 k + 40 k cases of these; they found the three classes of
+    axis-aligned geometries the model scan now covers.)"""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("replay_sweep", os.path.join(ROOT, "tools", "replay_sweep.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    problems = []
+    n, bad, worst, fixups = mod.sweep("axis", 2500, 101, hostemu, report=lambda *a: problems.append(a))
+    assert n > 2000 and bad == 0 and fixups >= 20, (n, bad, fixups, problems[:3])
+    n, bad, worst, fixups = mod.sweep("rotated", 2500, 102, hostemu, report=lambda *a: problems.append(a))
+    assert n > 2000 and bad == 0 and worst <= 0.7 * TOL, (n, bad, worst, problems[:3])
+
+
 def test_baseline_geometries_raise_no_knife_flags(aai, hostemu, po):
     """BASELINE configs 3 and 5 (at reduced size) never enter the strict path (zero end-point hits)."""
     for (W, sr, dr, ang) in ((768, 8192.0, 2731.0, 17.5), (96, 1.0, 4.0, 45.0)):

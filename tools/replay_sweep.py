@@ -1,0 +1,75 @@
+#!/usr/bin/env python3
+"""Structured randomised sweeps of the CPU replay (tests/emulation/host_emulation.cpp: the kernels' arithmetic, K1 tables +
+model scan + fix-up, fp32 quad formulation + scans + strict fix-up) against the CPU oracle -- the geometries where the
+reference's DBL_EPSILON rules decide: integer / rational ratios, isocenters on pixel centres, corners, half and quarter
+pixels, rotations at multiples of 90 degrees ("axis") or at atan(p/q), 15-degree steps and hair-breadth angles ("rotated").
+Needs no GPU.   usage: python tools/replay_sweep.py axis|rotated [cases] [seed]"""
+import math
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np                                   # noqa: E402
+import area_average_interpolation_amd as aai         # noqa: E402
+import conftest                                      # noqa: E402
+from oracle import pyoracle as po                    # noqa: E402  (checker only: this is a test tool)
+
+AXIS_RATIOS = [(5, 1), (3, 1), (2, 1), (4, 1), (7, 1), (1, 1), (5, 2), (3, 2), (1, 2), (2, 3), (2.5, 1), (1, 3), (6, 1), (9, 2), (7, 3), (4, 3),
+               (1.5, 1), (3, 4), (10, 3), (8, 1)]
+ROT_RATIOS = [(5, 1), (3, 1), (2, 1), (4, 1), (1, 1), (5, 2), (3, 2), (1, 2), (2, 3), (2.5, 1), (6, 1), (7, 3), (4, 3), (1.5, 1), (2 ** 0.5, 1),
+              (2 * 2 ** 0.5, 1), (5 ** 0.5, 1), (1, 2 ** 0.5), (2.236067977, 2), (1.25, 1)]
+ROT_ANGLES = [45.0, 30.0, 60.0, math.degrees(math.atan(0.5)), math.degrees(math.atan(2)), math.degrees(math.atan(0.75)), math.degrees(math.atan(1 / 3)),
+              22.5, 15.0, 75.0, math.degrees(math.atan(0.25)), 1e-7, 89.9999999, 0.001, 1.0]
+
+
+def sweep(kind, cases, seed, hostemu, report=print):
+    rng = np.random.default_rng(seed)
+    n = bad = fixups = 0
+    worst = 0.0
+    hostemu.aai_emu_use_quad(1)
+    try:
+        for _ in range(cases):
+            big = 48 if kind == "axis" else 40
+            W, H = int(rng.integers(1, big)), int(rng.integers(1, big))
+            ratios = AXIS_RATIOS if kind == "axis" else ROT_RATIOS
+            sr, dr = ratios[int(rng.integers(0, len(ratios)))]
+            if dr / sr > 2.2:
+                continue
+            iso = [((W - 1) / 2, (H - 1) / 2), (0.0, 0.0), (float(rng.integers(0, W)), float(rng.integers(0, H))), (W / 2, H / 2),
+                   (rng.integers(0, 4 * W) / 4.0, rng.integers(0, 4 * H) / 4.0), (rng.integers(-2, W + 2) + 0.5, float(rng.integers(-2, H + 2)))][int(rng.integers(0, 6))]
+            iso = (float(iso[0]), float(iso[1]))
+            if kind == "axis":
+                ang = float(rng.choice([0.0, 90.0, 180.0, 270.0, 360.0, -90.0]))
+            else:
+                ang = float(ROT_ANGLES[int(rng.integers(0, len(ROT_ANGLES)))] + 90 * int(rng.integers(-1, 4)))
+            mode = int(rng.choice([1, 1, 2]))
+            policy = int(rng.integers(0, 2)) if mode == 1 else 0
+            src = rng.random((H, W)).astype(np.float32)
+            gold = po.oracle_run(po.MODE_EXACT if mode == 1 else po.MODE_FAST, src.astype(np.float64), float(sr), float(dr), iso, ang, policy=policy).dst
+            if gold.size == 0:
+                continue
+            out, axis = hostemu.resample(aai.make_request(W, H, float(sr), float(dr), iso, ang, mode=mode, policy=policy), src)
+            err = float((np.abs(out - gold) / np.maximum(np.abs(gold), 1e-3)).max())
+            n += 1
+            worst = max(worst, err)
+            fixups += int(axis and hostemu.aai_emu_axis_fixups() > 0)
+            if err > 1e-5 or not np.array_equal(gold == 0, out == 0):
+                bad += 1
+                report("MISMATCH", dict(W=W, H=H, sr=sr, dr=dr, iso=iso, ang=ang, mode=mode, policy=policy), "err", err)
+    finally:
+        hostemu.aai_emu_use_quad(0)
+    return n, bad, worst, fixups
+
+
+if __name__ == "__main__":
+    kind = sys.argv[1] if len(sys.argv) > 1 else "axis"
+    cases = int(sys.argv[2]) if len(sys.argv) > 2 else 8000
+    seed = int(sys.argv[3]) if len(sys.argv) > 3 else 1
+    emu = conftest.hostemu.__wrapped__(aai)
+    t0 = time.time()
+    n, bad, worst, fixups = sweep(kind, cases, seed, emu)
+    print("%s sweep seed %d: cases %d mismatching %d worst relative error %.3g  K1 cases with fix-ups %d  (%.0f s)" % (kind, seed, n, bad, worst, fixups, time.time() - t0))
+    sys.exit(1 if bad else 0)
