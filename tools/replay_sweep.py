@@ -3,7 +3,8 @@
 model scan + fix-up, fp32 quad formulation + scans + strict fix-up) against the CPU oracle -- the geometries where the
 reference's DBL_EPSILON rules decide: integer / rational ratios, isocenters on pixel centres, corners, half and quarter
 pixels, rotations at multiples of 90 degrees ("axis") or at atan(p/q), 15-degree steps and hair-breadth angles ("rotated").
-Needs no GPU.   usage: python tools/replay_sweep.py axis|rotated [cases] [seed]"""
+Needs no GPU; with --gpu the same cases go through the device library instead (on a GPU box).
+usage: python tools/replay_sweep.py axis|rotated [cases] [seed] [--gpu]"""
 import math
 import os
 import sys
@@ -25,11 +26,13 @@ ROT_ANGLES = [45.0, 30.0, 60.0, math.degrees(math.atan(0.5)), math.degrees(math.
               22.5, 15.0, 75.0, math.degrees(math.atan(0.25)), 1e-7, 89.9999999, 0.001, 1.0]
 
 
-def sweep(kind, cases, seed, hostemu, report=print):
+def sweep(kind, cases, seed, hostemu, report=print, gpu=False):
+    """gpu=True: the same cases through the device library (aai.resample_host) instead of the CPU replay"""
     rng = np.random.default_rng(seed)
     n = bad = fixups = 0
     worst = 0.0
-    hostemu.aai_emu_use_quad(1)
+    if not gpu:
+        hostemu.aai_emu_use_quad(1)
     try:
         for _ in range(cases):
             big = 48 if kind == "axis" else 40
@@ -51,25 +54,37 @@ def sweep(kind, cases, seed, hostemu, report=print):
             gold = po.oracle_run(po.MODE_EXACT if mode == 1 else po.MODE_FAST, src.astype(np.float64), float(sr), float(dr), iso, ang, policy=policy).dst
             if gold.size == 0:
                 continue
-            out, axis = hostemu.resample(aai.make_request(W, H, float(sr), float(dr), iso, ang, mode=mode, policy=policy), src)
+            if gpu:
+                rc, msg, out, _, _ = aai.resample_host(src, float(sr), float(dr), iso, ang, mode=mode, policy=policy)
+                assert rc == 0, msg
+            else:
+                out, axis = hostemu.resample(aai.make_request(W, H, float(sr), float(dr), iso, ang, mode=mode, policy=policy), src)
+                fixups += int(axis and hostemu.aai_emu_axis_fixups() > 0)
             err = float((np.abs(out - gold) / np.maximum(np.abs(gold), 1e-3)).max())
             n += 1
             worst = max(worst, err)
-            fixups += int(axis and hostemu.aai_emu_axis_fixups() > 0)
             if err > 1e-5 or not np.array_equal(gold == 0, out == 0):
                 bad += 1
                 report("MISMATCH", dict(W=W, H=H, sr=sr, dr=dr, iso=iso, ang=ang, mode=mode, policy=policy), "err", err)
     finally:
-        hostemu.aai_emu_use_quad(0)
+        if not gpu:
+            hostemu.aai_emu_use_quad(0)
     return n, bad, worst, fixups
 
 
 if __name__ == "__main__":
-    kind = sys.argv[1] if len(sys.argv) > 1 else "axis"
-    cases = int(sys.argv[2]) if len(sys.argv) > 2 else 8000
-    seed = int(sys.argv[3]) if len(sys.argv) > 3 else 1
-    emu = conftest.hostemu.__wrapped__(aai)
+    on_gpu = "--gpu" in sys.argv
+    args = [a for a in sys.argv[1:] if a != "--gpu"]
+    kind = args[0] if len(args) > 0 else "axis"
+    cases = int(args[1]) if len(args) > 1 else 8000
+    seed = int(args[2]) if len(args) > 2 else 1
+    emu = None
+    if on_gpu:
+        aai.set_device(0)
+    else:
+        emu = conftest.hostemu.__wrapped__(aai)
     t0 = time.time()
-    n, bad, worst, fixups = sweep(kind, cases, seed, emu)
-    print("%s sweep seed %d: cases %d mismatching %d worst relative error %.3g  K1 cases with fix-ups %d  (%.0f s)" % (kind, seed, n, bad, worst, fixups, time.time() - t0))
+    n, bad, worst, fixups = sweep(kind, cases, seed, emu, gpu=on_gpu)
+    print("%s sweep seed %d (%s): cases %d mismatching %d worst relative error %.3g  K1 cases with fix-ups %s  (%.0f s)" % (
+        kind, seed, "GPU" if on_gpu else "CPU replay", n, bad, worst, "n/a" if on_gpu else fixups, time.time() - t0))
     sys.exit(1 if bad else 0)
