@@ -353,7 +353,7 @@ static const RotTune &rot_tune()
     return t;
 }
 
-// the fp32 quad kernels serve this launch (area mode: plain and interleaved images; fast mode: plain images)
+// the fp32 quad kernels serve this launch (RotLaunch::quad; area mode: plain and interleaved images; fast mode: plain images)
 static bool quad_serves(const RotLaunch &r, int srcType, ImageView sv)
 {
     return r.quad && rot_tune().quad != 0 && (r.mode == AAI_MODE_AREA || (r.mode == AAI_MODE_FAST && r.chan == 1)) && quad_can_address(r, srcType, sv);
