@@ -5,6 +5,7 @@ There is no Python or CPU fallback: if the shared object is missing, importing t
 """
 import ctypes
 import os
+import sys
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libaai_hip.so")
@@ -93,6 +94,14 @@ def load():
             raise ImportError(
                 "libaai_hip.so not found at %s -- run `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(there is no CPU fallback for the resampling path)" % LIB_PATH)
+        # One HIP runtime per process: PyTorch-ROCm ships its own libamdhip64, and a process that loads the system's copy
+        # first (through this library) and torch's afterwards finds "No HIP GPUs" in torch.  Loaded after torch, this
+        # library binds to the copy already in the process (same SONAME) -- so bring torch in first when it is installed.
+        if "torch" not in sys.modules:
+            try:
+                import torch  # noqa: F401
+            except ImportError:
+                pass
         lib = ctypes.CDLL(LIB_PATH)
         for name, (res, args) in SYMBOLS.items():
             fn = getattr(lib, name)      # AttributeError if the ABI and the header drifted apart

@@ -843,6 +843,7 @@ def test_dense_knife_geometry_takes_the_strict_pass_for_the_whole_image(po):
     import sys
     code = r"""
 import sys, numpy as np
+import torch            # (before the library: one HIP runtime per process)
 sys.path.insert(0, %r)
 import area_average_interpolation_amd as aai
 from oracle import pyoracle as po
@@ -857,6 +858,26 @@ for (W, H, sr, dr, ang, mode, omode) in ((96, 80, 2.0, 1.0, 45.0, 1, po.MODE_EXA
     gold = po.oracle_run(omode, src.astype(np.float64), sr, dr, iso, ang).dst
     err = np.abs(dst - gold) / np.maximum(np.abs(gold), 1e-3)
     assert err.max() <= 1e-5 and np.array_equal(gold == 0, dst == 0), (W, H, ang, mode, float(err.max()))
+# an axis-aligned geometry whose model scan flags more pixels than the list keeps (13 of 39 here): the whole image takes the
+# per-pixel replay instead of K1 -- plain, as a band from a footprint-only buffer, and interleaved
+W, H, sr, dr, ang = 40, 9, 3.0, 1.0, 0.0
+iso = ((W - 1) / 2, (H - 1) / 2)
+src = po.synth_image(W, H, 7)
+gold = po.oracle_run(po.MODE_EXACT, src.astype(np.float64), sr, dr, iso, ang).dst
+rc, msg, dst, giso, lay = aai.resample_host(src, sr, dr, iso, ang, mode=1)
+assert rc == 0 and "strict" in aai.last_kernel(), (msg, aai.last_kernel())
+assert (np.abs(dst - gold) / np.maximum(np.abs(gold), 1e-3)).max() <= 1e-6
+rq = aai.make_request(W, H, sr, dr, iso, ang, mode=1)
+dH, dW = gold.shape
+a, b = aai.band_source_rows(rq, 1, dH)
+band_src = torch.from_numpy(src[a:b].copy()).cuda()
+band_dst = torch.empty((dH - 1, dW), dtype=torch.float32, device="cuda")
+aai.resample_band_device(rq, 1, dH, band_src.data_ptr(), W, band_dst.data_ptr(), dW, torch.cuda.current_stream().cuda_stream)
+torch.cuda.synchronize()
+assert np.array_equal(band_dst.cpu().numpy(), dst[1:]), "band"
+inter = np.stack([src, 1.0 - src], axis=2).astype(np.float32)
+rc, msg, idst, ilay = aai.resample_interleaved_host(inter, sr, dr, iso, ang, mode=1)
+assert rc == 0 and (np.abs(idst[:, :, 0] - gold) / np.maximum(np.abs(gold), 1e-3)).max() <= 1e-6
 print("dense ok")
 """ % ROOT
     env = dict(os.environ, AAI_MAX_LISTED_PIXELS="10")
