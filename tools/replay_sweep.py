@@ -50,22 +50,39 @@ def sweep(kind, cases, seed, hostemu, report=print, gpu=False):
                 ang = float(ROT_ANGLES[int(rng.integers(0, len(ROT_ANGLES)))] + 90 * int(rng.integers(-1, 4)))
             mode = int(rng.choice([1, 1, 2]))
             policy = int(rng.integers(0, 2)) if mode == 1 else 0
-            src = rng.random((H, W)).astype(np.float32)
+            floor = 1e-3
+            form = int(rng.integers(0, 4)) if gpu else 0      # device only: 8- / 16-bit sources, interleaved channels
+            if form == 1:
+                src = rng.integers(0, 256, size=(H, W)).astype(np.uint8)
+                floor = 0.256
+            elif form == 2:
+                src = rng.integers(0, 65536, size=(H, W)).astype(np.uint16)
+                floor = 65.536
+            else:
+                src = rng.random((H, W)).astype(np.float32)
             gold = po.oracle_run(po.MODE_EXACT if mode == 1 else po.MODE_FAST, src.astype(np.float64), float(sr), float(dr), iso, ang, policy=policy).dst
             if gold.size == 0:
                 continue
-            if gpu:
+            if gpu and form == 3:
+                C = int(rng.integers(2, 5))
+                inter = rng.random((H, W, C)).astype(np.float32)
+                k = int(rng.integers(0, C))
+                inter[:, :, k] = src
+                rc, msg, iout, _ = aai.resample_interleaved_host(inter, float(sr), float(dr), iso, ang, mode=mode, policy=policy)
+                assert rc == 0, msg
+                out = iout[:, :, k]
+            elif gpu:
                 rc, msg, out, _, _ = aai.resample_host(src, float(sr), float(dr), iso, ang, mode=mode, policy=policy)
                 assert rc == 0, msg
             else:
                 out, axis = hostemu.resample(aai.make_request(W, H, float(sr), float(dr), iso, ang, mode=mode, policy=policy), src)
                 fixups += int(axis and hostemu.aai_emu_axis_fixups() > 0)
-            err = float((np.abs(out - gold) / np.maximum(np.abs(gold), 1e-3)).max())
+            err = float((np.abs(out - gold) / np.maximum(np.abs(gold), floor)).max())
             n += 1
             worst = max(worst, err)
             if err > 1e-5 or not np.array_equal(gold == 0, out == 0):
                 bad += 1
-                report("MISMATCH", dict(W=W, H=H, sr=sr, dr=dr, iso=iso, ang=ang, mode=mode, policy=policy), "err", err)
+                report("MISMATCH", dict(W=W, H=H, sr=sr, dr=dr, iso=iso, ang=ang, mode=mode, policy=policy, form=form), "err", err)
     finally:
         if not gpu:
             hostemu.aai_emu_use_quad(0)
