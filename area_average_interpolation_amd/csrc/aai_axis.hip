@@ -533,7 +533,7 @@ static hipError_t launch_axis_typed(const AxisLaunch &a, const T *src, ImageView
         if (a.maxOutputsPerStrip > 64) rows = a.maxRowSpan >= 2 ? 4 : 16;     // the four-column path (ratios below 4)
     }
     if (!a.transposed && a.maxOutputsPerStrip > 128 && a.maxOutputsPerStrip <= 256) rows = 32;      // ratios below 2: write-heavy
-    // the plan's measured choice for this (geometry, device) -- fp32 sources only (aai_capi.cpp: tune_axis_plan)
+    // the plan's measured choice for this (geometry, device) -- fp32 sources only (aai_engine.cpp: tune_axis_plan)
     if (sizeof(T) == 4 && a.tuneRows > 0) { rows = a.tuneRows; nt = a.tuneNt; swapXY = a.tuneSwap; }
     const AxisTune &tune = axis_tune();
     if (tune.nt >= 0) nt = tune.nt;

@@ -1,0 +1,345 @@
+// aai_engine.cpp -- the host-side engine behind the C ABI: per-thread error state, request checks, the plan cache
+// (K1 tables and launch-shape measurement, the one-off scans of a geometry and their fix-up lists) and the dispatch of a
+// request onto the kernels.  aai_capi.cpp holds the extern "C" entry points and the host-buffer paths built on this.
+//
+// There is deliberately no CPU implementation here: without a HIP device every compute entry point fails with
+// AAI_ERR_NO_DEVICE.  The CPU oracle under oracle/ is test infrastructure and is never linked or loaded.
+#include "aai_engine.hpp"
+
+#include <climits>
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <algorithm>
+
+namespace aai {
+namespace engine {
+
+thread_local std::string g_lastError;
+thread_local std::string g_lastKernel;
+
+int fail(int code, const std::string &msg)
+{
+    g_lastError = msg;
+    return code;
+}
+
+int hip_fail(hipError_t e, const char *what)
+{
+    std::string m = std::string(what) + ": " + hipGetErrorString(e);
+    // a missing / unusable device is reported as such so callers can tell it from a kernel fault
+    if (e == hipErrorNoDevice || e == hipErrorInvalidDevice || e == hipErrorInsufficientDriver || e == hipErrorNotInitialized)
+        return fail(AAI_ERR_NO_DEVICE, m);
+    return fail(AAI_ERR_HIP, m);
+}
+
+// ---- plan cache ------------------------------------------------------------------------------------
+std::mutex g_planMutex;
+std::list<Plan> g_plans;              // most recently used first
+constexpr size_t kMaxPlans = 32;
+constexpr unsigned kMaxListedPixels = 1u << 24;      // beyond 16 M flagged pixels the whole image takes the double-precision pass
+
+bool same_request(const aai_request &a, const aai_request &b)
+{
+    return a.mode == b.mode && a.policy == b.policy && a.src_width == b.src_width && a.src_height == b.src_height &&
+           a.src_res_x == b.src_res_x && a.src_res_y == b.src_res_y && a.dst_res_x == b.dst_res_x &&
+           a.dst_res_y == b.dst_res_y && a.src_iso_x == b.src_iso_x && a.src_iso_y == b.src_iso_y &&
+           a.rotation_deg == b.rotation_deg;
+}
+
+int check_request(const aai_request *rq)
+{
+    if (!rq) return fail(AAI_ERR_BAD_ARGUMENT, "Null request.");
+    if (rq->mode < AAI_MODE_AREA || rq->mode > AAI_MODE_BICUBIC) return fail(AAI_ERR_BAD_ARGUMENT, "Unknown interpolation mode.");
+    const int rule = rq->policy & ~AAI_POLICY_DOUBLE_PRECISION;
+    if (rule != AAI_POLICY_REFERENCE && rule != AAI_POLICY_EXACT) return fail(AAI_ERR_BAD_ARGUMENT, "Unknown weight policy.");
+    return AAI_OK;
+}
+
+// K1 row bands keep one more source row on either side where the fix-up pass behind K1 may run (get_plan: verifyAxis):
+// its window includes rows that only touch the dst pixel
+int axis_band_margin(const aai_request &rq)
+{
+    return rq.mode == AAI_MODE_AREA || rq.mode == AAI_MODE_FAST ? 1 : 0;
+}
+
+int pick_kernel(const aai_request &rq, const aai::Geometry &g)
+{
+    if (rq.mode == AAI_MODE_BILINEAR || rq.mode == AAI_MODE_BICUBIC) return AAI_KERNEL_SAMPLE;
+    if (g.axisAligned) return AAI_KERNEL_AXIS;
+    return rq.mode == AAI_MODE_FAST ? AAI_KERNEL_FAST : AAI_KERNEL_ROTATED;
+}
+
+int resolved_kernel(const aai_request &rq, const aai::Geometry &g)
+{
+    int kernel = pick_kernel(rq, g);
+    if (kernel == AAI_KERNEL_AXIS) {
+        aai::AxisTables t;
+        aai::build_axis_tables(g, rq.mode, t);
+        if (t.wide) kernel = AAI_KERNEL_AXIS_WIDE;
+    }
+    return kernel;
+}
+
+void fill_layout(const aai::Geometry &g, int kernel, aai_layout *out)
+{
+    aai_layout l{};
+    l.dst_width = g.dW; l.dst_height = g.dH;
+    l.dst_iso_x = g.dIsoX; l.dst_iso_y = g.dIsoY;
+    l.scale = g.scale; l.quadrant = g.quadrant;
+    l.reduced_angle_deg = g.angle; l.side = g.side;
+    l.kernel = kernel;
+    *out = l;
+}
+
+// the argument block of K1 for a plan and a dst row stride (elements)
+static aai::AxisLaunch make_axis_launch(const Plan &p, int channels, int64_t dstStride)
+{
+    const aai::AxisTables &t = p.tabs;
+    const aai::Geometry &g = p.g;
+    aai::AxisLaunch a{};
+    a.laneTab = p.dLane; a.rowTab = p.dRow; a.strips = p.dStrips;
+    a.nA = t.nA; a.nB = t.nB; a.nStrips = (int)t.strips.size();
+    a.srcW = g.W * channels; a.srcH = g.H;      // elements of a source row
+    a.wide = t.wide ? 1 : 0;
+    a.maxRowSpan = t.maxRowSpan;
+    a.rowsShared = t.rowsShared ? 1 : 0;
+    a.maxOutputsPerStrip = t.maxOutputsPerStrip;
+    // (ka,kb) -> dst element: the lane axis is dst x unless the quadrant transposes; flips run an axis
+    // backwards
+    // (with interleaved channels a dst pixel is `channels` elements wide and lane entry ka = pixel * channels + channel)
+    const int nApix = t.nA / channels;
+    const int64_t sa = t.transposed ? dstStride : channels, sb = t.transposed ? channels : dstStride;
+    a.outStrideA = t.flipA ? -sa : sa;
+    a.outStrideB = t.flipB ? -sb : sb;
+    a.outBase = (t.flipA ? (int64_t)(nApix - 1) * sa : 0) + (t.flipB ? (int64_t)(t.nB - 1) * sb : 0);
+    a.transposed = t.transposed ? 1 : 0;
+    a.tapStep = channels; a.outChan = channels;
+    if (channels > 1 && !t.transposed && !t.flipA) { a.outStrideA = 1; a.outChan = 1; }     // lane order = dst element order
+    a.tuneRows = p.tuneRows; a.tuneNt = p.tuneNt; a.tuneSwap = p.tuneSwap;
+    return a;
+}
+
+// K1 is HBM-bound and its best launch shape moves with the box by a few per cent (the same binary measured 5.8 to 6.9
+// TB/s across boxes of one pool: profiles/r01_axis_tune_sweep2.txt, profiles/r02_axis_autotune.txt), so a plan for a
+// large streaming geometry times the shapes that ever win -- output rows per workgroup, nontemporal or cached loads,
+// grid order -- once on this device, on scratch images larger than the Infinity Cache, and keeps the fastest.  Only the
+// common family (plain fp32 images, footprints of >= 4 source rows, un-transposed quadrants, whole image).
+static void tune_axis_plan(Plan &p, int channels, int band0)
+{
+    static const bool enabled = [] { const char *e = getenv("AAI_AXIS_AUTOTUNE"); return !(e && atoi(e) == 0); }();
+    const aai::AxisTables &t = p.tabs;
+    const aai::Geometry &g = p.g;
+    const size_t srcBytes = sizeof(float) * (size_t)g.W * g.H, dstBytes = sizeof(float) * (size_t)g.dW * g.dH;
+    if (!enabled || channels != 1 || band0 >= 0 || t.wide || t.transposed || t.maxRowSpan < 4 || t.maxOutputsPerStrip > 64 ||
+        srcBytes < ((size_t)64 << 20) || !dstBytes)
+        return;
+    const int images = (int)std::min<size_t>(8, std::max<size_t>(2, (((size_t)1 << 30) + srcBytes - 1) / srcBytes));
+    float *src = nullptr, *dst = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    bool ok = hipMalloc((void **)&src, srcBytes * images) == hipSuccess && hipMalloc((void **)&dst, dstBytes * images) == hipSuccess &&
+              hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess;
+    for (int b = 0; b < images && ok; ++b)         // realistic data: the memory system's speed depends on what it moves
+        ok = aai::launch_synth(src + (size_t)b * g.W * g.H, g.W, g.H, g.W, (uint64_t)b + 1, nullptr) == hipSuccess;
+    struct Shape { int rows, nt, swap; float ms; };
+    Shape shapes[] = {{1, 1, 0, 0.f}, {2, 1, 0, 0.f}, {1, 0, 0, 0.f}, {2, 0, 0, 0.f}, {4, 1, 0, 0.f}};
+    const aai::ImageView sv{g.W, (int64_t)g.W * g.H}, dv{g.dW, (int64_t)g.dW * g.dH};
+    // the shapes take turns, three rounds, two launches per turn; each keeps its fastest turn
+    for (int round = 0; round < 4 && ok; ++round)
+        for (Shape &sh : shapes) {
+            p.tuneRows = sh.rows; p.tuneNt = sh.nt; p.tuneSwap = sh.swap;
+            const aai::AxisLaunch a = make_axis_launch(p, 1, g.dW);
+            float ms = 0.f;
+            ok = ok && hipEventRecord(e0, nullptr) == hipSuccess &&
+                 aai::launch_axis(a, src, aai::SRC_F32, sv, dst, dv, images, nullptr, nullptr) == hipSuccess &&
+                 aai::launch_axis(a, src, aai::SRC_F32, sv, dst, dv, images, nullptr, nullptr) == hipSuccess &&
+                 hipEventRecord(e1, nullptr) == hipSuccess && hipEventSynchronize(e1) == hipSuccess && hipEventElapsedTime(&ms, e0, e1) == hipSuccess;
+            if (ok && round > 0 && (sh.ms == 0.f || ms < sh.ms)) sh.ms = ms;       // round 0 warms up
+        }
+    p.tuneRows = 0; p.tuneNt = 0; p.tuneSwap = 0;
+    if (ok) {
+        const Shape *best = &shapes[0];
+        for (const Shape &sh : shapes)
+            if (sh.ms < best->ms * 0.99f) best = &sh;          // a later shape must win by more than the timing noise
+        p.tuneRows = best->rows; p.tuneNt = best->nt; p.tuneSwap = best->swap;
+    }
+    (void)hipGetLastError();
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    if (src) (void)hipFree(src);
+    if (dst) (void)hipFree(dst);
+}
+
+// Finds or builds the plan for (request, current device).  Returns a pointer valid until evicted; callers
+// hold g_planMutex for the duration of the launch (launches only enqueue, so this is short).
+int get_plan(const aai_request &rq, int band0, int band1, int channels, Plan **out)
+{
+    int dev = -1;
+    AAI_HIP(hipGetDevice(&dev));
+    {
+        // Only K1's tables depend on the row band.  The per-pixel kernels take the band as launch parameters and their
+        // one-off scans cover the whole image, so every band and every channel count of a rotated request shares one plan.
+        aai::Geometry g0;
+        std::string msg0;
+        int rc0 = aai::make_geometry(rq, g0, msg0);
+        if (rc0 != AAI_OK) return fail(rc0, msg0);
+        if (pick_kernel(rq, g0) != AAI_KERNEL_AXIS) { band0 = band1 = -1; channels = 1; }
+    }
+    for (auto it = g_plans.begin(); it != g_plans.end(); ++it) {
+        if (it->device == dev && it->band0 == band0 && it->band1 == band1 && it->channels == channels && same_request(it->key, rq)) {
+            g_plans.splice(g_plans.begin(), g_plans, it);
+            *out = &g_plans.front();
+            return AAI_OK;
+        }
+    }
+    aai::Geometry g;
+    std::string msg;
+    int rc = aai::make_geometry(rq, g, msg);
+    if (rc != AAI_OK) return fail(rc, msg);
+
+    g_plans.emplace_front();
+    Plan &p = g_plans.front();
+    p.key = rq; p.band0 = band0; p.band1 = band1; p.channels = channels; p.device = dev; p.g = g; p.kernel = pick_kernel(rq, g);
+    p.srcRow0 = 0; p.srcRow1 = g.H;
+    if (p.kernel == AAI_KERNEL_AXIS) {
+        aai::build_axis_tables(g, rq.mode, p.tabs, channels);
+        if (band0 >= 0) aai::restrict_axis_tables_to_band(g, p.tabs, band0, band1, p.srcRow0, p.srcRow1, axis_band_margin(rq));
+        if (p.tabs.wide) p.kernel = AAI_KERNEL_AXIS_WIDE;
+        auto upload = [&](const void *h, size_t bytes, void **d) -> hipError_t {
+            if (!bytes) { *d = nullptr; return hipSuccess; }
+            hipError_t e = hipMalloc(d, bytes);
+            if (e != hipSuccess) return e;
+            return hipMemcpy(*d, h, bytes, hipMemcpyHostToDevice);
+        };
+        hipError_t e = upload(p.tabs.lane.data(), p.tabs.lane.size() * sizeof(aai::AxisEntry), (void **)&p.dLane);
+        if (e == hipSuccess) e = upload(p.tabs.row.data(), p.tabs.row.size() * sizeof(aai::AxisEntry), (void **)&p.dRow);
+        if (e == hipSuccess) e = upload(p.tabs.strips.data(), p.tabs.strips.size() * sizeof(aai::AxisStrip), (void **)&p.dStrips);
+        if (e != hipSuccess) { g_plans.pop_front(); return hip_fail(e, "uploading axis tables"); }
+        if (p.kernel == AAI_KERNEL_AXIS) tune_axis_plan(p, channels, band0);
+    }
+    const bool axisKernel = p.kernel == AAI_KERNEL_AXIS || p.kernel == AAI_KERNEL_AXIS_WIDE;
+    // K1's separable model against the reference's classifier (aai_axis_verify.hpp).  Both policies: they differ in the
+    // corner-triangle rule of a slanted left/right edge only, which does not exist at multiples of 90 degrees.
+    const bool verifyAxis = axisKernel && axis_band_margin(rq) != 0;
+    if (p.kernel == AAI_KERNEL_ROTATED || p.kernel == AAI_KERNEL_FAST || verifyAxis) {
+        // one-off scans of this geometry (rotated: aai_knife_scan_kernel, and aai_quad_scan_kernel where the fp32 quad
+        // kernels serve it; axis-aligned: aai_axis_verify_kernel); keeps the list of flagged pixels only if there are any
+        const aai::RotLaunch r = aai::make_rot_launch(g, rq.mode, rq.policy);
+        const size_t waves = aai::rotated_flag_words(r);
+        unsigned long long *dMasks = nullptr;
+        unsigned *dCount = nullptr;
+        unsigned count = 0;
+        hipError_t e = hipSuccess;
+        if (waves) {
+            e = hipMalloc((void **)&dMasks, waves * sizeof(unsigned long long));
+            if (e == hipSuccess) e = hipMalloc((void **)&dCount, sizeof(unsigned));
+            if (e == hipSuccess) e = hipMemset(dCount, 0, sizeof(unsigned));
+            if (e == hipSuccess) e = verifyAxis ? aai::launch_axis_verify(r, dMasks, dCount, nullptr) : aai::launch_knife_scan(r, dMasks, dCount, nullptr);
+            if (e == hipSuccess && r.quad) e = aai::launch_quad_scan(r, dMasks, dCount, nullptr);
+            if (e == hipSuccess) e = hipMemcpy(&count, dCount, sizeof(unsigned), hipMemcpyDeviceToHost);
+            // (AAI_MAX_LISTED_PIXELS: test hook, lowers the threshold so that small geometries exercise the dense form)
+            static const unsigned maxListed = [] { const char *v = getenv("AAI_MAX_LISTED_PIXELS"); return v ? (unsigned)strtoul(v, nullptr, 10) : kMaxListedPixels; }();
+            if (e == hipSuccess && count > maxListed) { p.dense = true; count = 0; }
+            if (e == hipSuccess && count) {
+                e = hipMalloc(&p.dList, (size_t)count * 2 * sizeof(unsigned));
+                if (e == hipSuccess) e = hipMemset(dCount, 0, sizeof(unsigned));
+                if (e == hipSuccess) e = aai::launch_flag_list(dMasks, waves, (unsigned)((g.dW + 15) / 16), p.dList, dCount, count, nullptr);
+                if (e == hipSuccess) e = hipDeviceSynchronize();
+            }
+            if (dCount) (void)hipFree(dCount);
+            if (e == hipSuccess && count && r.quad) {
+                // keep the masks: the quad kernel skips the flagged pixels and the fix-up pass runs beside it
+                p.dMasks = dMasks;
+                dMasks = nullptr;
+                e = hipStreamCreateWithFlags(&p.side, hipStreamNonBlocking);
+                if (e == hipSuccess) e = hipEventCreateWithFlags(&p.fork, hipEventDisableTiming);
+                if (e == hipSuccess) e = hipEventCreateWithFlags(&p.join, hipEventDisableTiming);
+            }
+            if (dMasks) (void)hipFree(dMasks);
+        }
+        if (e != hipSuccess) { g_plans.pop_front(); return hip_fail(e, verifyAxis ? "axis model scan" : "knife-edge scan"); }
+        p.flaggedPixels = count;
+    }
+    while (g_plans.size() > kMaxPlans) g_plans.pop_back();
+    *out = &p;
+    return AAI_OK;
+}
+
+constexpr int kMaxGridZ = 65535;
+
+// element offset into a typed source buffer
+static const void *src_at(const void *base, int srcType, int64_t elements)
+{
+    const int64_t esz = srcType == aai::SRC_U8 ? 1 : srcType == aai::SRC_U16 ? 2 : 4;
+    return static_cast<const char *>(base) + elements * esz;
+}
+
+int enqueue(const aai_request &rq, int batch, const void *dSrc, int srcType, int64_t srcStride, int64_t srcImageStride,
+            float *dDst, int64_t dstStride, int64_t dstImageStride, hipStream_t stream, int band0, int band1, int channels)
+{
+    std::lock_guard<std::mutex> lock(g_planMutex);
+    Plan *p = nullptr;
+    int rc = get_plan(rq, band0, band1, channels, &p);
+    if (rc != AAI_OK) return rc;
+    const aai::Geometry &g = p->g;
+    // strides are in elements; an interleaved pixel takes `channels` of them
+    if (srcStride < (int64_t)g.W * channels) return fail(AAI_ERR_BAD_ARGUMENT, "Source stride smaller than the image width.");
+    if (dstStride < (int64_t)g.dW * channels) return fail(AAI_ERR_BAD_ARGUMENT, "Destination stride smaller than the output width.");
+    if (g.dW == 0 || g.dH == 0 || batch == 0) return AAI_OK;
+
+    aai::ImageView sv{srcStride, srcImageStride}, dv{dstStride, dstImageStride};
+    const char *name = "";
+    hipError_t e;
+    const bool axisKernel = p->kernel == AAI_KERNEL_AXIS || p->kernel == AAI_KERNEL_AXIS_WIDE;
+    // per-pixel launch description: the rotated kernels, and the fix-up pass behind K1
+    aai::RotLaunch r = aai::make_rot_launch(g, rq.mode, rq.policy);
+    if (band0 >= 0) {
+        int srcRow0 = p->srcRow0, srcRow1 = p->srcRow1;
+        if (!axisKernel) aai::rotated_band_source_rows(g, band0, band1, p->kernel == AAI_KERNEL_SAMPLE, srcRow0, srcRow1);
+        r.dyBase = band0; r.dyEnd = band1; r.srcRow0 = srcRow0;
+    }
+    r.chan = channels;
+    if (axisKernel && !p->dense) {
+        const aai::AxisLaunch a = make_axis_launch(*p, channels, dstStride);
+        e = hipSuccess;
+        for (int b0 = 0; b0 < batch && e == hipSuccess; b0 += kMaxGridZ) {      // grid.z carries the batch
+            const void *s0 = src_at(dSrc, srcType, (int64_t)b0 * srcImageStride);
+            float *d0 = dDst + (int64_t)b0 * dstImageStride;
+            const int nb = std::min(batch - b0, kMaxGridZ);
+            e = aai::launch_axis(a, s0, srcType, sv, d0, dv, nb, stream, &name);
+            // dst pixels where the reference's classifier departs from the separable model (aai_axis_verify.hpp)
+            if (e == hipSuccess && p->flaggedPixels) {
+                aai::launch_rotated_fixup(r, nb, s0, srcType, sv, d0, dv, static_cast<const uint2 *>(p->dList), p->flaggedPixels, stream);
+                e = hipGetLastError();
+            }
+        }
+    } else {
+        // (an axis-aligned geometry lands here when the separable model fails for most of its pixels: `dense`)
+        const aai::QuadMap qm = aai::make_quad_map(g, srcStride, r.srcRow0, channels, srcType == aai::SRC_U8 ? 1 : srcType == aai::SRC_U16 ? 2 : 4);
+        aai::RotFlags flags;
+        flags.list = p->dList; flags.count = p->flaggedPixels; flags.dense = p->dense;
+        flags.masks = p->dMasks; flags.side = p->side; flags.fork = p->fork; flags.join = p->join;
+        e = hipSuccess;
+        for (int b0 = 0; b0 < batch && e == hipSuccess; b0 += kMaxGridZ)
+            e = aai::launch_rotated(r, qm, src_at(dSrc, srcType, (int64_t)b0 * srcImageStride), srcType, sv, dDst + (int64_t)b0 * dstImageStride, dv,
+                                    std::min(batch - b0, kMaxGridZ), flags, stream, &name);
+    }
+    g_lastKernel = name;
+    if (e != hipSuccess) return hip_fail(e, name);
+    return AAI_OK;
+}
+
+int require_device()
+{
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) {
+        (void)hipGetLastError();
+        return fail(AAI_ERR_NO_DEVICE, "No HIP device available: libaai_hip has no CPU fallback.");
+    }
+    return AAI_OK;
+}
+
+
+}  // namespace engine
+}  // namespace aai

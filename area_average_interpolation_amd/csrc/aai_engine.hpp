@@ -1,0 +1,85 @@
+// aai_engine.hpp -- host-side engine behind the C ABI (aai_engine.cpp): error state, request checks, plan cache, dispatch.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <list>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "aai_kernels.hpp"
+
+namespace aai {
+namespace engine {
+
+// per-thread texts behind aai_last_error() / aai_last_kernel()
+extern thread_local std::string g_lastError;
+extern thread_local std::string g_lastKernel;
+int fail(int code, const std::string &msg);                 // records msg, returns code
+int hip_fail(hipError_t e, const char *what);               // AAI_ERR_NO_DEVICE for a missing / unusable device, else AAI_ERR_HIP
+
+#define AAI_HIP(call)                                                     \
+    do {                                                                  \
+        hipError_t e__ = (call);                                          \
+        if (e__ != hipSuccess) return ::aai::engine::hip_fail(e__, #call); \
+    } while (0)
+
+struct Plan {
+    aai_request key{};
+    int band0 = -1, band1 = -1;      // dst row band this plan serves (-1: the whole image)
+    int channels = 1;                // interleaved channels the K1 tables were built for
+    int srcRow0 = 0, srcRow1 = 0;     // source rows the band reads; the source pointer addresses row srcRow0
+    int device = -1;
+    aai::Geometry g;
+    int kernel = 0;
+    // K1
+    aai::AxisTables tabs;
+    aai::AxisEntry *dLane = nullptr, *dRow = nullptr;
+    aai::AxisStrip *dStrips = nullptr;
+    int tuneRows = 0, tuneNt = 0, tuneSwap = 0;      // K1 launch shape measured on this device (0 rows = built-in default)
+    // K2/K3: the dst pixels flagged by the one-off scans (knife edges of the reference's classifier; decisions the fp32
+    // quad kernel leaves to double precision) as a list of (dx, dy) the fix-up pass runs over; `dense` when there are
+    // so many that the whole image takes that pass instead
+    void *dList = nullptr;
+    unsigned flaggedPixels = 0;
+    bool dense = false;
+    // quad kernel: the lane masks of the flagged pixels (it skips them) and the side stream the fix-up pass runs on
+    unsigned long long *dMasks = nullptr;
+    hipStream_t side = nullptr;
+    hipEvent_t fork = nullptr, join = nullptr;
+    ~Plan()
+    {
+        if (side) { (void)hipStreamSynchronize(side); (void)hipStreamDestroy(side); }
+        if (fork) (void)hipEventDestroy(fork);
+        if (join) (void)hipEventDestroy(join);
+        if (dMasks) (void)hipFree(dMasks);
+        if (dList) (void)hipFree(dList);
+        if (dLane) (void)hipFree(dLane);
+        if (dRow) (void)hipFree(dRow);
+        if (dStrips) (void)hipFree(dStrips);
+    }
+};
+
+
+extern std::mutex g_planMutex;          // held while a plan is looked up, built and launched from (launches only enqueue)
+extern std::list<Plan> g_plans;         // most recently used first
+
+bool same_request(const aai_request &a, const aai_request &b);
+int check_request(const aai_request *rq);
+int axis_band_margin(const aai_request &rq);                 // extra source rows either side of a K1 row band (fix-up pass)
+int pick_kernel(const aai_request &rq, const Geometry &g);
+int resolved_kernel(const aai_request &rq, const Geometry &g);      // pick_kernel, with AXIS -> AXIS_WIDE where the tables say so
+void fill_layout(const Geometry &g, int kernel, aai_layout *out);
+int require_device();
+
+// Finds or builds the plan for (request, current device); the caller holds g_planMutex.
+int get_plan(const aai_request &rq, int band0, int band1, int channels, Plan **out);
+
+// Enqueues one batched launch (plus the fix-up pass where the plan has one) on `stream`.  Strides in elements.
+int enqueue(const aai_request &rq, int batch, const void *dSrc, int srcType, int64_t srcStride, int64_t srcImageStride,
+            float *dDst, int64_t dstStride, int64_t dstImageStride, hipStream_t stream, int band0 = -1, int band1 = -1,
+            int channels = 1);
+
+}  // namespace engine
+}  // namespace aai

@@ -1,4 +1,4 @@
-// aai_kernels.hpp -- launcher declarations shared between the C ABI (aai_capi.cpp) and the HIP
+// aai_kernels.hpp -- launcher declarations shared between the host engine (aai_engine.cpp, aai_capi.cpp) and the HIP
 // translation units.  Every launcher only enqueues work on `stream`.
 #pragma once
 

@@ -171,7 +171,7 @@ static void emu_axis(const Geometry &g, int mode, const float *src, int64_t srcS
     }
 }
 
-// Interleaved channels through the axis-aligned path (mirrors enqueue() in csrc/aai_capi.cpp and the CH = true kernel):
+// Interleaved channels through the axis-aligned path (mirrors enqueue() in csrc/aai_engine.cpp and the CH = true kernel):
 // lane entries are (pixel, channel) pairs over the source row's elements, taps `C` elements apart.
 static int emu_axis_channels(const Geometry &g, int mode, int C, const float *src, float *dst)
 {
@@ -517,7 +517,7 @@ int aai_emu_resample(const aai_request *rq, const float *src, float *dst, int *d
     g_axisFixups = 0;
     if (axis) {
         emu_axis(g, rq->mode, src, g.W, dst, g.dW);
-        // (mirrors get_plan / enqueue in aai_capi.cpp)
+        // (mirrors get_plan / enqueue in aai_engine.cpp)
         if (!g_skipAxisFixup)
             emu_rotated(g, *rq, src, g.W, dst, g.dW, true);
     } else emu_rotated(g, *rq, src, g.W, dst, g.dW);

@@ -25,7 +25,7 @@ for f in find("trace/**/*kernel_trace.csv"):
     rows = list(csv.DictReader(open(f)))
     if rows:
         r = [x for x in rows if "aai_" in x.get("Kernel_Name", "")]
-        # per launch shape: the plan's one-off launch-shape measurement (aai_capi.cpp: tune_axis_plan) shows up as a few
+        # per launch shape: the plan's one-off launch-shape measurement (aai_engine.cpp: tune_axis_plan) shows up as a few
         # launches of other grids; the shape with most launches is the one the timed steps ran
         shapes = defaultdict(list)
         for x in r:
