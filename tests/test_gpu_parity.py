@@ -835,6 +835,37 @@ def test_outputs_taller_than_one_grid(gpu, po):
         del out
 
 
+def test_sources_larger_than_4_gib(gpu, po):
+    """A 33,000 x 33,000 fp32 source (4.36 GB: byte offsets no longer fit 32 bits, element offsets still do) and, for K1,
+    a 46,500 x 46,500 one (8.6 GB, 2.16 G elements: past 32-bit element offsets too): K1 streams them, the rotated
+    requests fall back from the fp32 window kernels (32-bit byte offsets per lane) to the double-precision kernels.
+    Sampled row bands against the CPU oracle's rows."""
+    import torch
+    st = torch.cuda.current_stream().cuda_stream
+    for (W, H, cases) in ((33000, 33000, ((4.0, 1.0, 0.0, 1, po.MODE_EXACT), (3.0, 1.0, 17.5, 1, po.MODE_EXACT), (3.0, 1.0, 17.5, 2, po.MODE_FAST),
+                                          (4.0, 1.0, 90.0, 1, po.MODE_EXACT))),
+                          (46500, 46500, ((4.0, 1.0, 0.0, 1, po.MODE_EXACT), (5.0, 1.0, 180.0, 2, po.MODE_FAST)))):
+        src = torch.empty((H, W), dtype=torch.float32, device="cuda")
+        gpu.synth_device(src.data_ptr(), W, H, W, 11)
+        host = src.cpu().numpy()
+        for (sr, dr, ang, mode, omode) in cases:
+            iso = ((W - 1) / 2, (H - 1) / 2)
+            rq = gpu.make_request(W, H, sr, dr, iso, ang, mode=mode)
+            rc, msg, lay = gpu.query(rq)
+            assert rc == 0, msg
+            out = _device_run(gpu, rq, src)
+            assert "quad" not in gpu.last_kernel()
+            dH, dW = lay.dst_height, lay.dst_width
+            for r0 in (0, dH // 2, dH - 8):
+                gold = po.oracle_rows(omode, host, sr, dr, iso, ang, r0, r0 + 8, dW)
+                got = out[r0:r0 + 8].cpu().numpy()
+                assert rel_err(got, gold).max() <= TOL, (W, ang, mode, r0, gpu.last_kernel(), float(rel_err(got, gold).max()))
+                assert np.array_equal(gold == 0, got == 0), (W, ang, mode, r0)
+            del out
+        del src, host
+        torch.cuda.empty_cache()
+
+
 def test_dense_knife_geometry_takes_the_strict_pass_for_the_whole_image(po):
     """When (nearly) every dst pixel is flagged the plan keeps no list and the double-precision pass computes the whole image
     (threshold 16 M pixels; lowered to 10 through the test hook AAI_MAX_LISTED_PIXELS, in a child process because the
