@@ -11,10 +11,12 @@
 // of two closed intervals there.
 //
 // So, once per geometry, the plan compares the two models pair by pair for every dst pixel that has a knife edge at all
-// (area mode under either policy -- they differ in the corner-triangle rule of a slanted edge only -- and fast mode): the reference's side is exactly what the fix-up pass (aai_rotated_kernel<AREA, STRICT>)
-// computes, the other side is the product of the two clipped extents.  Dst pixels where any pair differs are recomputed by
-// that fix-up pass behind K1; at 8192^2 -> 2048^2 (every edge on a pixel boundary, every vertex on a pixel corner)
-// none differs.  Shared by the plan-time scan kernel and the CPU replay of the test-suite.
+// (area mode under either policy -- they differ in the corner-triangle rule of a slanted edge only -- and fast mode):
+// the reference's side is exactly what the fix-up pass (aai_rotated_kernel<..., STRICT>) computes, the other side is
+// what K1's tables say (the product of the two clipped extents; two closed intervals).  Dst pixels where any pair
+// differs, and dst pixels that only graze the lattice, are recomputed by that fix-up pass behind K1; at 8192^2 -> 2048^2
+// (every edge on a pixel boundary, every vertex on a pixel corner) none differs.  Shared by the plan-time scan kernel
+// and the CPU replay of the test-suite.
 #pragma once
 #include "aai_rot_math.hpp"
 #include "aai_strict.hpp"
