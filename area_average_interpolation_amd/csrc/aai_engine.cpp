@@ -176,26 +176,26 @@ int get_plan(const aai_request &rq, int band0, int band1, int channels, Plan **o
 {
     int dev = -1;
     AAI_HIP(hipGetDevice(&dev));
-    {
-        // Only K1's tables depend on the row band.  The per-pixel kernels take the band as launch parameters and their
-        // one-off scans cover the whole image, so every band and every channel count of a rotated request shares one plan.
-        aai::Geometry g0;
-        std::string msg0;
-        int rc0 = aai::make_geometry(rq, g0, msg0);
-        if (rc0 != AAI_OK) return fail(rc0, msg0);
-        if (pick_kernel(rq, g0) != AAI_KERNEL_AXIS) { band0 = band1 = -1; channels = 1; }
-    }
-    for (auto it = g_plans.begin(); it != g_plans.end(); ++it) {
-        if (it->device == dev && it->band0 == band0 && it->band1 == band1 && it->channels == channels && same_request(it->key, rq)) {
-            g_plans.splice(g_plans.begin(), g_plans, it);
-            *out = &g_plans.front();
-            return AAI_OK;
-        }
-    }
+    auto cached = [&](int b0, int b1, int ch) -> bool {
+        for (auto it = g_plans.begin(); it != g_plans.end(); ++it)
+            if (it->device == dev && it->band0 == b0 && it->band1 == b1 && it->channels == ch && same_request(it->key, rq)) {
+                g_plans.splice(g_plans.begin(), g_plans, it);
+                *out = &g_plans.front();
+                return true;
+            }
+        return false;
+    };
+    if (cached(band0, band1, channels)) return AAI_OK;       // the common case costs no geometry set-up
     aai::Geometry g;
     std::string msg;
     int rc = aai::make_geometry(rq, g, msg);
     if (rc != AAI_OK) return fail(rc, msg);
+    if (pick_kernel(rq, g) != AAI_KERNEL_AXIS && (band0 >= 0 || channels != 1)) {
+        // Only K1's tables depend on the row band.  The per-pixel kernels take the band as launch parameters and their
+        // one-off scans cover the whole image, so every band and every channel count of a rotated request shares one plan.
+        band0 = band1 = -1; channels = 1;
+        if (cached(band0, band1, channels)) return AAI_OK;
+    }
 
     g_plans.emplace_front();
     Plan &p = g_plans.front();
