@@ -221,99 +221,144 @@ __device__ __forceinline__ void load_taps(const float *p, float (&t)[N])
 
 __device__ __forceinline__ void keys(float t, float w[4])
 {
+    // Every multiply-add spelled out: the planar fast path and the general path (typed sources, interleaved channels) must
+    // round these weights alike, whatever the compiler would fuse in either place.
     const float a = -0.5f, t2 = t * t, t3 = t2 * t;
-    w[0] = a * (t3 - 2.f * t2 + t);
-    w[1] = (a + 2.f) * t3 - (a + 3.f) * t2 + 1.f;
-    w[2] = -(a + 2.f) * t3 + (2.f * a + 3.f) * t2 - a * t;
-    w[3] = a * (t2 - t3);
+    w[0] = a * (fmaf(-2.f, t2, t3) + t);                                  // a (t^3 - 2 t^2 + t)
+    w[1] = fmaf(a + 2.f, t3, fmaf(-(a + 3.f), t2, 1.f));                  // (a + 2) t^3 - (a + 3) t^2 + 1
+    w[2] = fmaf(-(a + 2.f), t3, fmaf(2.f * a + 3.f, t2, -(a * t)));       // -(a + 2) t^3 + (2 a + 3) t^2 - a t
+    w[3] = a * (t2 - t3);                                                 // a (t^2 - t^3)
 }
+
+// one sample point: integer tap origin, fractions, and whether it lies outside the image extent
+struct SamplePoint { int ix, iy; float tx, ty; bool outside; };
+
+// the sample point of dst pixel (dx, dy) in continuous original-image coordinates: affine in (dx, dy), coefficients from
+// the host (the same expression for every caller, so that row bands reproduce the full image bit for bit)
+__device__ __forceinline__ SamplePoint sample_point(const RotLaunch &r, int dx, int dy)
+{
+    const double ddx = (double)dx, ddy = (double)dy;
+    const double sx = fma(ddx, r.sAx, fma(ddy, r.sBx, r.sCx)), sy = fma(ddx, r.sAy, fma(ddy, r.sBy, r.sCy));
+    // (a guard of 1e-9 pixels on the extent: points exactly on its edge are inside however the map was rounded)
+    const double guard = 1e-9;
+    SamplePoint p;
+    p.outside = sx < -0.5 - guard || sx > r.W - 0.5 + guard || sy < -0.5 - guard || sy > r.H - 0.5 + guard;
+    const double fx = floor(sx), fy = floor(sy);
+    p.ix = p.outside ? 0 : (int)fx; p.iy = p.outside ? 0 : (int)fy;
+    p.tx = (float)(sx - fx); p.ty = (float)(sy - fy);
+    return p;
+}
+
+// rows of dst pixels per wave (a wave = 64 consecutive dx): with one row per wave the kernel was bound by the latency of a
+// wave's life -- coordinates, two dependent loads, one store -- not by instructions or bytes
+template <int MODE> struct SampleRows { static constexpr int value = MODE == AAI_MODE_BILINEAR ? 4 : 2; };      // (8 rows: 1.84 ms where 4 take 1.11)
 
 template <int MODE, typename T>
 __global__ __launch_bounds__(kBlock) void aai_sample_kernel(RotLaunch r, const T *__restrict__ src, ImageView sv,
                                                              float *__restrict__ dst, ImageView dv)
 {
-    const int dx = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int dy = r.dyBase + blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (dx >= r.dW || dy >= r.dyEnd) return;
-    const T *img = src + (int64_t)blockIdx.z * sv.imageStride;
-    // the sample point in continuous original-image coordinates: affine in (dx, dy), coefficients from the host
-    const double ddx = (double)dx, ddy = (double)dy;
-    const double sx = fma(ddx, r.sAx, fma(ddy, r.sBx, r.sCx)), sy = fma(ddx, r.sAy, fma(ddy, r.sBy, r.sCy));
-    const int chan = r.chan > 1 ? r.chan : 1;          // interleaved channels share the taps' positions and weights
-    float *out = dst + (int64_t)blockIdx.z * dv.imageStride + (int64_t)(dy - r.dyBase) * dv.rowStride + (int64_t)dx * chan;
-    // (a guard of 1e-9 pixels on the extent: points exactly on its edge are inside however the map was rounded)
-    const double guard = 1e-9;
-    const bool outside = sx < -0.5 - guard || sx > r.W - 0.5 + guard || sy < -0.5 - guard || sy > r.H - 0.5 + guard;
-    const double fx = floor(sx), fy = floor(sy);
-    const int ix = outside ? 0 : (int)fx, iy = outside ? 0 : (int)fy;
-    const float tx = (float)(sx - fx), ty = (float)(sy - fy);
-    // clamp-to-edge taps: column offsets (elements) and row offsets once per pixel, then plain loads
+    constexpr int R = SampleRows<MODE>::value;
     constexpr int N = MODE == AAI_MODE_BILINEAR ? 2 : 4, FIRST = MODE == AAI_MODE_BILINEAR ? 0 : -1;
-    int xo[N];
-    int64_t yo[N];
+    const int dx = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);    // wave-uniform: row addresses are scalar
+    const int dy0 = r.dyBase + (blockIdx.y * 4 + wave) * R;
+    if (dx >= r.dW || dy0 >= r.dyEnd) return;
+    const int nRows = min(R, r.dyEnd - dy0);
+    const T *img = src + (int64_t)blockIdx.z * sv.imageStride;
+    const int chan = r.chan > 1 ? r.chan : 1;          // interleaved channels share the taps' positions and weights
+    float *outRow0 = dst + (int64_t)blockIdx.z * dv.imageStride + (int64_t)(dy0 - r.dyBase) * dv.rowStride;
+
+    SamplePoint pt[R];
+    bool whole = true;          // no tap column of this lane is clamped (or the point is outside: no taps at all)
 #pragma unroll
-    for (int i = 0; i < N; ++i) {
-        xo[i] = min(max(ix + FIRST + i, 0), r.W - 1) * chan;
-        yo[i] = (int64_t)(min(max(iy + FIRST + i, 0), r.H - 1) - r.srcRow0) * sv.rowStride;
+    for (int j = 0; j < R; ++j) {
+        pt[j] = sample_point(r, dx, dy0 + (j < nRows ? j : 0));
+        whole = whole && (pt[j].outside || (pt[j].ix + FIRST >= 0 && pt[j].ix + FIRST + N <= r.W));
     }
-    float wx[4], wy[4];
-    if (MODE != AAI_MODE_BILINEAR) { keys(tx, wx); keys(ty, wy); }
-    // The N taps of a tap row are neighbours in memory: one vector load per row instead of N scalar ones (neighbouring
+    // The N taps of a tap row are neighbours in memory: one vector load per tap row instead of N scalar ones (neighbouring
     // lanes sample a fraction of a pixel apart along a slanted line, so every load instruction touches ~10 cache lines
-    // and their number is what the texture path charges for: 16 -> 4 per bicubic sample).  Plain fp32 images, and only
-    // while no lane of the wave has a clamped column.
-    const bool wholeRow = outside || (ix + FIRST >= 0 && ix + FIRST + N <= r.W);
-    if (sizeof(T) == 4 && chan == 1 && __all(wholeRow)) {
-        float v = 0.f;
-        if (!outside) {
-            const float *base = reinterpret_cast<const float *>(img) + xo[0];
-            float rows[N];
+    // and their number is what the texture path charges for: 16 -> 4 per bicubic sample), all R x N of them in flight
+    // together.  Plain fp32 images below 4 GiB (a scalar base plus an unsigned 32-bit byte offset per lane), and only while
+    // no lane of the wave has a clamped column.
+    const bool below4G = (int64_t)r.H * sv.rowStride * (int64_t)sizeof(T) < ((int64_t)1 << 32);
+    if (sizeof(T) == 4 && chan == 1 && below4G && __all(whole)) {
+        const char *base = reinterpret_cast<const char *>(img) - (int64_t)r.srcRow0 * sv.rowStride * 4;
+        const unsigned rowBytes = (unsigned)sv.rowStride * 4u;
+        float t[R][N][N];
 #pragma unroll
-            for (int j = 0; j < N; ++j) {
-                float t[N];
-                load_taps<N>(base + yo[j], t);
-                if (MODE == AAI_MODE_BILINEAR) rows[j] = fmaf(t[1] - t[0], tx, t[0]);
+        for (int j = 0; j < R; ++j) {
+            const unsigned colBytes = (unsigned)(pt[j].ix + FIRST) * 4u;
+#pragma unroll
+            for (int k = 0; k < N; ++k) {
+                const unsigned row = (unsigned)min(max(pt[j].iy + FIRST + k, 0), r.H - 1);
+                if (!pt[j].outside) load_taps<N>(reinterpret_cast<const float *>(base + (row * rowBytes + colBytes)), t[j][k]);
                 else {
-                    float row = 0.f;
 #pragma unroll
-                    for (int i = 0; i < N; ++i) row = fmaf(wx[i], t[i], row);
-                    rows[j] = row;
+                    for (int i = 0; i < N; ++i) t[j][k][i] = 0.f;
                 }
             }
-            if (MODE == AAI_MODE_BILINEAR) v = fmaf(rows[N - 1] - rows[0], ty, rows[0]);
-            else {
-#pragma unroll
-                for (int j = 0; j < N; ++j) v = fmaf(wy[j], rows[j], v);
-            }
         }
-        out[0] = v;
+#pragma unroll
+        for (int j = 0; j < R; ++j) {
+            float v;
+            if (MODE == AAI_MODE_BILINEAR) {
+                const float top = fmaf(t[j][0][1] - t[j][0][0], pt[j].tx, t[j][0][0]), bot = fmaf(t[j][1][1] - t[j][1][0], pt[j].tx, t[j][1][0]);
+                v = fmaf(bot - top, pt[j].ty, top);
+            } else {
+                float wx[4], wy[4];
+                keys(pt[j].tx, wx); keys(pt[j].ty, wy);
+                v = 0.f;
+#pragma unroll
+                for (int k = 0; k < N; ++k) {
+                    float row = 0.f;
+#pragma unroll
+                    for (int i = 0; i < N; ++i) row = fmaf(wx[i], t[j][k][i], row);
+                    v = fmaf(wy[k], row, v);
+                }
+            }
+            if (j < nRows) outRow0[(int64_t)j * dv.rowStride + dx] = pt[j].outside ? 0.f : v;
+        }
         return;
     }
-    if (outside) {
-        for (int c = 0; c < chan; ++c) out[c] = 0.f;
-        return;
-    }
-    for (int c = 0; c < chan; ++c) {
-        const T *ch = img + c;
-        float v;
-        if (MODE == AAI_MODE_BILINEAR) {
-            const float v00 = (float)ch[yo[0] + xo[0]], v10 = (float)ch[yo[0] + xo[1]];
-            const float v01 = (float)ch[yo[N - 1] + xo[0]], v11 = (float)ch[yo[N - 1] + xo[1]];
-            // explicit fused multiply-adds: the same rounding whatever the compiler does with the channel loop
-            const float top = fmaf(v10 - v00, tx, v00), bot = fmaf(v11 - v01, tx, v01);
-            v = fmaf(bot - top, ty, top);
-        } else {
-            float acc = 0.f;
-#pragma unroll
-            for (int j = 0; j < N; ++j) {
-                float row = 0.f;
-#pragma unroll
-                for (int i = 0; i < N; ++i) row = fmaf(wx[i], (float)ch[yo[j] + xo[i]], row);
-                acc = fmaf(wy[j], row, acc);
-            }
-            v = acc;
+    // the general path, row by row: clamp-to-edge taps, typed sources, interleaved channels
+    for (int j = 0; j < nRows; ++j) {
+        const SamplePoint p = pt[j];
+        float *out = outRow0 + (int64_t)j * dv.rowStride + (int64_t)dx * chan;
+        if (p.outside) {
+            for (int c = 0; c < chan; ++c) out[c] = 0.f;
+            continue;
         }
-        out[c] = v;
+        int xo[N];
+        int64_t yo[N];
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            xo[i] = min(max(p.ix + FIRST + i, 0), r.W - 1) * chan;
+            yo[i] = (int64_t)(min(max(p.iy + FIRST + i, 0), r.H - 1) - r.srcRow0) * sv.rowStride;
+        }
+        float wx[4], wy[4];
+        if (MODE != AAI_MODE_BILINEAR) { keys(p.tx, wx); keys(p.ty, wy); }
+        for (int c = 0; c < chan; ++c) {
+            const T *ch = img + c;
+            float v;
+            if (MODE == AAI_MODE_BILINEAR) {
+                const float v00 = (float)ch[yo[0] + xo[0]], v10 = (float)ch[yo[0] + xo[1]];
+                const float v01 = (float)ch[yo[N - 1] + xo[0]], v11 = (float)ch[yo[N - 1] + xo[1]];
+                // explicit fused multiply-adds: the same rounding whatever the compiler does with the channel loop
+                const float top = fmaf(v10 - v00, p.tx, v00), bot = fmaf(v11 - v01, p.tx, v01);
+                v = fmaf(bot - top, p.ty, top);
+            } else {
+                float acc = 0.f;
+#pragma unroll
+                for (int k = 0; k < N; ++k) {
+                    float row = 0.f;
+#pragma unroll
+                    for (int i = 0; i < N; ++i) row = fmaf(wx[i], (float)ch[yo[k] + xo[i]], row);
+                    acc = fmaf(wy[k], row, acc);
+                }
+                v = acc;
+            }
+            out[c] = v;
+        }
     }
 }
 
@@ -359,13 +404,14 @@ static bool quad_serves(const RotLaunch &r, int srcType, ImageView sv)
     return r.quad && rot_tune().quad != 0 && (r.mode == AAI_MODE_AREA || (r.mode == AAI_MODE_FAST && r.chan == 1)) && quad_can_address(r, srcType, sv);
 }
 
-// one launch of at most 65535 tile rows (sampler: 4-row tiles, the others 16-row tiles)
+// one launch of at most 65535 tile rows (16-row tiles; the bicubic sampler: 8-row tiles)
 template <typename T>
 static hipError_t launch_rotated_band(const RotLaunch &r, const QuadMap &m, const T *src, int srcType, ImageView sv, float *dst, ImageView dv,
                                       int batch, const RotFlags &flags, hipStream_t stream, const char **kernelName)
 {
     if (r.mode == AAI_MODE_BILINEAR || r.mode == AAI_MODE_BICUBIC) {
-        dim3 grid((r.dW + 63) / 64, (r.dyEnd - r.dyBase + 3) / 4, batch);
+        const int tileRows = 4 * (r.mode == AAI_MODE_BILINEAR ? SampleRows<AAI_MODE_BILINEAR>::value : SampleRows<AAI_MODE_BICUBIC>::value);
+        dim3 grid((r.dW + 63) / 64, (r.dyEnd - r.dyBase + tileRows - 1) / tileRows, batch);
         if (r.mode == AAI_MODE_BILINEAR) {
             if (kernelName) *kernelName = "aai_sample_kernel<bilinear>";
             hipLaunchKernelGGL((aai_sample_kernel<AAI_MODE_BILINEAR, T>), grid, dim3(kBlock), 0, stream, r, src, sv, dst, dv);
@@ -423,7 +469,7 @@ static hipError_t launch_rotated_typed(const RotLaunch &r, const QuadMap &m, con
                                        int batch, const RotFlags &flags, hipStream_t stream, const char **kernelName)
 {
     if (r.dW <= 0 || r.dyEnd <= r.dyBase || batch <= 0) return hipSuccess;
-    // grid.y carries at most 65535 tiles: taller outputs (more than ~1M rows, 262k for the samplers) go in several launches
+    // grid.y carries at most 65535 tiles: taller outputs (more than ~1M rows, 524k for the bicubic sampler) go in several launches
     const bool sampler = r.mode == AAI_MODE_BILINEAR || r.mode == AAI_MODE_BICUBIC;
     if (!sampler && flags.dense) {
         // (nearly) every pixel sits on a knife edge: the double-precision pass computes the whole image
@@ -436,7 +482,7 @@ static hipError_t launch_rotated_typed(const RotLaunch &r, const QuadMap &m, con
         }
         return hipGetLastError();
     }
-    const int maxRows = kMaxGridY * (sampler ? 4 : 16);
+    const int maxRows = kMaxGridY * (r.mode == AAI_MODE_BICUBIC ? 8 : 16);
     // The double-precision pass over the pixels the plan's scans flagged (none for the samplers).  Behind the production
     // pass on the same stream -- or, when the production kernel is the quad kernel and skips those pixels, beside it on
     // the plan's side stream: fork before, join after.
