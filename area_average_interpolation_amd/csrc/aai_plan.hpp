@@ -70,6 +70,7 @@ struct QuadMap {
     // interleaved 8- / 16-bit pixels are fetched with one 4- / 8-byte load each, which may reach past the pixel: loads start
     // no later than lastLoad4 / lastLoad8 (byte offsets of the last 4 / 8 bytes of the image) and shift the rest away
     uint32_t lastLoad4, lastLoad8;
+    int anchorRows;              // set by the launcher for plain images of 4 GiB and more: offsets are relative to an anchor row per wave (QuadSrc::issue)
 };
 QuadMap make_quad_map(const Geometry &g, int64_t rowStride, int srcRow0, int channels = 1, int elementBytes = 4);      // channels: elements per pixel (interleaved)
 

@@ -68,14 +68,14 @@ struct QuadSrc {
 
     __device__ __forceinline__ void issue(int xg0, int yg0, unsigned long long)
     {
-        unsigned colOff[WIN], rowOff[WIN];
+        unsigned colOff[WIN], rowOff[WIN];            // source indices along virtual X / Y first, byte offsets below
         const unsigned sxb = (unsigned)m->strideX * (unsigned)sizeof(T), syb = (unsigned)m->strideY * (unsigned)sizeof(T);
         if (!SCALED) {
 #pragma unroll
             for (int i = 0; i < WIN; ++i) {
                 const int X = min(max(xg0 + i, 0), mW - 1), Y = min(max(yg0 + i, 0), mH - 1);
-                colOff[i] = (unsigned)(m->flipX ? m->nX - 1 - X : X) * sxb;
-                rowOff[i] = (unsigned)(m->flipY ? m->nY - 1 - Y : Y) * syb;
+                colOff[i] = (unsigned)(m->flipX ? m->nX - 1 - X : X);
+                rowOff[i] = (unsigned)(m->flipY ? m->nY - 1 - Y : Y);
             }
         } else {
             // floor division of coordinates that are >= -8 (the window meets the lattice): exact, (n + 0.5) / scale is
@@ -89,10 +89,25 @@ struct QuadSrc {
             for (int i = 0; i < WIN; ++i) {
                 const int ix = min(max(xg0 + i, 0), mW - 1) - xg0, iy = min(max(yg0 + i, 0), mH - 1) - yg0;
                 const int qx = qx0 - 8 + (int)((remX + (float)ix) * m->invScale), qy = qy0 - 8 + (int)((remY + (float)iy) * m->invScale);
-                colOff[i] = (unsigned)(m->flipX ? m->nX - 1 - qx : qx) * sxb;
-                rowOff[i] = (unsigned)(m->flipY ? m->nY - 1 - qy : qy) * syb;
+                colOff[i] = (unsigned)(m->flipX ? m->nX - 1 - qx : qx);
+                rowOff[i] = (unsigned)(m->flipY ? m->nY - 1 - qy : qy);
             }
         }
+        // Images of 4 GiB and more: offsets are taken from an anchor row of this WAVE instead of the image's first row --
+        // every lane of a 16 x 4 dst tile reads within anchorRows source rows of any other lane (QuadMap::anchorRows, 0
+        // for smaller images), so the anchor is one lane's first row less that bound and the base pointer moves with it
+        if (m->anchorRows) {
+            const bool rowsAlongX = sxb > syb;           // wave-uniform: which window axis walks the source rows
+            const int first = __builtin_amdgcn_readfirstlane((int)(rowsAlongX ? colOff[0] : rowOff[0]));
+            const unsigned anchor = (unsigned)max(first - m->anchorRows, 0);
+            img += (int64_t)anchor * (int64_t)(rowsAlongX ? sxb : syb);
+#pragma unroll
+            for (int i = 0; i < WIN; ++i) {
+                if (rowsAlongX) colOff[i] -= anchor; else rowOff[i] -= anchor;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < WIN; ++i) { colOff[i] *= sxb; rowOff[i] *= syb; }
         // Without replication one axis of the window is contiguous in memory (virtual X along source x in quadrants 0 / 2,
         // virtual Y in 1 / 3): fetch each of its WIN lines with one or two vector loads instead of WIN scalar ones -- lanes
         // are L source pixels apart, so every load instruction touches a dozen cache lines and their NUMBER is what the
@@ -486,11 +501,24 @@ hipError_t launch_quad_typed(const RotLaunch &r, const QuadMap &m, const T *src,
 
 }  // namespace
 
+// How many source rows apart two lanes of one wave (a 16 x 4 dst tile) can read: their centres differ by at most
+// 15.6 dst pixel sides, each reaches half a window further, plus slack for rounding and clamping.
+static int quad_anchor_rows(const RotLaunch &r)
+{
+    const int win = (int)floor(2.0 * (r.h * (r.c + r.s) - 0.5 + 1e-5)) + 3;
+    return (int)ceil(15.6 * 2.0 * r.h / r.scale) + win + 4;
+}
+
 bool quad_can_address(const RotLaunch &r, int srcType, ImageView sv)
 {
-    // lanes address their pixels with unsigned 32-bit byte offsets from the image's first element
+    // lanes address their pixels with unsigned 32-bit byte offsets from the image's first element -- or, for plain images
+    // of 4 GiB and more, from an anchor row of their wave (quad_anchor_rows)
     const int64_t esz = srcType == SRC_U8 ? 1 : srcType == SRC_U16 ? 2 : 4;
-    if ((int64_t)r.H * sv.rowStride * esz >= ((int64_t)1 << 32)) return false;
+    if ((int64_t)r.H * sv.rowStride * esz >= ((int64_t)1 << 32)) {
+        if (r.chan > 1) return false;
+        const int win = (int)floor(2.0 * (r.h * (r.c + r.s) - 0.5 + 1e-5)) + 3;
+        if ((int64_t)(2 * quad_anchor_rows(r) + win + 2) * sv.rowStride * esz >= ((int64_t)1 << 32)) return false;
+    }
     if (r.chan > 1) {
         // interleaved channels: the staged window (win^2 slots of `words` LDS words per lane) must leave room for two
         // workgroups per CU
@@ -501,10 +529,13 @@ bool quad_can_address(const RotLaunch &r, int srcType, ImageView sv)
     return true;
 }
 
-hipError_t launch_quad(const RotLaunch &r, const QuadMap &m, const void *src, int srcType, ImageView sv, float *dst, ImageView dv,
+hipError_t launch_quad(const RotLaunch &r, const QuadMap &map, const void *src, int srcType, ImageView sv, float *dst, ImageView dv,
                        int batch, const unsigned long long *skipMasks, hipStream_t stream)
 {
     if (r.dW <= 0 || r.dyEnd <= r.dyBase || batch <= 0) return hipSuccess;
+    QuadMap m = map;
+    const int64_t esz = srcType == SRC_U8 ? 1 : srcType == SRC_U16 ? 2 : 4;
+    m.anchorRows = (int64_t)r.H * sv.rowStride * esz >= ((int64_t)1 << 32) ? quad_anchor_rows(r) : 0;
     switch (srcType) {
     case SRC_U8: return launch_quad_typed(r, m, static_cast<const unsigned char *>(src), sv, dst, dv, batch, skipMasks, stream);
     case SRC_U16: return launch_quad_typed(r, m, static_cast<const unsigned short *>(src), sv, dst, dv, batch, skipMasks, stream);
