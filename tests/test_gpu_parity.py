@@ -805,6 +805,11 @@ def test_double_precision_policy(gpu, po):
         for c in range(3):
             g = po.oracle_run(omode, isrc[:, :, c].astype(np.float64), sr, dr, iso, ang, policy=1).dst
             assert rel_err(idst[:, :, c], g).max() <= 1.5e-7
+        # multiples of 90 degrees and the samplers have no fp32 formulation to leave: the flag changes nothing there
+        for (a2, m2) in ((90.0, mode), (17.5, 3)):
+            rc, msg, a, _, _ = gpu.resample_host(src, sr, dr, iso, a2, mode=m2, policy=0)
+            rc2, msg2, b, _, _ = gpu.resample_host(src, sr, dr, iso, a2, mode=m2, policy=flag)
+            assert rc == 0 and rc2 == 0 and np.array_equal(a, b), (a2, m2)
 
 
 def test_outputs_taller_than_one_grid(gpu, po):
