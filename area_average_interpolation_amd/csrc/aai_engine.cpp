@@ -36,7 +36,7 @@ int hip_fail(hipError_t e, const char *what)
 // ---- plan cache ------------------------------------------------------------------------------------
 std::mutex g_planMutex;
 std::list<Plan> g_plans;              // most recently used first
-constexpr size_t kMaxPlans = 32;
+constexpr size_t kMaxPlans = 32;       // per device
 constexpr unsigned kMaxListedPixels = 1u << 24;      // beyond 16 M flagged pixels the whole image takes the double-precision pass
 
 bool same_request(const aai_request &a, const aai_request &b)
@@ -260,7 +260,13 @@ int get_plan(const aai_request &rq, int band0, int band1, int channels, Plan **o
         if (e != hipSuccess) { g_plans.pop_front(); return hip_fail(e, verifyAxis ? "axis model scan" : "knife-edge scan"); }
         p.flaggedPixels = count;
     }
-    while (g_plans.size() > kMaxPlans) g_plans.pop_back();
+    // the cache is sized per device: the least recently used plans of THIS device go first
+    size_t mine = 0;
+    for (const Plan &q : g_plans) mine += q.device == dev ? 1 : 0;
+    for (auto it = g_plans.end(); mine > kMaxPlans && it != g_plans.begin();) {
+        --it;
+        if (it->device == dev) { it = g_plans.erase(it); --mine; }
+    }
     *out = &p;
     return AAI_OK;
 }
