@@ -840,6 +840,59 @@ def test_outputs_taller_than_one_grid(gpu, po):
         del out
 
 
+def test_concurrent_host_threads(gpu):
+    """Four host threads, each with its own HIP stream, issue 60 requests over 45 distinct geometries (more than the plan
+    cache holds per device, so plans are built, reused and evicted under contention; ctypes releases the GIL during the
+    calls): every result equals the one a single thread computed before, bit for bit, and errors stay per thread."""
+    import threading
+    import torch
+    geoms = []
+    for k in range(45):
+        W, H = 96 + 8 * (k % 7), 80 + 4 * (k % 5)
+        geoms.append((W, H, float(1 + k % 4), 1.0, ((W - 1) / 2, (H - 1) / 2), (0.0, 90.0, 17.5, 45.0, 200.0, 0.5)[k % 6], 1 + k % 4))
+    rng = np.random.default_rng(3)
+    srcs = {}
+    for (W, H, *_rest) in geoms:
+        if (W, H) not in srcs:
+            srcs[(W, H)] = torch.from_numpy(rng.random((H, W)).astype(np.float32)).cuda()
+
+    def run(g, stream):
+        W, H, sr, dr, iso, ang, mode = g
+        rq = gpu.make_request(W, H, sr, dr, iso, ang, mode=mode)
+        rc, msg, lay = gpu.query(rq)
+        assert rc == 0, msg
+        out = torch.empty((lay.dst_height, lay.dst_width), dtype=torch.float32, device="cuda")
+        gpu.resample_device(rq, srcs[(W, H)].data_ptr(), W, out.data_ptr(), lay.dst_width, stream.cuda_stream)
+        stream.synchronize()
+        return out.cpu().numpy()
+
+    main = torch.cuda.current_stream()
+    expected = [run(g, main) for g in geoms]
+    failures = []
+
+    def worker(tid):
+        try:
+            stream = torch.cuda.Stream()
+            order = np.random.default_rng(100 + tid).integers(0, len(geoms), size=60)
+            for k in order:
+                got = run(geoms[int(k)], stream)
+                if not np.array_equal(got, expected[int(k)]):
+                    failures.append((tid, int(k), "result differs"))
+                if tid == 0 and k % 7 == 0:         # an error on this thread must not leak into the others' last_error
+                    rc, msg, _lay = gpu.query(gpu.make_request(8, 8, 1.0, 0.0, (0.0, 0.0), 0.0))
+                    if rc == 0 or "resolution" not in msg:
+                        failures.append((tid, int(k), "error text", msg))
+        except Exception as e:                      # noqa: BLE001
+            failures.append((tid, repr(e)))
+
+    threads = [threading.Thread(target=worker, args=(t,)) for t in range(4)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not failures, failures[:5]
+
+
 def test_sources_larger_than_4_gib(gpu, po):
     """A 33,000 x 33,000 fp32 source (4.36 GB: byte offsets from the image's first element no longer fit 32 bits) and, for
     K1, a 46,500 x 46,500 one (8.6 GB, 2.16 G elements: past 32-bit element offsets too): K1 streams them, the fp32
