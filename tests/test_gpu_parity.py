@@ -713,9 +713,9 @@ def test_multi_device_entry_and_prepare(gpu):
     process -- on this one-GPU box both shards live on device 0, on two streams -- bit-identical to the batched call.
     aai_prepare builds the plan up front, so that a captured stream only sees launches."""
     import torch
-    W = H = 768
-    for (sr, dr, ang) in ((4, 1, 0.0), (3, 1, 17.5)):
-        rq = gpu.make_request(W, H, sr, dr, ((W - 1) / 2, (H - 1) / 2), ang)
+    # (the third geometry: K1 with a fix-up list behind it; the fourth: fast mode, fix-up beside the kernel on the side stream)
+    for (W, H, sr, dr, ang, mode) in ((768, 768, 4, 1, 0.0, 1), (768, 768, 3, 1, 17.5, 1), (40, 9, 3, 1, 0.0, 1), (768, 768, 2, 1, 45.0, 2)):
+        rq = gpu.make_request(W, H, sr, dr, ((W - 1) / 2, (H - 1) / 2), ang, mode=mode)
         gpu.prepare(rq)
         rc, msg, lay = gpu.query(rq)
         dW, dH = lay.dst_width, lay.dst_height
