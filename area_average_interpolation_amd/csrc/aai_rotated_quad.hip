@@ -1,7 +1,7 @@
-// aai_rotated_quad.hip -- K2, the area average at a general rotation, in its fp32 "quad" formulation for gfx950
-// (the arithmetic lives in aai_rot_quad.hpp, shared with the CPU replay of the test-suite).
+// aai_rotated_quad.hip -- K2, the area average at a general rotation, in its fp32 "quad" formulation for gfx950, and K3,
+// fast mode, in the same frame (the arithmetic lives in aai_rot_quad.hpp, shared with the CPU replay of the test-suite).
 //
-// Replaces Source.cpp:413-579 + 986-1431 of the reference.  One lane per dst pixel, a wave covers a 16 x 4 dst
+// Replaces Source.cpp:413-579 + 986-1431 (area) and 868-907 + 837-864 (fast) of the reference.  One lane per dst pixel, a wave covers a 16 x 4 dst
 // tile, no barrier.  The dst pixel's centre is the only double-precision quantity (coordinates reach ~3e4 virtual
 // pixels); everything after it is relative to the nearest virtual pixel and runs in fp32 at twice the fp64 issue
 // rate and half the registers.
@@ -10,13 +10,17 @@
 // window is classified), parks it in one LDS column of its own (slot-major, so a wave's accesses are conflict
 // free and no barrier is needed) and the area passes read values at LDS latency instead of waiting for a
 // dependent global load per (dst, src) pair -- with loads inside the passes the kernel spent 42 % of its wave
-// cycles in s_waitcnt (profiles/r02_quad_counters.txt).  The bound is VALU issue, not HBM: cfg3 moves 26.9
+// cycles in s_waitcnt (profiles/r02_cfg3_sq_counters.txt).  The bound is VALU issue, not HBM: cfg3 moves 26.9
 // algorithmic bytes per dst pixel through ~1.1 k vector instructions per wave.
 //
 // The production kernel takes no numerically delicate decision by itself: the plan runs the SCAN kernel once per
 // geometry (same code, no pixel loads); pixels it flags -- a decision within QuadConsts::margin of its threshold,
 // or a border pixel with too little total area for fp32 weights -- are recomputed afterwards by the
 // double-precision fix-up pass (aai_rotated_kernel<STRICT>), exactly like the knife-edge pixels.
+//
+// Kernels: aai_quad_kernel (plain images), aai_quad_multi_kernel (2..4 interleaved channels, packed LDS slots),
+// aai_quad_fast_kernel (fast mode: window in registers, no LDS), aai_quad_scan_kernel (the plan's scan for all three),
+// aai_flag_list_kernel (flag words -> pixel list).
 #include "aai_kernels.hpp"
 #include "aai_rot_quad.hpp"
 
