@@ -134,7 +134,8 @@ int aai_device_synchronize(void);
 int aai_resample_f32(const aai_request *req, const float *src, int64_t src_stride,
                      float *dst, int64_t dst_stride, aai_layout *layout);
 /* Same with the reference's element type (IMG = vector<vector<double>>, Source.cpp:31).  The device
- * computes on fp32 pixels (weights and geometry in fp64); results agree with the reference to 1e-5 relative. */
+ * computes on fp32 pixels (geometry in fp64, weights in fp32 relative to the nearest source pixel or fp64, see
+ * AAI_POLICY_DOUBLE_PRECISION); results agree with the reference to 1e-5 relative. */
 int aai_resample_f64(const aai_request *req, const double *src, int64_t src_stride,
                      double *dst, int64_t dst_stride, aai_layout *layout);
 
