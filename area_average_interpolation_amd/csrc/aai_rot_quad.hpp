@@ -63,6 +63,7 @@ struct QuadConsts {
     int hiPrec;
     F marginT;                        // SCAN, hiPrec: margin of the t thresholds lo / hi taken on the precise t
     double cD, sD, hpkD;
+    double oxD[4], oyD[4], m1D, im1D;     // hiPrec: the vertex offsets and edge slopes in double precision
 };
 
 // fp32 error budget of a coordinate relative to the dst pixel's centre: the constants' rounding times an index of at
@@ -117,6 +118,9 @@ AAI_HD QuadConsts<F> make_quad_consts(double side, double c, double s, int polic
     q.hiPrec = quad_needs_hiprec(side, c, s) ? 1 : 0;
     q.marginT = (F)(1e-6 * lo);
     q.cD = c; q.sD = s; q.hpkD = h + k;
+    q.oxD[0] = o0x; q.oyD[0] = o0y; q.oxD[1] = o1x; q.oyD[1] = o1y;
+    q.oxD[2] = -o1x; q.oyD[2] = -o1y; q.oxD[3] = -o0x; q.oyD[3] = -o0y;
+    q.m1D = s / c; q.im1D = c / s;
     return q;
 }
 
@@ -185,7 +189,9 @@ AAI_HD F quad_double(const QuadConsts<F> &q, F A, F B, F tpA, bool flipA, F tpB,
 // sum over the pixel's sides of (distance of the vertex from the side) x (length of the side inside the wedge);
 // vertices 1-3 are vertex 0 seen through a quarter turn.  Exact for both policies (Source.cpp:1276-1401).
 template <typename F>
-AAI_HD F quad_vertex_area(const QuadConsts<F> &q, F fx, F fy, int vidx)
+AAI_HD F quad_vertex_area(const QuadConsts<F> &q, F fx, F fy, int vidx);
+template <typename F>
+AAI_HD F quad_vertex_area(F m1, F im1, F fx, F fy, int vidx)
 {
     F x, y;
     switch (vidx) {
@@ -196,12 +202,14 @@ AAI_HD F quad_vertex_area(const QuadConsts<F> &q, F fx, F fy, int vidx)
     }
     // vertex 0: the wedge opens towards +x between the rays (c,-s) and (s,c)
     const F dR = F(0.5) - x, dT = y + F(0.5), dB = F(0.5) - y;
-    const F y1 = qfma(-dR, q.m1, y), y2 = qfma(dR, q.im1, y);      // where the two rays meet the line x = 1/2
+    const F y1 = qfma(-dR, m1, y), y2 = qfma(dR, im1, y);          // where the two rays meet the line x = 1/2
     const F lenR = qmin(y2, F(0.5)) - qmax(y1, F(-0.5));
-    const F lenT = qmax(F(0), F(0.5) - qfma(dT, q.im1, x));  // ray 1 leaves through the top side
-    const F lenB = qmax(F(0), F(0.5) - qfma(dB, q.m1, x));   // ray 2 leaves through the bottom side
+    const F lenT = qmax(F(0), F(0.5) - qfma(dT, im1, x));    // ray 1 leaves through the top side
+    const F lenB = qmax(F(0), F(0.5) - qfma(dB, m1, x));     // ray 2 leaves through the bottom side
     return F(0.5) * qfma(dR, lenR, qfma(dT, lenT, dB * lenB));
 }
+template <typename F>
+AAI_HD F quad_vertex_area(const QuadConsts<F> &q, F fx, F fy, int vidx) { return quad_vertex_area<F>(q.m1, q.im1, fx, fy, vidx); }
 
 AAI_HD int quad_ctz(unsigned long long m)
 {
@@ -338,7 +346,13 @@ AAI_HD bool quad_pixel(const QuadConsts<F> &q, int Xc, int Yc, double dfx, doubl
         if (SCAN && (qabs(fx) > F(0.5) - q.margin || qabs(fy) > F(0.5) - q.margin)) uncertain = true;
         mDouble &= ~bit;
         if (valid & bit) {
-            const F area = quad_vertex_area(q, fx, fy, vtx);
+            F area;
+            if (HP) {
+                // near an axis one of the edge slopes is ~1 / min(c, s): the vertex's position inside its pixel in double
+                // precision (from the centre's double-precision fraction), the area formula in double as well
+                const double fxD = (dfx + q.oxD[vtx]) - (double)rx, fyD = (dfy + q.oyD[vtx]) - (double)ry;
+                area = (F)quad_vertex_area<double>(q.m1D, q.im1D, fxD, fyD, vtx);
+            } else area = quad_vertex_area(q, fx, fy, vtx);
             sumA += area;
             accumulate(area, slot);
         }
