@@ -61,6 +61,7 @@ struct QuadConsts {
     // h + k - |b| in double precision from the centre's double-precision fraction (three fp64 operations each per pair)
     // and only then rounds them to F.
     int hiPrec;
+    int steep;                        // hiPrec because of an edge slope ~1 / min(c, s): the vertex area formula in double precision too
     F marginT;                        // SCAN, hiPrec: margin of the t thresholds lo / hi taken on the precise t
     double cD, sD, hpkD;
     double oxD[4], oyD[4], m1D, im1D;     // hiPrec: the vertex offsets and edge slopes in double precision
@@ -94,7 +95,7 @@ AAI_HD bool quad_supported(double side, double c, double s)
 }
 
 template <typename F>
-AAI_HD QuadConsts<F> make_quad_consts(double side, double c, double s, int policy)
+AAI_HD QuadConsts<F> make_quad_consts(double side, double c, double s, int policy, int scale = 1)
 {
     QuadConsts<F> q;
     const double h = 0.5 * side, k = 0.5 * (c + s);
@@ -115,7 +116,11 @@ AAI_HD QuadConsts<F> make_quad_consts(double side, double c, double s, int polic
     q.minArea = (F)(side * side < 4.0 ? 0.25 * side * side : 1.0);
     q.ref = policy == AAI_POLICY_REFERENCE ? 1 : 0;
     q.win = (int)floor(2.0 * (hb - 0.5 + 1e-5)) + 3;
-    q.hiPrec = quad_needs_hiprec(side, c, s) ? 1 : 0;
+    // ... and with replicated source pixels (up-sampling): a dst pixel then covers one or two source pixels and a dst value is
+    // nearly a copy of a source value, so on noisy data it can be a hundred times smaller than its neighbours -- where the
+    // 1e-7 absolute error of an fp32 area shows as several 1e-6 relative (7e-6 on 8-bit noise; 4e-7 with hiPrec)
+    q.steep = quad_needs_hiprec(side, c, s) ? 1 : 0;
+    q.hiPrec = (q.steep || scale > 1) ? 1 : 0;
     q.marginT = (F)(1e-6 * lo);
     q.cD = c; q.sD = s; q.hpkD = h + k;
     q.oxD[0] = o0x; q.oyD[0] = o0y; q.oxD[1] = o1x; q.oyD[1] = o1y;
@@ -351,7 +356,8 @@ AAI_HD bool quad_pixel(const QuadConsts<F> &q, int Xc, int Yc, double dfx, doubl
                 // near an axis one of the edge slopes is ~1 / min(c, s): the vertex's position inside its pixel in double
                 // precision (from the centre's double-precision fraction), the area formula in double as well
                 const double fxD = (dfx + q.oxD[vtx]) - (double)rx, fyD = (dfy + q.oyD[vtx]) - (double)ry;
-                area = (F)quad_vertex_area<double>(q.m1D, q.im1D, fxD, fyD, vtx);
+                if (q.steep) area = (F)quad_vertex_area<double>(q.m1D, q.im1D, fxD, fyD, vtx);
+                else area = quad_vertex_area(q, (F)fxD, (F)fyD, vtx);
             } else area = quad_vertex_area(q, fx, fy, vtx);
             sumA += area;
             accumulate(area, slot);

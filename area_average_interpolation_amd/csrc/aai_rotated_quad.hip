@@ -482,7 +482,7 @@ template <typename T>
 hipError_t launch_quad_typed(const RotLaunch &r, const QuadMap &m, const T *src, ImageView sv, float *dst, ImageView dv, int batch,
                              const unsigned long long *skipMasks, hipStream_t stream)
 {
-    const QuadConsts<float> q = make_quad_consts<float>(r.side, r.c, r.s, r.policy);
+    const QuadConsts<float> q = make_quad_consts<float>(r.side, r.c, r.s, r.policy, r.scale);
     if (r.chan > 1) {
         switch (q.win) {
         case 3: return launch_quad_multi_win<T, 3>(r, q, m, src, sv, dst, dv, batch, skipMasks, stream);
@@ -550,7 +550,7 @@ hipError_t launch_quad(const RotLaunch &r, const QuadMap &map, const void *src, 
 hipError_t launch_quad_scan(const RotLaunch &r, unsigned long long *laneMasks, unsigned *counter, hipStream_t stream)
 {
     if (r.dW <= 0 || r.dH <= 0) return hipSuccess;
-    const QuadConsts<float> q = make_quad_consts<float>(r.side, r.c, r.s, r.policy);
+    const QuadConsts<float> q = make_quad_consts<float>(r.side, r.c, r.s, r.policy, r.scale);
     const int tileRows = (r.dH + 15) / 16;
     for (int t0 = 0; t0 < tileRows; t0 += 65535) {         // grid.y carries at most 65535 tiles
         const dim3 grid((r.dW + 15) / 16, tileRows - t0 < 65535 ? tileRows - t0 : 65535, 1);

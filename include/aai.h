@@ -65,9 +65,10 @@ enum {
                                  that are not multiples of 90 degrees) */
     /* OR into either policy: general rotations compute in double precision throughout (about 3 x the time).  The
      * default kernels evaluate overlap areas in fp32 relative to the nearest source pixel: each area is off by at most
-     * ~1e-7 ABSOLUTE (steep cases near the axes are taken in double precision), a dst value by ~5e-8 x the spread of the
-     * source values under its footprint -- inside the 1e-5 relative bar wherever a dst value is not hundreds of times
-     * smaller than those neighbours (fuzz of round 2: worst 8.5e-6 of max(|value|, 1e-3) over ~70 k random cases).  Images
+     * ~1e-7 ABSOLUTE (rotations near the axes and up-sampling take their edge parameters from double precision), a dst
+     * value by ~5e-8 x the spread of the source values under its footprint -- inside the 1e-5 relative bar wherever a
+     * dst value is not hundreds of times smaller than those neighbours (fuzz of round 2: worst 1-3e-6 of
+     * max(|value|, 1e-3) per 3,000 random cases).  Images
      * whose neighbouring values span many orders of magnitude can ask for double precision here. */
     AAI_POLICY_DOUBLE_PRECISION = 0x100
 };

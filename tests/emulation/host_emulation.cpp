@@ -304,7 +304,7 @@ static void emu_rotated(const Geometry &g, const aai_request &rq, const float *i
     g_quadPixels = g_quadUncertain = 0;
     const bool quad = g_useQuad && r.quad;
     const bool fastQuad = rq.mode == AAI_MODE_FAST;
-    const QuadConsts<float> qc = make_quad_consts<float>(r.side, r.c, r.s, r.policy);
+    const QuadConsts<float> qc = make_quad_consts<float>(r.side, r.c, r.s, r.policy, r.scale);
     for (int dy = 0; dy < r.dH; ++dy)
         for (int dx = 0; dx < r.dW; ++dx) {
             double px, py;
@@ -464,7 +464,7 @@ static void emu_quad_sums(const RotLaunch &r, const float *img, double px, doubl
         void commit() {}
         void at(int slot, F (&vals)[1]) const { vals[0] = (F)v[slot]; }
     } qs{&r, img, r.W, {}};
-    const QuadConsts<F> q = make_quad_consts<F>(r.side, r.c, r.s, r.policy);
+    const QuadConsts<F> q = make_quad_consts<F>(r.side, r.c, r.s, r.policy, r.scale);
     const double cxr = std::floor(px + 0.5), cyr = std::floor(py + 0.5);
     F a, va[1];
     if (q.hiPrec) quad_pixel<F, WIN, false, true, 1>(q, (int)cxr, (int)cyr, px - cxr, py - cyr, r.mW, r.mH, qs, a, va);
@@ -476,7 +476,7 @@ template <typename F, int WIN>
 static void emu_quad_slot_areas(const RotLaunch &r, double px, double py, double *areas)
 {
     struct Src { int hot; void issue(int, int, unsigned long long) {} void commit() {} void at(int slot, F (&vals)[1]) const { vals[0] = slot == hot ? F(1) : F(0); } };
-    const QuadConsts<F> q = make_quad_consts<F>(r.side, r.c, r.s, r.policy);
+    const QuadConsts<F> q = make_quad_consts<F>(r.side, r.c, r.s, r.policy, r.scale);
     const double cxr = std::floor(px + 0.5), cyr = std::floor(py + 0.5);
     for (int k = 0; k < WIN * WIN; ++k) {
         Src qs{k};
@@ -493,7 +493,7 @@ int aai_emu_quad_slot_debug(const aai_request *rq, int dx, int dy, double *f32ar
     if (make_geometry(*rq, g, msg) != AAI_OK) return -1;
     const RotLaunch r = make_rot_launch(g, AAI_MODE_AREA, rq->policy);
     double px, py; pixel_centre(r, dx, dy, px, py);
-    const QuadConsts<float> q = make_quad_consts<float>(r.side, r.c, r.s, r.policy);
+    const QuadConsts<float> q = make_quad_consts<float>(r.side, r.c, r.s, r.policy, r.scale);
     switch (q.win) {
     case 3: emu_quad_slot_areas<float, 3>(r, px, py, f32areas); emu_quad_slot_areas<double, 3>(r, px, py, f64areas); break;
     case 4: emu_quad_slot_areas<float, 4>(r, px, py, f32areas); emu_quad_slot_areas<double, 4>(r, px, py, f64areas); break;
@@ -595,7 +595,7 @@ int aai_emu_quad_pixel_debug(const aai_request *rq, int dx, int dy, const float 
     if (make_geometry(*rq, g, msg) != AAI_OK) return -1;
     const RotLaunch r = make_rot_launch(g, AAI_MODE_AREA, rq->policy);
     double px, py; pixel_centre(r, dx, dy, px, py);
-    const QuadConsts<float> q = make_quad_consts<float>(r.side, r.c, r.s, r.policy);
+    const QuadConsts<float> q = make_quad_consts<float>(r.side, r.c, r.s, r.policy, r.scale);
     switch (q.win) {
     case 3: emu_quad_sums<float, 3>(r, img, px, py, out4 + 0, out4 + 1); emu_quad_sums<double, 3>(r, img, px, py, out4 + 2, out4 + 3); break;
     case 4: emu_quad_sums<float, 4>(r, img, px, py, out4 + 0, out4 + 1); emu_quad_sums<double, 4>(r, img, px, py, out4 + 2, out4 + 3); break;
@@ -619,7 +619,7 @@ long aai_emu_quad_pair_check(const aai_request *rq, double *maxOld, double *maxS
     if (make_geometry(*rq, g, msg) != AAI_OK || g.axisAligned) return -1;
     const RotLaunch r = make_rot_launch(g, AAI_MODE_AREA, rq->policy);
     if (!quad_supported(r.side, r.c, r.s)) return -1;
-    const QuadConsts<double> q = make_quad_consts<double>(r.side, r.c, r.s, r.policy);
+    const QuadConsts<double> q = make_quad_consts<double>(r.side, r.c, r.s, r.policy, r.scale);
     long n = 0;
     for (int dy = 0; dy < r.dH; ++dy)
         for (int dx = 0; dx < r.dW; ++dx) {
