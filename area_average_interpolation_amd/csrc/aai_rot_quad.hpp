@@ -63,7 +63,7 @@ struct QuadConsts {
     int hiPrec;
     int steep;                        // hiPrec because of an edge slope ~1 / min(c, s): the vertex area formula in double precision too
     F marginT;                        // SCAN, hiPrec: margin of the t thresholds lo / hi taken on the precise t
-    double cD, sD, hpkD;
+    double cD, sD, hpkD, hmkD;
     double oxD[4], oyD[4], m1D, im1D;     // hiPrec: the vertex offsets and edge slopes in double precision
 };
 
@@ -122,7 +122,7 @@ AAI_HD QuadConsts<F> make_quad_consts(double side, double c, double s, int polic
     q.steep = quad_needs_hiprec(side, c, s) ? 1 : 0;
     q.hiPrec = (q.steep || scale > 1) ? 1 : 0;
     q.marginT = (F)(1e-6 * lo);
-    q.cD = c; q.sD = s; q.hpkD = h + k;
+    q.cD = c; q.sD = s; q.hpkD = h + k; q.hmkD = h - k;
     q.oxD[0] = o0x; q.oyD[0] = o0y; q.oxD[1] = o1x; q.oyD[1] = o1y;
     q.oxD[2] = -o1x; q.oyD[2] = -o1y; q.oxD[3] = -o0x; q.oyD[3] = -o0y;
     q.m1D = s / c; q.im1D = c / s;
@@ -298,11 +298,12 @@ AAI_HD bool quad_pixel(const QuadConsts<F> &q, int Xc, int Yc, double dfx, doubl
     // where a dst value far below its neighbours gets its relative accuracy from
     auto precise_tp = [&](F fi, F fj, bool lr, bool &flip) -> F {
         const double ad = lr ? qfma((double)fi, q.cD, qfma(-(double)fj, q.sD, acD)) : qfma((double)fi, q.sD, qfma((double)fj, q.cD, bcD));
-        double t = q.hpkD - (ad < 0.0 ? -ad : ad);
-        const double k2 = q.cD + q.sD;
-        t = t < 0.0 ? 0.0 : (t > k2 ? k2 : t);
-        flip = t > 0.5 * k2;
-        return (F)(flip ? k2 - t : t);
+        const double m = ad < 0.0 ? -ad : ad;
+        // t = (h + k) - |coordinate| and its mirror image c + s - t = |coordinate| - (h - k), each as ONE difference in double
+        // precision; the nearer one, clamped at 0, is the mirrored parameter
+        const F t1 = (F)(q.hpkD - m), t2 = (F)(m - q.hmkD);
+        flip = t1 > t2;
+        return qmax(qmin(t1, t2), F(0));
     };
     bool uncertain = false;
 
