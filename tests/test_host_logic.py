@@ -583,6 +583,35 @@ def test_double_precision_policy_keeps_requests_off_the_fp32_formulation(aai, ho
     assert rc == 6 and "policy" in msg        # AAI_ERR_BAD_ARGUMENT
 
 
+def test_quad_accuracy_where_dst_values_are_far_below_their_neighbours(aai, hostemu, po):
+    """The two situations the GPU fuzz of round 2 found close to (or past) the bar in plain fp32 -- rotations within ~1.6
+    degrees of an axis, and up-sampling, both on noise that puts tiny values beside large ones -- now run under hiPrec
+    (edge parameters and vertex positions from double precision; profiles/r02_fuzz_parity.txt).  CPU replay of the kernels'
+    arithmetic against the oracle on 8-bit noise: 7e-6 ... 1.2e-5 before, at most 2.5e-6 now."""
+    cases = [  # W, H, srcRes, dstRes, angle, isocenter, policy
+        (217, 168, 1.0119315959847874, 1.854544895549838, 360.50747310428073, None, 0),
+        (113, 72, 0.922939311056676, 1.219781765637425, 179.59630264794134, None, 1),
+        (95, 126, 0.48711324967955455, 0.9586407503613487, -359.9196040876093, None, 1),
+        (140, 231, 1.0, 2.0, 297.258112637219, (60.64185182247049, 197.4686723371354), 0),
+        (119, 58, 0.8158969581426692, 1.7949733079138723, 287.5, (59.0, 28.5), 0),
+        (128, 128, 1.0, 4.0, 45.0, None, 0),
+    ]
+    hostemu.aai_emu_use_quad(1)
+    try:
+        for (W, H, sr, dr, ang, iso, policy) in cases:
+            iso = iso or ((W - 1) / 2, (H - 1) / 2)
+            worst = 0.0
+            for seed in range(6):
+                src = np.random.default_rng(seed).integers(0, 256, size=(H, W)).astype(np.float32)      # 8-bit noise: a 1 beside a 255
+                gold = po.oracle_run(po.MODE_EXACT, src.astype(np.float64), sr, dr, iso, ang, policy=policy).dst
+                out, _ = hostemu.resample(aai.make_request(W, H, sr, dr, iso, ang, mode=1, policy=policy), src)
+                assert hostemu.quad_stats()[0] > 0
+                worst = max(worst, float(rel_err(out, gold, floor=0.256).max()))
+            assert worst <= 4e-6, (W, H, sr, dr, ang, worst)
+    finally:
+        hostemu.aai_emu_use_quad(0)
+
+
 def test_quad_serves_the_baseline_rotated_configs(aai, hostemu):
     """configs 3 and 5 take the quad kernel, and so do rotations close to an axis (with the left/right edge's t in double
     precision); wide footprints and angles within ~0.006 degrees of an axis stay on the double-precision kernels"""
