@@ -265,8 +265,8 @@ int aai_prepare(const aai_request *req, int32_t channels)
     int rc = check_request(req);
     if (rc != AAI_OK) return rc;
     if (channels < 1 || channels > 4) return fail(AAI_ERR_BAD_ARGUMENT, "Channels must be 1..4.");
+    aai::Geometry g;
     {
-        aai::Geometry g;
         std::string msg;
         rc = aai::make_geometry(*req, g, msg);
         if (rc != AAI_OK) return fail(rc, msg);
@@ -275,7 +275,8 @@ int aai_prepare(const aai_request *req, int32_t channels)
     if (rc != AAI_OK) return rc;
     std::lock_guard<std::mutex> lock(g_planMutex);
     Plan *p = nullptr;
-    rc = get_plan(*req, -1, -1, channels, &p);
+    // (the plan of a packed fp32 image: what the device entries build on their first call)
+    rc = get_plan(*req, -1, -1, channels, rot_form(*req, g, channels, aai::SRC_F32, (int64_t)g.W * channels), &p);
     if (rc == AAI_OK) g_lastError.clear();
     return rc;
 }

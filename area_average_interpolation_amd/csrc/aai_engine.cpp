@@ -172,24 +172,33 @@ static void tune_axis_plan(Plan &p, int channels, int band0)
 
 // Finds or builds the plan for (request, current device).  Returns a pointer valid until evicted; callers
 // hold g_planMutex for the duration of the launch (launches only enqueue, so this is short).
-int get_plan(const aai_request &rq, int band0, int band1, int channels, Plan **out)
+int rot_form(const aai_request &rq, const aai::Geometry &g, int channels, int srcType, int64_t srcStride)
+{
+    if (pick_kernel(rq, g) != AAI_KERNEL_ROTATED) return aai::ROT_FORM_QUAD;
+    aai::RotLaunch r = aai::make_rot_launch(g, rq.mode, rq.policy);
+    r.chan = channels;
+    return aai::cell_can_serve(r, srcType, aai::ImageView{srcStride, 0}) ? aai::ROT_FORM_CELL : aai::ROT_FORM_QUAD;
+}
+
+int get_plan(const aai_request &rq, int band0, int band1, int channels, int form, Plan **out)
 {
     int dev = -1;
     AAI_HIP(hipGetDevice(&dev));
     auto cached = [&](int b0, int b1, int ch) -> bool {
         for (auto it = g_plans.begin(); it != g_plans.end(); ++it)
-            if (it->device == dev && it->band0 == b0 && it->band1 == b1 && it->channels == ch && same_request(it->key, rq)) {
+            if (it->device == dev && it->band0 == b0 && it->band1 == b1 && it->channels == ch && it->form == form && same_request(it->key, rq)) {
                 g_plans.splice(g_plans.begin(), g_plans, it);
                 *out = &g_plans.front();
                 return true;
             }
         return false;
     };
-    if (cached(band0, band1, channels)) return AAI_OK;       // the common case costs no geometry set-up
     aai::Geometry g;
     std::string msg;
     int rc = aai::make_geometry(rq, g, msg);
     if (rc != AAI_OK) return fail(rc, msg);
+    if (pick_kernel(rq, g) != AAI_KERNEL_ROTATED) form = aai::ROT_FORM_QUAD;
+    if (cached(band0, band1, channels)) return AAI_OK;
     if (pick_kernel(rq, g) != AAI_KERNEL_AXIS && (band0 >= 0 || channels != 1)) {
         // Only K1's tables depend on the row band.  The per-pixel kernels take the band as launch parameters and their
         // one-off scans cover the whole image, so every band and every channel count of a rotated request shares one plan.
@@ -199,7 +208,7 @@ int get_plan(const aai_request &rq, int band0, int band1, int channels, Plan **o
 
     g_plans.emplace_front();
     Plan &p = g_plans.front();
-    p.key = rq; p.band0 = band0; p.band1 = band1; p.channels = channels; p.device = dev; p.g = g; p.kernel = pick_kernel(rq, g);
+    p.key = rq; p.band0 = band0; p.band1 = band1; p.channels = channels; p.form = form; p.device = dev; p.g = g; p.kernel = pick_kernel(rq, g);
     p.srcRow0 = 0; p.srcRow1 = g.H;
     if (p.kernel == AAI_KERNEL_AXIS) {
         aai::build_axis_tables(g, rq.mode, p.tabs, channels);
@@ -235,7 +244,7 @@ int get_plan(const aai_request &rq, int band0, int band1, int channels, Plan **o
             if (e == hipSuccess) e = hipMalloc((void **)&dCount, sizeof(unsigned));
             if (e == hipSuccess) e = hipMemset(dCount, 0, sizeof(unsigned));
             if (e == hipSuccess) e = verifyAxis ? aai::launch_axis_verify(r, dMasks, dCount, nullptr) : aai::launch_knife_scan(r, dMasks, dCount, nullptr);
-            if (e == hipSuccess && r.quad) e = aai::launch_quad_scan(r, dMasks, dCount, nullptr);
+            if (e == hipSuccess && r.quad) e = form == aai::ROT_FORM_CELL ? aai::launch_cell_scan(r, dMasks, dCount, nullptr) : aai::launch_quad_scan(r, dMasks, dCount, nullptr);
             if (e == hipSuccess) e = hipMemcpy(&count, dCount, sizeof(unsigned), hipMemcpyDeviceToHost);
             // (AAI_MAX_LISTED_PIXELS: test hook, lowers the threshold so that small geometries exercise the dense form)
             static const unsigned maxListed = [] { const char *v = getenv("AAI_MAX_LISTED_PIXELS"); return v ? (unsigned)strtoul(v, nullptr, 10) : kMaxListedPixels; }();
@@ -285,7 +294,14 @@ int enqueue(const aai_request &rq, int batch, const void *dSrc, int srcType, int
 {
     std::lock_guard<std::mutex> lock(g_planMutex);
     Plan *p = nullptr;
-    int rc = get_plan(rq, band0, band1, channels, &p);
+    int rc;
+    {
+        aai::Geometry g0;
+        std::string msg;
+        rc = aai::make_geometry(rq, g0, msg);
+        if (rc != AAI_OK) return fail(rc, msg);
+        rc = get_plan(rq, band0, band1, channels, rot_form(rq, g0, channels, srcType, srcStride), &p);
+    }
     if (rc != AAI_OK) return rc;
     const aai::Geometry &g = p->g;
     // strides are in elements; an interleaved pixel takes `channels` of them
@@ -324,7 +340,7 @@ int enqueue(const aai_request &rq, int batch, const void *dSrc, int srcType, int
         const aai::QuadMap qm = aai::make_quad_map(g, srcStride, r.srcRow0, channels, srcType == aai::SRC_U8 ? 1 : srcType == aai::SRC_U16 ? 2 : 4);
         aai::RotFlags flags;
         flags.list = p->dList; flags.count = p->flaggedPixels; flags.dense = p->dense;
-        flags.masks = p->dMasks; flags.side = p->side; flags.fork = p->fork; flags.join = p->join;
+        flags.masks = p->dMasks; flags.side = p->side; flags.fork = p->fork; flags.join = p->join; flags.form = p->form;
         e = hipSuccess;
         for (int b0 = 0; b0 < batch && e == hipSuccess; b0 += kMaxGridZ)
             e = aai::launch_rotated(r, qm, src_at(dSrc, srcType, (int64_t)b0 * srcImageStride), srcType, sv, dDst + (int64_t)b0 * dstImageStride, dv,

@@ -29,6 +29,7 @@ struct Plan {
     aai_request key{};
     int band0 = -1, band1 = -1;      // dst row band this plan serves (-1: the whole image)
     int channels = 1;                // interleaved channels the K1 tables were built for
+    int form = 0;                    // rotated area / fast requests: the fp32 formulation whose scan flagged the pixels (aai::RotForm)
     int srcRow0 = 0, srcRow1 = 0;     // source rows the band reads; the source pointer addresses row srcRow0
     int device = -1;
     aai::Geometry g;
@@ -74,7 +75,10 @@ void fill_layout(const Geometry &g, int kernel, aai_layout *out);
 int require_device();
 
 // Finds or builds the plan for (request, current device); the caller holds g_planMutex.
-int get_plan(const aai_request &rq, int band0, int band1, int channels, Plan **out);
+// form: aai::RotForm of a rotated request's launch (rot_form below); ignored by the other kernels
+int get_plan(const aai_request &rq, int band0, int band1, int channels, int form, Plan **out);
+// which fp32 formulation serves a launch of this request: the cell formulation takes plain images below 4 GiB in area mode
+int rot_form(const aai_request &rq, const Geometry &g, int channels, int srcType, int64_t srcStride);
 
 // Enqueues one batched launch (plus the fix-up pass where the plan has one) on `stream`.  Strides in elements.
 int enqueue(const aai_request &rq, int batch, const void *dSrc, int srcType, int64_t srcStride, int64_t srcImageStride,

@@ -56,9 +56,11 @@ struct RotFlags {
     // FOLLOW it: it runs beside it on the plan's side stream (fork / join through two events), where its few,
     // latency-bound waves cost nothing instead of ~40 us behind the production pass.
     const unsigned long long *masks = nullptr;
+    int form = 0;                      // which fp32 formulation's scan produced the flags: ROT_FORM_QUAD or ROT_FORM_CELL (it serves the launch)
     hipStream_t side = nullptr;
     hipEvent_t fork = nullptr, join = nullptr;
 };
+enum RotForm { ROT_FORM_QUAD = 0, ROT_FORM_CELL = 1 };
 size_t rotated_flag_words(const RotLaunch &r);      // waves of the tiling = 64-bit words of the mask array
 hipError_t launch_knife_scan(const RotLaunch &r, unsigned long long *laneMasks, unsigned *counter, hipStream_t stream);
 // the double-precision fix-up pass over a list of dst pixels (defined in aai_rotated_strict.hip);
@@ -74,6 +76,13 @@ hipError_t launch_rotated(const RotLaunch &r, const QuadMap &m, const void *src,
                           int batch, const RotFlags &flags, hipStream_t stream, const char **kernelName);
 bool quad_can_address(const RotLaunch &r, int srcType, ImageView sv);
 hipError_t launch_quad(const RotLaunch &r, const QuadMap &m, const void *src, int srcType, ImageView sv, float *dst, ImageView dv,
+                       int batch, const unsigned long long *skipMasks, hipStream_t stream);
+
+// the cell formulation (aai_rotated_cell.hip): one lane per cell of the dst grid, every (dst, src) pair evaluated once
+bool cell_can_serve(const RotLaunch &r, int srcType, ImageView sv);      // r.chan set; plain images below 4 GiB, area mode
+int cell_rows_per_strip(int dW, int rows, int batch);
+hipError_t launch_cell_scan(const RotLaunch &r, unsigned long long *laneMasks, unsigned *counter, hipStream_t stream);
+hipError_t launch_cell(const RotLaunch &r, const QuadMap &m, const void *src, int srcType, ImageView sv, float *dst, ImageView dv,
                        int batch, const unsigned long long *skipMasks, hipStream_t stream);
 
 // ---- utilities -----------------------------------------------------------------------------------------

@@ -2,6 +2,7 @@
 // kernel.  Double precision throughout; mirrors Source.cpp:112-305 of the reference.
 #include "aai_plan.hpp"
 #include "aai_rot_quad.hpp"
+#include "aai_rot_cell.hpp"
 #include "aai_axis_verify.hpp"
 
 #include <algorithm>
@@ -157,6 +158,8 @@ RotLaunch make_rot_launch(const Geometry &g, int mode, int policy)
     // kernel fetches just those, where the window kernel fetches its whole 3 x 3 ... 5 x 5 window (x2 up-sampling at 30
     // degrees 0.69 vs 0.96 ms, x4 at 45 degrees 2.75 vs 4.33 ms: profiles/r02_fast_envelope.txt).
     if (mode == AAI_MODE_FAST && g.scale > 1) r.quad = 0;
+    // Area mode: the cell formulation (aai_rot_cell.hpp) evaluates every (dst, src) pair once instead of once per dst pixel
+    r.cell = (r.quad && mode == AAI_MODE_AREA && cell_supported(g.side, c, s)) ? 1 : 0;
     {
         // virtual centre: X = dx (side cs) + dy (side sn) + X0, Y = -dx (side sn) + dy (side cs) + Y0   (pixel_centre)
         const double u0 = g.fracX * g.side - g.isoX + g.offX, v0 = g.fracY * g.side - g.isoY + g.offY;

@@ -1,0 +1,307 @@
+// aai_rot_cell.hpp -- third formulation of the rotated-lattice area average (K2): every (dst, src) pair's geometry is
+// evaluated ONCE, by the cell of the dst grid that owns the source pixel, and shared between the dst pixels it feeds.
+//
+// Replaces Source.cpp:413-579 + 986-1431 of the reference, like aai_rot_quad.hpp, for every dst pixel that is not on one
+// of the reference's DBL_EPSILON knife edges.  Same per-pair area formulas as the quad formulation (quad_cut_tp,
+// quad_vertex_area); what changes is WHO evaluates a pair.
+//
+// The quad formulation gives each dst pixel a lane that visits every virtual source pixel its square can touch:
+// (L + c + s)^2 of them, half of which it shares with its neighbours -- at config 5 (L = 1.5 at 45 degrees) 8.5 touched
+// pixels per dst pixel of which 8 lie on an edge or a vertex of the square; at config 3 (L = 3) 18.  But in the dst frame
+// the squares form a regular grid: a source pixel cut by the grid line between two dst pixels contributes g to one and
+// 1 - g to the other (under the reference's corner rule too: types 2 and 4 of Source.cpp:1055-1062, 1083-1086 are
+// complementary on the same legs), and a source pixel near a grid vertex G feeds the four dst pixels around G from ONE
+// classification.  So the plane of pixel CENTRES is tiled by zones, one per cell (= dst pixel + its top-left grid vertex
+// G): with (a', b') the centre's dst-frame coordinates relative to G and k = (c + s) / 2 the pixel's half extent along
+// either dst axis, the zone is [-k, L - k) x [-k, L - k) and splits into
+//   * a' < k and b' < k   "vertex zone": both grid lines through G cut the pixel.  Either it holds G -- its four wedge
+//                         areas go to the four dst pixels around G (reference types 7-9) -- or exactly one vertical and
+//                         one horizontal RAY from G cross it: the dst pixel between the two rays gets gA + gB - 1, the
+//                         one across the vertical ray the left/right cut ALONE (the reference's corner rule applies),
+//                         the one across the horizontal ray the top/bottom cut alone, the fourth nothing (types 2-6);
+//   * a' < k <= b'        "left-edge zone": only the vertical grid line cuts it: g to this cell's dst pixel, 1 - g to its
+//                         left neighbour, both with the reference's corner rule (types 2, 3, 4);
+//   * b' < k <= a'        "top-edge zone": g to this cell's dst pixel, 1 - g to the one above (exact under both policies);
+//   * k <= a', k <= b'    interior: area 1 to this cell's dst pixel.
+// Every virtual pixel lies in exactly one zone, so a dst pixel costs L^2 pair evaluations (2.25 at config 5, 9 at
+// config 3) and a window of floor(L (c + s)) + 1 lattice positions per axis (3 and 4) instead of 4 and 5.
+// dst pixel (x, y) = own part of cell (x, y) + W part of cell (x + 1, y) + N part of cell (x, y + 1) + NW part of cell
+// (x + 1, y + 1): the kernel (aai_rotated_cell.hip) keeps a wave on 64 consecutive cells of a row, walks down the rows and
+// passes the parts between lanes / iterations in registers.
+//
+// Precision and decisions: as in the quad formulation everything is relative to a lattice point next to the zone's
+// centre and runs in fp32 (hiPrec: the edges' t from double precision).  A zone boundary is a DECISION here -- a pixel
+// claimed by two cells or by none is an error of its whole area -- so SCAN mode reports a cell when any of its
+// decisions (zone and sub-zone membership, the reference's triangle / trapezoid switch, G inside a pixel, which rays
+// cross) is closer than QuadConsts::margin to its threshold, and the plan leaves all four dst pixels that cell feeds to the
+// double-precision fix-up pass.
+#pragma once
+
+#include "aai_rot_quad.hpp"
+
+namespace aai {
+
+enum CellTarget { CELL_O = 0, CELL_W = 1, CELL_N = 2, CELL_NW = 3 };     // own dst pixel (x, y); (x-1, y); (x, y-1); (x-1, y-1)
+
+template <typename F>
+struct CellConsts {
+    F thr;                 // 2k - h: a zone coordinate below this puts the pixel centre within k of the grid line through G
+    F hbz;                 // h (c + s) + guard: half extent of the lattice window that holds a zone
+    int win;               // lattice positions per axis of that window, <= kQuadMaxWin
+    double zx, zy;         // zone centre - dst pixel centre, virtual frame
+    double gx, gy;         // G - zone centre, virtual frame
+    double kD, hmkD;
+};
+
+template <typename F>
+AAI_HD CellConsts<F> make_cell_consts(double side, double c, double s)
+{
+    CellConsts<F> z;
+    const double h = 0.5 * side, k = 0.5 * (c + s), hmk = h - k;
+    z.thr = (F)(2.0 * k - h);
+    const double hbz = h * (c + s) + 1e-5;
+    z.hbz = (F)hbz;
+    z.win = (int)floor(2.0 * hbz) + 1;
+    // the zone is the dst square shifted by (-k, -k) in the dst frame; a dst-frame offset (a, b) is (a c + b s, -a s + b c)
+    z.zx = -k * (c + s); z.zy = k * (s - c);
+    z.gx = -hmk * (c + s); z.gy = hmk * (s - c);
+    z.kD = k; z.hmkD = hmk;
+    return z;
+}
+
+// the cell formulation serves what the quad formulation serves (same formulas, same precision switches)
+AAI_HD bool cell_supported(double side, double c, double s)
+{
+    if (!quad_supported(side, c, s)) return false;
+    return (int)floor(2.0 * (0.5 * side * (c + s) + 1e-5)) + 1 <= kQuadMaxWin;
+}
+
+// A grid line cuts a unit pixel into a smaller and a larger part; tp = the line's distance from the pixel's nearer extreme
+// corner (quad_cut_tp's mirrored parameter).  Area of the SMALLER part, exact and under the reference's corner rule for a
+// left/right line; the larger part is one minus it.  Each side of the line takes its own part directly -- never
+// 1 - (1 - small): a dst value far below its neighbours gets its relative accuracy from the small parts.
+template <typename F>
+AAI_HD void cell_cut_small(const QuadConsts<F> &q, F tp, F &exact, F &ref)
+{
+    const F trap = qfma(tp, q.rhi, -q.trapOff);
+    const F triExact = (tp * tp) * q.r2cs;
+    const F triRef = qfma(-q.hrc, tp, F(0.5)) * qfma(-q.rs, tp, F(1));
+    const bool tri = tp <= q.lo;
+    exact = tri ? triExact : trap;
+    ref = tri ? (q.ref != 0 ? triRef : triExact) : trap;
+}
+
+// One cell.  (Zx, Zy) = the lattice point nearest the zone's centre, (dfx, dfy) = zone centre - (Zx, Zy), both in
+// [-1/2, 1/2].  Source protocol as in quad_pixel (issue / commit / at).  sA[t], sVA[t] = sums of areas and of area x value
+// this cell contributes to target t (CellTarget).  SCAN: src is never touched, every value counts as 1, and the return
+// value says whether a decision of this cell is too close to its threshold for fp32.
+template <typename F, int WIN, bool SCAN, bool HP, typename Src>
+AAI_HD bool cell_eval(const QuadConsts<F> &q, const CellConsts<F> &z, int Zx, int Zy, double dfx, double dfy, int mW, int mH, Src &src,
+                      F (&sA)[4], F (&sVA)[4])
+{
+    typedef typename QuadMask<WIN>::type u64;
+    static_assert(WIN >= 1 && WIN <= kQuadMaxWin, "window size");
+    const F fpx = (F)dfx, fpy = (F)dfy;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) { sA[t] = F(0); sVA[t] = F(0); }
+    auto value = [&](int slot) -> F {
+        if (SCAN) return F(1);
+        F vals[1];
+        src.at(slot, vals);
+        return vals[0];
+    };
+    auto add = [&](int target, F area, F v) { sA[target] += area; sVA[target] = qfma(area, v, sVA[target]); };
+
+    // window origin: the first lattice point the zone's bounding box can hold
+    const F fi0 = ceil(fpx - z.hbz), fj0 = ceil(fpy - z.hbz);
+    const int i0 = (int)fi0, j0 = (int)fj0;
+    const int xg0 = Zx + i0, yg0 = Zy + j0;
+    u64 valid;
+    {
+        const int ia = xg0 < 0 ? -xg0 : 0, ib = (mW - 1 - xg0 < WIN - 1) ? mW - 1 - xg0 : WIN - 1;
+        const int ja = yg0 < 0 ? -yg0 : 0, jb = (mH - 1 - yg0 < WIN - 1) ? mH - 1 - yg0 : WIN - 1;
+        if (ia > ib || ja > jb) return false;                                 // the whole window misses the image
+        const unsigned cols = (2u << ib) - (1u << ia);
+        valid = 0;
+#pragma unroll
+        for (int j = 0; j < WIN; ++j)
+            if (j >= ja && j <= jb) valid |= (u64)cols << (j * WIN);
+    }
+    if (!SCAN) src.issue(xg0, yg0, valid);
+
+    // zone coordinates (dst frame, relative to the zone's centre) of lattice point (Zx, Zy)
+    const F ac = qfma(fpy, q.s, -(fpx * q.c)), bc = -qfma(fpx, q.s, fpy * q.c);
+    // hiPrec: the same relative to G, in double precision (a' = az + (h - k))
+    const double a1cD = qfma(dfy, q.sD, -(dfx * q.cD)) + z.hmkD, b1cD = -qfma(dfx, q.sD, dfy * q.cD) + z.hmkD;
+    // a grid line's mirrored parameter for lattice point (fi, fj): t = k + m on the E / S side, k - m on the W / N side with
+    // m the centre's signed distance from the line through G; flip: the E / S side holds more than half of the pixel
+    auto precise_tp = [&](F fi, F fj, bool lr, bool &flip) -> F {
+        const double m = lr ? qfma((double)fi, q.cD, qfma(-(double)fj, q.sD, a1cD)) : qfma((double)fi, q.sD, qfma((double)fj, q.cD, b1cD));
+        const F t1 = (F)(z.kD + m), t2 = (F)(z.kD - m);
+        flip = t1 > t2;
+        return qmax(qmin(t1, t2), F(0));
+    };
+    auto plain_tp = [&](F m1, bool &flip) -> F {        // m1 = the centre's distance from the line, fp32
+        const F t = qmin(qmax(m1 + q.k, F(0)), q.k2);
+        flip = t > q.k;
+        return qmin(t, q.k2 - t);
+    };
+    bool uncertain = false;
+
+    // ---- pass 1: which zone does every lattice point of the window belong to ------------------------------------------
+    u64 pZ = 0, pV = 0, pH = 0;           // in this cell's zone; within k of the vertical / horizontal grid line through G
+#pragma unroll
+    for (int j = 0; j < WIN; ++j) {
+        const F fj = fj0 + (F)j;
+        const F rowA = qfma(-fj, q.s, ac), rowB = qfma(fj, q.c, bc);
+#pragma unroll
+        for (int i = 0; i < WIN; ++i) {
+            const F fi = fi0 + (F)i;
+            const F az = qfma(fi, q.c, rowA), bz = qfma(fi, q.s, rowB);
+            const u64 bit = (u64)1 << (j * WIN + i);
+            if (qabs(az) < q.h && qabs(bz) < q.h) pZ |= bit;
+            if (az < z.thr) pV |= bit;
+            if (bz < z.thr) pH |= bit;
+            if (SCAN) {
+                const bool live = (valid & bit) != 0;
+                const F na = qabs(qabs(az) - q.h), nb = qabs(qabs(bz) - q.h);
+                const bool nearZone = qabs(az) < q.h + q.margin && qabs(bz) < q.h + q.margin;
+                if (live && nearZone && (na < q.margin || nb < q.margin || qabs(az - z.thr) < q.margin || qabs(bz - z.thr) < q.margin)) uncertain = true;
+            }
+        }
+    }
+    pZ &= valid;
+    u64 mVtx = pZ & pV & pH, mLeft = pZ & pV & ~pH, mTop = pZ & ~pV & pH, mIn = pZ & ~pV & ~pH;
+    if (!SCAN) src.commit();
+
+    // ---- the pixel that holds G: four wedge areas, one per dst pixel around G ----------------------------------------------
+    const F gzx = HP ? (F)(dfx + z.gx) : fpx + (F)z.gx, gzy = HP ? (F)(dfy + z.gy) : fpy + (F)z.gy;     // G relative to (Zx, Zy)
+    {
+        const F rx = floor(gzx + F(0.5)), ry = floor(gzy + F(0.5));
+        const F fx = gzx - rx, fy = gzy - ry;
+        const int i = (int)rx - i0, j = (int)ry - j0;
+        if (i < 0 || i >= WIN || j < 0 || j >= WIN) { if (SCAN) uncertain = true; }       // cannot happen (the window holds G's pixel)
+        else {
+            const int slot = j * WIN + i;
+            const u64 bit = (u64)1 << slot;
+            if (SCAN && (qabs(fx) > F(0.5) - q.margin || qabs(fy) > F(0.5) - q.margin)) uncertain = true;
+            mVtx &= ~bit; mLeft &= ~bit; mTop &= ~bit; mIn &= ~bit;
+            if (valid & bit) {
+                const F v = value(slot);
+                F area[4];
+                if (HP) {
+                    const double fxD = (dfx + z.gx) - (double)rx, fyD = (dfy + z.gy) - (double)ry;
+#pragma unroll
+                    for (int t = 0; t < 4; ++t)
+                        area[t] = q.steep ? (F)quad_vertex_area<double>(q.m1D, q.im1D, fxD, fyD, t) : quad_vertex_area(q, (F)fxD, (F)fyD, t);
+                } else {
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) area[t] = quad_vertex_area(q, fx, fy, t);
+                }
+                // G is vertex 0 (left/top) of the cell's own dst pixel, vertex 1 (right/top) of its left neighbour,
+                // vertex 2 (left/bottom) of the one above, vertex 3 of the one above left
+#pragma unroll
+                for (int t = 0; t < 4; ++t) add(t, area[t], v);
+            }
+        }
+    }
+
+    // ---- interior: area 1 to the cell's own dst pixel --------------------------------------------------------------------
+    while (mIn) {
+        const int slot = quad_ctz(mIn);
+        mIn &= mIn - 1;
+        add(CELL_O, F(1), value(slot));
+    }
+    // ---- left-edge zone: the vertical grid line alone (the reference's corner rule applies on both sides) -----------------
+    while (mLeft) {
+        const int slot = quad_ctz(mLeft);
+        mLeft &= mLeft - 1;
+        const int j = slot / WIN, i = slot - j * WIN;
+        const F fj = fj0 + (F)j, fi = fi0 + (F)i;
+        const F a1 = qfma(fi, q.c, qfma(-fj, q.s, ac)) + q.hmk;
+        bool flip;
+        F tp = plain_tp(a1, flip);
+        if (HP) tp = precise_tp(fi, fj, true, flip);
+        if (SCAN && q.ref != 0 && qabs(tp - q.lo) < (HP ? q.marginT : q.margin)) uncertain = true;
+        F sE, sR;
+        cell_cut_small(q, tp, sE, sR);
+        const F v = value(slot);
+        add(CELL_O, flip ? F(1) - sR : sR, v);               // flip: the E side holds the larger part
+        add(CELL_W, flip ? sR : F(1) - sR, v);
+    }
+    // ---- top-edge zone: the horizontal grid line alone (exact under both policies) ------------------------------------------
+    while (mTop) {
+        const int slot = quad_ctz(mTop);
+        mTop &= mTop - 1;
+        const int j = slot / WIN, i = slot - j * WIN;
+        const F fj = fj0 + (F)j, fi = fi0 + (F)i;
+        const F b1 = qfma(fi, q.s, qfma(fj, q.c, bc)) + q.hmk;
+        bool flip;
+        F tp = plain_tp(b1, flip);
+        if (HP) tp = precise_tp(fi, fj, false, flip);
+        F sS, unused;
+        cell_cut_small(q, tp, sS, unused);
+        const F v = value(slot);
+        add(CELL_O, flip ? F(1) - sS : sS, v);
+        add(CELL_N, flip ? sS : F(1) - sS, v);
+    }
+    // ---- vertex zone, G outside the pixel: one vertical and one horizontal ray from G cross it --------------------------------
+    while (mVtx) {
+        const int slot = quad_ctz(mVtx);
+        mVtx &= mVtx - 1;
+        const int j = slot / WIN, i = slot - j * WIN;
+        const F fj = fj0 + (F)j, fi = fi0 + (F)i;
+        const F a1 = qfma(fi, q.c, qfma(-fj, q.s, ac)) + q.hmk, b1 = qfma(fi, q.s, qfma(fj, q.c, bc)) + q.hmk;
+        bool flipA, flipB;
+        F tpA = plain_tp(a1, flipA), tpB = plain_tp(b1, flipB);
+        if (HP) { tpA = precise_tp(fi, fj, true, flipA); tpB = precise_tp(fi, fj, false, flipB); }
+        // G relative to the pixel centre along the pixel's own axes; the vertical grid line runs along (s, c), the
+        // horizontal one along (c, -s): the chord of either line lies on the ray that leads back towards the pixel
+        const F gx = gzx - fi, gy = gzy - fj;
+        const bool xout = qabs(gx) > F(0.5);
+        const bool down = xout ? gx < F(0) : gy < F(0);
+        const bool right = xout ? gx < F(0) : gy > F(0);
+        if (SCAN) {
+            if (qmin(qabs(qabs(gx) - F(0.5)), qabs(qabs(gy) - F(0.5))) < q.margin) uncertain = true;
+            if (q.ref != 0 && qabs(tpA - q.lo) < (HP ? q.marginT : q.margin)) uncertain = true;
+        }
+        F sA_, sAr, sB_, unused;
+        cell_cut_small(q, tpA, sA_, sAr);
+        cell_cut_small(q, tpB, sB_, unused);
+        const F gE = flipA ? F(1) - sA_ : sA_, gW = flipA ? sA_ : F(1) - sA_;          // exact parts E / W of the vertical line
+        const F gEr = flipA ? F(1) - sAr : sAr, gWr = flipA ? sAr : F(1) - sAr;        // ... under the reference's corner rule
+        const F gS = flipB ? F(1) - sB_ : sB_, gN = flipB ? sB_ : F(1) - sB_;          // parts S / N of the horizontal line
+        // the dst pixel between the two rays: both edges cross the pixel, exact
+        const F both = qmax((right ? gE : gW) + (down ? gS : gN) - F(1), F(0));
+        const F aO = right ? (down ? both : gS) : (down ? gEr : F(0));
+        const F aW = right ? (down ? gWr : F(0)) : (down ? both : gS);
+        const F aN = right ? (down ? gN : both) : (down ? F(0) : gEr);
+        const F aNW = right ? (down ? F(0) : gWr) : (down ? gN : both);
+        const F v = value(slot);
+        add(CELL_O, aO, v);
+        add(CELL_W, aW, v);
+        add(CELL_N, aN, v);
+        add(CELL_NW, aNW, v);
+    }
+    return uncertain;
+}
+
+// The zone centre of cell (dx, dy) on the virtual lattice: nearest lattice point and fraction.  false: so far from the
+// lattice that the cell touches nothing (and the integers below would leave int range).
+template <typename F>
+AAI_HD bool cell_anchor(const RotLaunch &r, const CellConsts<F> &z, int dx, int dy, int &Zx, int &Zy, double &dfx, double &dfy)
+{
+    double px, py;
+    pixel_centre(r, dx, dy, px, py);
+    const double zx = px + z.zx, zy = py + z.zy;
+    const double cx = floor(zx + 0.5), cy = floor(zy + 0.5);
+    if (!(cx > -16.0 && cx < (double)r.mW + 16.0 && cy > -16.0 && cy < (double)r.mH + 16.0)) return false;
+    Zx = (int)cx; Zy = (int)cy; dfx = zx - cx; dfy = zy - cy;
+    return true;
+}
+
+// dst pixel (x, y) from the parts of its four cells, in the order the kernel adds them
+template <typename F>
+AAI_HD void cell_combine(F own, F w, F n, F nw, F &total) { total = (own + w) + (n + nw); }
+
+}  // namespace aai

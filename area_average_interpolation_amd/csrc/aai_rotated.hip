@@ -404,6 +404,12 @@ static bool quad_serves(const RotLaunch &r, int srcType, ImageView sv)
     return r.quad && rot_tune().quad != 0 && (r.mode == AAI_MODE_AREA || (r.mode == AAI_MODE_FAST && r.chan == 1)) && quad_can_address(r, srcType, sv);
 }
 
+// ... or the cell formulation does: the plan's scan was the cell scan (RotFlags::form) and the launch is one it takes
+static bool cell_serves(const RotLaunch &r, int srcType, ImageView sv, const RotFlags &flags)
+{
+    return flags.form == ROT_FORM_CELL && rot_tune().quad != 0 && cell_can_serve(r, srcType, sv);
+}
+
 // one launch of at most 65535 tile rows (16-row tiles; the bicubic sampler: 8-row tiles)
 template <typename T>
 static hipError_t launch_rotated_band(const RotLaunch &r, const QuadMap &m, const T *src, int srcType, ImageView sv, float *dst, ImageView dv,
@@ -424,6 +430,11 @@ static hipError_t launch_rotated_band(const RotLaunch &r, const QuadMap &m, cons
     dim3 grid((r.dW + 15) / 16, (r.dyEnd - r.dyBase + 15) / 16, batch);
     const RotTune &tune = rot_tune();
     const bool quad = quad_serves(r, srcType, sv);
+    if (cell_serves(r, srcType, sv, flags)) {
+        // the cell formulation: one lane per cell of the dst grid, every (dst, src) pair evaluated once
+        if (kernelName) *kernelName = "aai_cell_kernel<area>";
+        return launch_cell(r, m, src, srcType, sv, dst, dv, batch, flags.count ? flags.masks : nullptr, stream);
+    }
     if (r.chan > 1 && quad) {
         // interleaved channels through the fp32 quad formulation: areas once per pair, applied to every channel
         if (kernelName) *kernelName = "aai_quad_multi_kernel<area, channels>";
@@ -487,7 +498,7 @@ static hipError_t launch_rotated_typed(const RotLaunch &r, const QuadMap &m, con
     // pass on the same stream -- or, when the production kernel is the quad kernel and skips those pixels, beside it on
     // the plan's side stream: fork before, join after.
     const bool fixup = !sampler && flags.count != 0;
-    const bool beside = fixup && flags.masks && flags.side && quad_serves(r, srcType, sv);
+    const bool beside = fixup && flags.masks && flags.side && (quad_serves(r, srcType, sv) || cell_serves(r, srcType, sv, flags));
     hipError_t e = hipSuccess;
     if (beside) {
         e = hipEventRecord(flags.fork, stream);

@@ -23,12 +23,13 @@
 // aai_flag_list_kernel (flag words -> pixel list).
 #include "aai_kernels.hpp"
 #include "aai_rot_quad.hpp"
+#include "aai_quad_src.hpp"
 
 namespace aai {
 
 namespace {
 
-constexpr int kQuadBlock = 256;      // 16 x 16 dst pixels, the tiling of the scans
+// (kQuadBlock = 256 lanes: 16 x 16 dst pixels, the tiling of the scans -- aai_quad_src.hpp)
 constexpr int kQuadMaxChan = 4;
 
 // the `chan` (2..4) interleaved fp32 channels of one pixel in ONE load instruction (element-aligned)
@@ -42,119 +43,6 @@ __device__ __forceinline__ void load_channels(const float *p, int chan, float (&
     else if (chan == 4) { const f4u q = *reinterpret_cast<const f4u *>(p); v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w; }
     else { const f2u q = *reinterpret_cast<const f2u *>(p); v[0] = q.x; v[1] = q.y; }
 }
-
-// N consecutive fp32 elements from an element-aligned address in as few load instructions as possible
-template <int N>
-__device__ __forceinline__ void load_line(const float *p, float (&seg)[N])
-{
-    typedef float f2u __attribute__((ext_vector_type(2), aligned(4)));
-    typedef float f3u __attribute__((ext_vector_type(3), aligned(4)));
-    typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
-    int at = 0;
-    if (N >= 4) { const f4u q = *reinterpret_cast<const f4u *>(p); seg[0] = q.x; seg[1] = q.y; seg[2] = q.z; seg[3] = q.w; at = 4; }
-    if (N - at == 4) { const f4u q = *reinterpret_cast<const f4u *>(p + at); seg[at] = q.x; seg[at + 1] = q.y; seg[at + 2] = q.z; seg[at + 3] = q.w; }
-    else if (N - at == 3) { const f3u q = *reinterpret_cast<const f3u *>(p + at); seg[at] = q.x; seg[at + 1] = q.y; seg[at + 2] = q.z; }
-    else if (N - at == 2) { const f2u q = *reinterpret_cast<const f2u *>(p + at); seg[at] = q.x; seg[at + 1] = q.y; }
-    else if (N - at == 1) seg[at] = p[at];
-}
-
-// The staged window of one lane.  Offsets are unsigned bytes from the image's first element (QuadMap: non-negative
-// strides), one table per axis; positions outside the lattice are clamped onto it -- their values are fetched but
-// never read (quad_pixel only reads slots whose valid bit is set).
-template <typename T, int WIN, bool SCALED>
-struct QuadSrc {
-    const char *img;                 // first element of this image (band offset included)
-    const QuadMap *m;
-    int mW, mH;
-    float (*lds)[kQuadBlock];        // [WIN * WIN][kQuadBlock]
-    int tid;
-    T v[WIN * WIN];
-
-    __device__ __forceinline__ void issue(int xg0, int yg0, unsigned long long)
-    {
-        unsigned colOff[WIN], rowOff[WIN];            // source indices along virtual X / Y first, byte offsets below
-        const unsigned sxb = (unsigned)m->strideX * (unsigned)sizeof(T), syb = (unsigned)m->strideY * (unsigned)sizeof(T);
-        if (!SCALED) {
-#pragma unroll
-            for (int i = 0; i < WIN; ++i) {
-                const int X = min(max(xg0 + i, 0), mW - 1), Y = min(max(yg0 + i, 0), mH - 1);
-                colOff[i] = (unsigned)(m->flipX ? m->nX - 1 - X : X);
-                rowOff[i] = (unsigned)(m->flipY ? m->nY - 1 - Y : Y);
-            }
-        } else {
-            // floor division of coordinates that are >= -8 (the window meets the lattice): exact, (n + 0.5) / scale is
-            // at least 0.5 / scale away from an integer; inside the window (rem + i + 0.5) / scale with rem + i <
-            // scale + 8 is far from every integer compared with fp32 rounding
-            const int scale = m->scale;
-            const int tx = xg0 + 8 * scale, ty = yg0 + 8 * scale;
-            const int qx0 = (int)(((double)tx + 0.5) * m->invScaleD), qy0 = (int)(((double)ty + 0.5) * m->invScaleD);
-            const float remX = (float)(tx - qx0 * scale) + 0.5f, remY = (float)(ty - qy0 * scale) + 0.5f;
-#pragma unroll
-            for (int i = 0; i < WIN; ++i) {
-                const int ix = min(max(xg0 + i, 0), mW - 1) - xg0, iy = min(max(yg0 + i, 0), mH - 1) - yg0;
-                const int qx = qx0 - 8 + (int)((remX + (float)ix) * m->invScale), qy = qy0 - 8 + (int)((remY + (float)iy) * m->invScale);
-                colOff[i] = (unsigned)(m->flipX ? m->nX - 1 - qx : qx);
-                rowOff[i] = (unsigned)(m->flipY ? m->nY - 1 - qy : qy);
-            }
-        }
-        // Images of 4 GiB and more: offsets are taken from an anchor row of this WAVE instead of the image's first row --
-        // every lane of a 16 x 4 dst tile reads within anchorRows source rows of any other lane (QuadMap::anchorRows, 0
-        // for smaller images), so the anchor is one lane's first row less that bound and the base pointer moves with it
-        if (m->anchorRows) {
-            const bool rowsAlongX = sxb > syb;           // wave-uniform: which window axis walks the source rows
-            const int first = __builtin_amdgcn_readfirstlane((int)(rowsAlongX ? colOff[0] : rowOff[0]));
-            const unsigned anchor = (unsigned)max(first - m->anchorRows, 0);
-            img += (int64_t)anchor * (int64_t)(rowsAlongX ? sxb : syb);
-#pragma unroll
-            for (int i = 0; i < WIN; ++i) {
-                if (rowsAlongX) colOff[i] -= anchor; else rowOff[i] -= anchor;
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < WIN; ++i) { colOff[i] *= sxb; rowOff[i] *= syb; }
-        // Without replication one axis of the window is contiguous in memory (virtual X along source x in quadrants 0 / 2,
-        // virtual Y in 1 / 3): fetch each of its WIN lines with one or two vector loads instead of WIN scalar ones -- lanes
-        // are L source pixels apart, so every load instruction touches a dozen cache lines and their NUMBER is what the
-        // texture path charges for.  Only where no lane of the wave has a clamped (off-image) column or row.
-        const bool inside = xg0 >= 0 && xg0 + WIN <= mW && yg0 >= 0 && yg0 + WIN <= mH;
-        if (!SCALED && sizeof(T) == 4 && __all(inside)) {
-            const bool alongX = sxb == (unsigned)sizeof(T);               // wave-uniform
-#pragma unroll
-            for (int k = 0; k < WIN; ++k) {
-                // line k: fixed row (alongX) or fixed column, its WIN elements ascending in memory from `first`
-                const unsigned first = alongX ? rowOff[k] + min(colOff[0], colOff[WIN - 1]) : colOff[k] + min(rowOff[0], rowOff[WIN - 1]);
-                const bool rev = alongX ? colOff[0] > colOff[WIN - 1] : rowOff[0] > rowOff[WIN - 1];
-                float seg[WIN];
-                load_line<WIN>(reinterpret_cast<const float *>(img + first), seg);
-#pragma unroll
-                for (int e = 0; e < WIN; ++e) {
-                    const float val = rev ? seg[WIN - 1 - e] : seg[e];
-                    if (alongX) v[k * WIN + e] = (T)val; else v[e * WIN + k] = (T)val;
-                }
-            }
-            return;
-        }
-#pragma unroll
-        for (int j = 0; j < WIN; ++j)
-#pragma unroll
-            for (int i = 0; i < WIN; ++i)
-                v[j * WIN + i] = *reinterpret_cast<const T *>(img + (colOff[i] + rowOff[j]));
-    }
-    __device__ __forceinline__ void commit()
-    {
-#pragma unroll
-        for (int k = 0; k < WIN * WIN; ++k) lds[k][tid] = (float)v[k];
-    }
-    __device__ __forceinline__ void at(int slot, float (&vals)[1]) const { vals[0] = lds[slot][tid]; }
-    __device__ __forceinline__ float reg(int slot) const { return (float)v[slot]; }
-};
-
-struct NoSrc {
-    __device__ __forceinline__ float reg(int) const { return 1.f; }
-    __device__ __forceinline__ void issue(int, int, unsigned long long) {}
-    __device__ __forceinline__ void commit() {}
-    __device__ __forceinline__ void at(int, float (&vals)[1]) const { vals[0] = 1.f; }
-};
 
 // Interleaved channels (2..4 per pixel): the same window, every slot holding all channels of its pixel -- as WORDS raw
 // words, so that 8-bit RGB(A) costs one LDS word per slot like a plain image (16-bit: one or two, fp32: one per

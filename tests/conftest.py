@@ -67,6 +67,7 @@ def hostemu(aai):
             os.path.join(ROOT, "area_average_interpolation_amd", "csrc", "aai_plan.hpp"),
             os.path.join(ROOT, "area_average_interpolation_amd", "csrc", "aai_rot_math.hpp"),
             os.path.join(ROOT, "area_average_interpolation_amd", "csrc", "aai_rot_quad.hpp"),
+            os.path.join(ROOT, "area_average_interpolation_amd", "csrc", "aai_rot_cell.hpp"),
             os.path.join(ROOT, "area_average_interpolation_amd", "csrc", "aai_strict.hpp")]
     if not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
         _run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-o", so, srcs[0]])
@@ -119,6 +120,8 @@ def hostemu(aai):
     lib.aai_emu_skip_axis_fixup.argtypes = [ctypes.c_int]
     lib.aai_emu_use_quad.restype = None
     lib.aai_emu_use_quad.argtypes = [ctypes.c_int]
+    lib.aai_emu_use_cell.restype = None
+    lib.aai_emu_use_cell.argtypes = [ctypes.c_int]
     lib.aai_emu_quad_stats.restype = None
     lib.aai_emu_quad_stats.argtypes = [ctypes.POINTER(ctypes.c_long), ctypes.POINTER(ctypes.c_long)]
     lib.aai_emu_quad_pair_check.restype = ctypes.c_long

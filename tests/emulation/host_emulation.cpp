@@ -15,6 +15,7 @@
 #include "../../area_average_interpolation_amd/csrc/aai_rot_math.hpp"
 #include "../../area_average_interpolation_amd/csrc/aai_strict.hpp"
 #include "../../area_average_interpolation_amd/csrc/aai_rot_quad.hpp"
+#include "../../area_average_interpolation_amd/csrc/aai_rot_cell.hpp"
 #include "../../area_average_interpolation_amd/csrc/aai_axis_verify.hpp"
 
 using namespace aai;
@@ -241,6 +242,7 @@ static int g_skipAxisFixup = 0;  // test hook: K1's separable weights alone, wit
 static int g_forceRotated = 0;   // test hook: axis-aligned requests take the per-pixel path (production pass + knife-edge fix-up) too
 static int g_useQuad = 0;        // test hook: 1 = unflagged area-mode pixels take the fp32 quad formulation (aai_rot_quad.hpp) like the GPU does
 static long g_quadPixels = 0, g_quadUncertain = 0;   // pixels answered by the quad path / left to the double-precision path by its scan
+static int g_useCell = 0;        // test hook: 1 = unflagged area-mode pixels take the fp32 cell formulation (aai_rot_cell.hpp) like aai_cell_kernel does
 
 // source access of the quad formulation: window slot -> virtual pixel -> image element (staged like the GPU does)
 template <int WIN>
@@ -293,6 +295,71 @@ static bool emu_quad_fast_pixel(const QuadConsts<float> &qc, const RotLaunch &r,
     return true;
 }
 
+// The cell formulation (aai_rot_cell.hpp) over a whole image, as aai_cell_kernel runs it: every cell (x, y), x in [0, dW],
+// y in [0, dH], evaluated once (scan first: a cell with a decision too close to its threshold marks itself), its four parts
+// kept; emu_rotated combines them per dst pixel in the kernel's order.
+struct EmuCells {
+    int W1 = 0, H1 = 0;
+    std::vector<float> a[4], va[4];
+    std::vector<unsigned char> unc;
+    bool ok = false;
+};
+template <int WIN>
+static void emu_cells_win(const RotLaunch &r, const QuadConsts<float> &qc, const CellConsts<float> &zc, const float *img, int64_t stride, EmuCells &out)
+{
+    for (int y = 0; y <= r.dH; ++y)
+        for (int x = 0; x <= r.dW; ++x) {
+            const size_t at = (size_t)y * out.W1 + x;
+            int Zx, Zy; double dfx, dfy;
+            if (!cell_anchor(r, zc, x, y, Zx, Zy, dfx, dfy)) continue;
+            EmuQuadSrc<WIN> qs{&r, img, stride, {}};
+            float sA[4], sVA[4];
+            bool u;
+            if (qc.hiPrec) {
+                u = cell_eval<float, WIN, true, true>(qc, zc, Zx, Zy, dfx, dfy, r.mW, r.mH, qs, sA, sVA);
+                cell_eval<float, WIN, false, true>(qc, zc, Zx, Zy, dfx, dfy, r.mW, r.mH, qs, sA, sVA);
+            } else {
+                u = cell_eval<float, WIN, true, false>(qc, zc, Zx, Zy, dfx, dfy, r.mW, r.mH, qs, sA, sVA);
+                cell_eval<float, WIN, false, false>(qc, zc, Zx, Zy, dfx, dfy, r.mW, r.mH, qs, sA, sVA);
+            }
+            out.unc[at] = u ? 1 : 0;
+            for (int t = 0; t < 4; ++t) { out.a[t][at] = sA[t]; out.va[t][at] = sVA[t]; }
+        }
+}
+static void emu_cells(const RotLaunch &r, const float *img, int64_t stride, EmuCells &out)
+{
+    const QuadConsts<float> qc = make_quad_consts<float>(r.side, r.c, r.s, r.policy, r.scale);
+    const CellConsts<float> zc = make_cell_consts<float>(r.side, r.c, r.s);
+    out.W1 = r.dW + 1; out.H1 = r.dH + 1;
+    const size_t n = (size_t)out.W1 * out.H1;
+    for (int t = 0; t < 4; ++t) { out.a[t].assign(n, 0.f); out.va[t].assign(n, 0.f); }
+    out.unc.assign(n, 0);
+    out.ok = true;
+    switch (zc.win) {
+    case 1: emu_cells_win<1>(r, qc, zc, img, stride, out); break;
+    case 2: emu_cells_win<2>(r, qc, zc, img, stride, out); break;
+    case 3: emu_cells_win<3>(r, qc, zc, img, stride, out); break;
+    case 4: emu_cells_win<4>(r, qc, zc, img, stride, out); break;
+    case 5: emu_cells_win<5>(r, qc, zc, img, stride, out); break;
+    case 6: emu_cells_win<6>(r, qc, zc, img, stride, out); break;
+    case 7: emu_cells_win<7>(r, qc, zc, img, stride, out); break;
+    case 8: emu_cells_win<8>(r, qc, zc, img, stride, out); break;
+    default: out.ok = false; break;
+    }
+}
+// dst pixel (x, y) from its four cells; false: one of them (or the pixel's total area) leaves it to double precision
+static bool emu_cell_pixel(const EmuCells &c, const QuadConsts<float> &qc, int x, int y, float &value)
+{
+    const size_t o = (size_t)y * c.W1 + x, w = o + 1, n = o + c.W1, nw = n + 1;
+    if (c.unc[o] || c.unc[w] || c.unc[n] || c.unc[nw]) return false;
+    float A, VA;
+    cell_combine(c.a[CELL_O][o], c.a[CELL_W][w], c.a[CELL_N][n], c.a[CELL_NW][nw], A);
+    cell_combine(c.va[CELL_O][o], c.va[CELL_W][w], c.va[CELL_N][n], c.va[CELL_NW][nw], VA);
+    if (A > 0.f && A < qc.minArea) return false;
+    value = A > 0.f ? VA / A : 0.f;
+    return true;
+}
+
 static long g_axisFixups = 0;      // dst pixels of the last axis-aligned request recomputed by the fix-up pass
 // onlyAxisDiffering: the fix-up pass behind K1 -- only the dst pixels where the separable model departs from the
 // reference's classifier (aai_axis_verify.hpp) are computed, the others keep what K1 wrote
@@ -305,6 +372,8 @@ static void emu_rotated(const Geometry &g, const aai_request &rq, const float *i
     const bool quad = g_useQuad && r.quad;
     const bool fastQuad = rq.mode == AAI_MODE_FAST;
     const QuadConsts<float> qc = make_quad_consts<float>(r.side, r.c, r.s, r.policy, r.scale);
+    EmuCells cells;
+    if (g_useCell && r.quad && rq.mode == AAI_MODE_AREA && cell_supported(r.side, r.c, r.s) && !onlyAxisDiffering) emu_cells(r, img, srcStride, cells);
     for (int dy = 0; dy < r.dH; ++dy)
         for (int dx = 0; dx < r.dW; ++dx) {
             double px, py;
@@ -322,7 +391,11 @@ static void emu_rotated(const Geometry &g, const aai_request &rq, const float *i
             long knifeHere = 0;
             // the production pass flags whole dst pixels; only flagged ones reach the strict replay
             const bool flagged = pixel_on_knife_edge(r, px, py, rq.mode != AAI_MODE_FAST);
-            if (quad && !flagged) {
+            if (cells.ok && !flagged) {
+                float value = 0.f;
+                if (emu_cell_pixel(cells, qc, dx, dy, value)) { *out = value; ++g_quadPixels; continue; }
+                ++g_quadUncertain;
+            } else if (quad && !flagged) {
                 // the GPU's production pass for generic pixels: fp32, relative to the nearest virtual pixel
                 float value = 0.f;
                 bool done;
@@ -486,6 +559,32 @@ static void emu_quad_slot_areas(const RotLaunch &r, double px, double py, double
         areas[k] = va[0];
     }
 }
+// debugging aid / precision check: the four parts (own, W, N, NW: area sums, then area x value sums) of dst pixel (dx, dy)
+// in the cell formulation, evaluated in fp32 as the kernel does (out32[8]) and with the same code in double precision
+// (out64[8]); returns the cell window size, or < 0
+template <typename F, int WIN>
+static void emu_cell_parts(const RotLaunch &r, const float *img, int dx, int dy, double *out)
+{
+    struct Src {
+        const RotLaunch *r; const float *img; int64_t stride; float v[WIN * WIN];
+        void issue(int xg0, int yg0, unsigned long long valid) { for (int j = 0; j < WIN; ++j) for (int i = 0; i < WIN; ++i) v[j * WIN + i] = ((valid >> (j * WIN + i)) & 1) ? img[virt_offset(*r, xg0 + i, yg0 + j, stride)] : 0.f; }
+        void commit() {}
+        void at(int slot, F (&vals)[1]) const { vals[0] = (F)v[slot]; }
+    };
+    const QuadConsts<F> q = make_quad_consts<F>(r.side, r.c, r.s, r.policy, r.scale);
+    const CellConsts<F> z = make_cell_consts<F>(r.side, r.c, r.s);
+    const int cxs[4] = {dx, dx + 1, dx, dx + 1}, cys[4] = {dy, dy, dy + 1, dy + 1};
+    for (int t = 0; t < 4; ++t) {
+        out[t] = out[4 + t] = 0;
+        int Zx, Zy; double dfx, dfy;
+        if (!cell_anchor(r, z, cxs[t], cys[t], Zx, Zy, dfx, dfy)) continue;
+        Src qs{&r, img, r.W, {}};
+        F sA[4], sVA[4];
+        if (q.hiPrec) cell_eval<F, WIN, false, true>(q, z, Zx, Zy, dfx, dfy, r.mW, r.mH, qs, sA, sVA);
+        else cell_eval<F, WIN, false, false>(q, z, Zx, Zy, dfx, dfy, r.mW, r.mH, qs, sA, sVA);
+        out[t] = sA[t]; out[4 + t] = sVA[t];
+    }
+}
 extern "C" {
 int aai_emu_quad_slot_debug(const aai_request *rq, int dx, int dy, double *f32areas, double *f64areas)
 {
@@ -585,6 +684,25 @@ int aai_emu_resample_channels(const aai_request *rq, int C, const float *src, fl
 
 void aai_emu_force_general(int on) { g_forceGeneral = on; }
 void aai_emu_use_quad(int on) { g_useQuad = on; }
+void aai_emu_use_cell(int on) { g_useCell = on; }
+
+int aai_emu_cell_parts(const aai_request *rq, int dx, int dy, const float *img, double *out32, double *out64)
+{
+    Geometry g; std::string msg;
+    if (make_geometry(*rq, g, msg) != AAI_OK) return -1;
+    const RotLaunch r = make_rot_launch(g, AAI_MODE_AREA, rq->policy);
+    if (!r.cell) return -2;
+    const int win = make_cell_consts<float>(r.side, r.c, r.s).win;
+    switch (win) {
+    case 2: emu_cell_parts<float, 2>(r, img, dx, dy, out32); emu_cell_parts<double, 2>(r, img, dx, dy, out64); break;
+    case 3: emu_cell_parts<float, 3>(r, img, dx, dy, out32); emu_cell_parts<double, 3>(r, img, dx, dy, out64); break;
+    case 4: emu_cell_parts<float, 4>(r, img, dx, dy, out32); emu_cell_parts<double, 4>(r, img, dx, dy, out64); break;
+    case 5: emu_cell_parts<float, 5>(r, img, dx, dy, out32); emu_cell_parts<double, 5>(r, img, dx, dy, out64); break;
+    case 6: emu_cell_parts<float, 6>(r, img, dx, dy, out32); emu_cell_parts<double, 6>(r, img, dx, dy, out64); break;
+    default: return -3;
+    }
+    return win;
+}
 void aai_emu_force_rotated(int on) { g_forceRotated = on; }
 void aai_emu_skip_axis_fixup(int on) { g_skipAxisFixup = on; }
 long aai_emu_axis_fixups() { return g_axisFixups; }

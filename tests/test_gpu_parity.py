@@ -782,6 +782,32 @@ def test_quad_kernel_equals_its_cpu_replay_bit_for_bit(gpu, hostemu, po):
         hostemu.aai_emu_use_quad(0)
 
 
+def test_cell_kernel_equals_its_cpu_replay_bit_for_bit(gpu, hostemu, po):
+    """The cell kernel (one lane per cell of the dst grid, every (dst, src) pair evaluated once and shared between the dst
+    pixels it feeds: csrc/aai_rot_cell.hpp) against the CPU replay of the same header, which adds a dst pixel's four parts
+    in the kernel's order: bit for bit outside the pixels the scan leaves to the double-precision pass.  Plain fp32 and
+    8-bit sources, every quadrant, both policies, up- and down-sampling, a strip boundary (more than 63 dst columns) and
+    row bands of the kernel's strips (more than 32 dst rows)."""
+    rng = np.random.default_rng(78)
+    hostemu.aai_emu_use_cell(1)
+    try:
+        for (W, H, sr, dr, ang, policy) in ((200, 160, 8192.0, 2731.0, 17.5, 0), (96, 96, 1.0, 4.0, 45.0, 0), (180, 140, 4.0, 1.0, 0.5, 0),
+                                            (150, 150, 2.0, 1.0, 117.3, 1), (120, 90, 1.0, 1.0, 200.0, 0), (128, 128, 3.0, 2.0, 300.0, 0),
+                                            (256, 64, 2.5, 1.0, 33.0, 0), (90, 200, 1.0, 1.9, 251.0, 0)):
+            iso = (float(rng.uniform(0, W)), float(rng.uniform(0, H)))
+            src = rng.random((H, W)).astype(np.float32)
+            rq = gpu.make_request(W, H, sr, dr, iso, ang, mode=1, policy=policy)
+            ref, axis = hostemu.resample(rq, src)
+            cell, flagged = hostemu.quad_stats()
+            rc, msg, dst, _, lay = gpu.resample_host(src, sr, dr, iso, ang, mode=1, policy=policy)
+            assert rc == 0 and "aai_cell_kernel" in gpu.last_kernel(), (msg, gpu.last_kernel())
+            differ = int((dst != ref).sum())
+            assert cell > 0 and differ <= flagged, (W, H, sr, dr, ang, differ, flagged, cell)
+            assert rel_err(dst, ref).max() <= 3e-7
+    finally:
+        hostemu.aai_emu_use_cell(0)
+
+
 def test_double_precision_policy(gpu, po):
     """AAI_POLICY_DOUBLE_PRECISION routes general rotations to the double-precision kernels: exact to fp32 rounding on
     the geometry class where the fp32 formulation has its tail (dst values far below their neighbours: slight

@@ -528,6 +528,53 @@ def test_quad_fp32_replay_matches_small_golden(aai, hostemu, po, small_golden):
         hostemu.aai_emu_use_quad(0)
 
 
+def test_cell_fp32_replay_matches_reference_goldens(aai, hostemu, po, small_golden, knife_golden):
+    """The cell formulation (csrc/aai_rot_cell.hpp: every (dst, src) pair evaluated once, by the cell of the dst grid whose
+    zone holds the source pixel's centre, and shared between the up to four dst pixels it feeds) replayed on the CPU in the
+    kernel's arrangement -- fp32 cells where the cell scan flags nothing, the double-precision path (strict replay at knife
+    edges) elsewhere -- against the unmodified reference's outputs: all 140 small cases and the 189 knife-edge geometries,
+    no pixel excepted."""
+    hostemu.aai_emu_use_cell(1)
+    try:
+        for z, manifest in (small_golden, knife_golden):
+            cell = flagged = 0
+            for i, c in enumerate(manifest):
+                src = po.synth_image(c["W"], c["H"], c["seed"])
+                rq = aai.make_request(c["W"], c["H"], c["src_res"], c["dst_res"], c["iso"], c["angle"], mode=1)
+                out, axis = hostemu.resample(rq, src)
+                key = "c%03d_exact" % i
+                gold = z[key] if key in z.files else z["k%03d_exact" % i]
+                q, u = hostemu.quad_stats()
+                cell += q
+                flagged += u
+                assert rel_err(out, gold).max() <= 0.3 * TOL, (i, c, float(rel_err(out, gold).max()))
+                assert np.array_equal(gold == 0, out == 0), i
+            assert cell > 20000 and flagged < 0.2 * cell, (cell, flagged)
+    finally:
+        hostemu.aai_emu_use_cell(0)
+
+
+def test_cell_fp32_replay_against_oracle_at_larger_sizes(aai, hostemu, po):
+    """... and against the oracle at sizes where border pixels no longer dominate: BASELINE config 3's and 5's geometries,
+    all quadrants, both policies, near-axis rotations (hiPrec); few pixels left to the double-precision pass."""
+    hostemu.aai_emu_use_cell(1)
+    try:
+        for (W, sr, dr, ang, policy) in ((768, 8192.0, 2731.0, 17.5, 0), (512, 3.0, 1.0, 33.0, 0), (128, 1.0, 4.0, 45.0, 0),
+                                         (256, 1.0, 1.0, 61.0, 0), (200, 1.0, 2.0, 117.5, 1), (384, 2.0, 1.0, 215.0, 0),
+                                         (512, 4.0, 1.0, 0.5, 0), (400, 2.0, 1.0, 89.5, 0), (300, 1.0, 1.0, 179.9, 0),
+                                         (200, 1.0, 2.0, 0.2, 0), (384, 2.5, 1.0, 357.0, 1)):
+            src = po.synth_image(W, W, 2)
+            iso = ((W - 1) / 2, (W - 1) / 2)
+            out, axis = hostemu.resample(aai.make_request(W, W, sr, dr, iso, ang, mode=1, policy=policy), src)
+            q, u = hostemu.quad_stats()
+            gold = po.oracle_run(po.MODE_EXACT, src.astype(np.float64), sr, dr, iso, ang, policy=policy).dst
+            assert not axis and q > 0 and u < 0.02 * q, (W, sr, dr, ang, q, u)
+            assert rel_err(out, gold).max() <= 0.5 * TOL, (W, sr, dr, ang, float(rel_err(out, gold).max()))
+            assert np.array_equal(gold == 0, out == 0)
+    finally:
+        hostemu.aai_emu_use_cell(0)
+
+
 def test_quad_fp32_replay_against_oracle_at_larger_sizes(aai, hostemu, po):
     """BASELINE config 3's ratio and angle, config 5's (x4 up-sampling at 45 degrees: replicated virtual pixels) and a few
     others at sizes where border pixels no longer dominate: error well inside the bar and few pixels left to the
