@@ -27,7 +27,8 @@ __device__ __forceinline__ void load_line(const float *p, float (&seg)[N])
 // The staged window of one lane.  Offsets are unsigned bytes from the image's first element (QuadMap: non-negative
 // strides), one table per axis; positions outside the lattice are clamped onto it -- their values are fetched but
 // never read (quad_pixel only reads slots whose valid bit is set).
-template <typename T, int WIN, bool SCALED>
+// STAGED: the caller reads values through commit() / at() only (not reg()): vector-loaded lines may stay in memory order
+template <typename T, int WIN, bool SCALED, bool STAGED = false>
 struct QuadSrc {
     const char *img;                 // first element of this image (band offset included)
     const QuadMap *m;
@@ -35,6 +36,7 @@ struct QuadSrc {
     float (*lds)[kQuadBlock];        // [WIN * WIN][kQuadBlock]
     int tid;
     T v[WIN * WIN];
+    int arranged;                    // STAGED: 0 = v[] is in slot order; else 1 + arrangement of the vector-loaded lines (commit)
 
     __device__ __forceinline__ void issue(int xg0, int yg0, unsigned long long)
     {
@@ -83,15 +85,30 @@ struct QuadSrc {
         // are L source pixels apart, so every load instruction touches a dozen cache lines and their NUMBER is what the
         // texture path charges for.  Only where no lane of the wave has a clamped (off-image) column or row.
         const bool inside = xg0 >= 0 && xg0 + WIN <= mW && yg0 >= 0 && yg0 + WIN <= mH;
+        arranged = 0;
         if (!SCALED && sizeof(T) == 4 && __all(inside)) {
-            const bool alongX = sxb == (unsigned)sizeof(T);               // wave-uniform
+            // (every condition below is wave-uniform: the map is a kernel argument)
+            const bool alongX = sxb == (unsigned)sizeof(T);
+            const bool rev = alongX ? m->flipX != 0 : m->flipY != 0;      // the window axis runs against memory
+            const unsigned first0 = alongX ? (rev ? colOff[WIN - 1] : colOff[0]) : (rev ? rowOff[WIN - 1] : rowOff[0]);
+            if (STAGED) {
+                // keep the lines as they lie in memory; commit() parks every element in its slot (static LDS offsets per
+                // arrangement: no per-element selects, nothing to merge back into registers)
+                arranged = 1 + (alongX ? 0 : 2) + (rev ? 1 : 0);
+#pragma unroll
+                for (int k = 0; k < WIN; ++k) {
+                    float seg[WIN];
+                    load_line<WIN>(reinterpret_cast<const float *>(img + ((alongX ? rowOff[k] : colOff[k]) + first0)), seg);
+#pragma unroll
+                    for (int e = 0; e < WIN; ++e) v[k * WIN + e] = (T)seg[e];
+                }
+                return;
+            }
 #pragma unroll
             for (int k = 0; k < WIN; ++k) {
                 // line k: fixed row (alongX) or fixed column, its WIN elements ascending in memory from `first`
-                const unsigned first = alongX ? rowOff[k] + min(colOff[0], colOff[WIN - 1]) : colOff[k] + min(rowOff[0], rowOff[WIN - 1]);
-                const bool rev = alongX ? colOff[0] > colOff[WIN - 1] : rowOff[0] > rowOff[WIN - 1];
                 float seg[WIN];
-                load_line<WIN>(reinterpret_cast<const float *>(img + first), seg);
+                load_line<WIN>(reinterpret_cast<const float *>(img + ((alongX ? rowOff[k] : colOff[k]) + first0)), seg);
 #pragma unroll
                 for (int e = 0; e < WIN; ++e) {
                     const float val = rev ? seg[WIN - 1 - e] : seg[e];
@@ -108,6 +125,31 @@ struct QuadSrc {
     }
     __device__ __forceinline__ void commit()
     {
+        if (STAGED && arranged) {
+            const int a = __builtin_amdgcn_readfirstlane(arranged) - 1;      // bit 1: lines are columns, bit 0: reversed
+            if (a == 0) {
+#pragma unroll
+                for (int k = 0; k < WIN; ++k)
+#pragma unroll
+                    for (int e = 0; e < WIN; ++e) lds[k * WIN + e][tid] = (float)v[k * WIN + e];
+            } else if (a == 1) {
+#pragma unroll
+                for (int k = 0; k < WIN; ++k)
+#pragma unroll
+                    for (int e = 0; e < WIN; ++e) lds[k * WIN + (WIN - 1 - e)][tid] = (float)v[k * WIN + e];
+            } else if (a == 2) {
+#pragma unroll
+                for (int k = 0; k < WIN; ++k)
+#pragma unroll
+                    for (int e = 0; e < WIN; ++e) lds[e * WIN + k][tid] = (float)v[k * WIN + e];
+            } else {
+#pragma unroll
+                for (int k = 0; k < WIN; ++k)
+#pragma unroll
+                    for (int e = 0; e < WIN; ++e) lds[(WIN - 1 - e) * WIN + k][tid] = (float)v[k * WIN + e];
+            }
+            return;
+        }
 #pragma unroll
         for (int k = 0; k < WIN * WIN; ++k) lds[k][tid] = (float)v[k];
     }

@@ -27,8 +27,13 @@ namespace {
 
 constexpr int kCellCols = 63;        // dst columns a wave completes (its 64th cell only feeds column 62)
 
-// lane i <- lane i + 1 (lane 63 gets its own value: it never stores)
-__device__ __forceinline__ float from_next_lane(float v) { return __shfl_down(v, 1); }
+// lane i <- lane i + 1 (lane 63 gets 0: it never stores): one DPP move across the whole wave (wave_shl:1, a gfx9 control)
+// instead of a round trip through the LDS crossbar (ds_bpermute) at the end of every row
+__device__ __forceinline__ float from_next_lane(float v)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x130, 0xf, 0xf, false));
+}
+__device__ __forceinline__ int from_next_lane(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x130, 0xf, 0xf, false); }
 
 // waves per SIMD the staged windows leave room for: WIN * WIN KiB of LDS per 256-lane block, 160 KiB per CU
 constexpr int cell_waves_per_simd(int win) { return 160 / (win * win) >= 8 ? 8 : 160 / (win * win); }
@@ -51,12 +56,15 @@ __global__ __launch_bounds__(kQuadBlock, cell_min_waves(WIN)) void aai_cell_kern
     const int x0 = (blockIdx.x * (kQuadBlock / 64) + wave) * kCellCols;
     if (x0 >= r.dW) return;                                   // wave-uniform; no barrier below
     const int cx = x0 + lane;
+    // (row bands in launch order: dealing them from the middle outwards, so that the launch's tail is made of the cheap
+    // corner bands, measured 5 % SLOWER at config 3 -- profiles/r03_cell_kernel.txt)
     const int y0 = r.dyBase + blockIdx.y * rowsPerStrip;
     const int y1 = min(y0 + rowsPerStrip, r.dyEnd);           // dst rows [y0, y1); cells rows y0 .. y1
     const bool stores = lane < kCellCols && cx < r.dW;
     float *outCol = dst + (int64_t)blockIdx.z * dv.imageStride + cx;
     const char *img = reinterpret_cast<const char *>(src + (int64_t)blockIdx.z * sv.imageStride + m.base);
 
+    const CellColumn col = cell_column(r, z, cx);
     float pendA = 0.f, pendVA = 0.f;
     for (int cy = y0; cy <= y1; ++cy) {
         // the row above is finished in this iteration: is its pixel one the plan's scans left to the fix-up pass?
@@ -66,9 +74,9 @@ __global__ __launch_bounds__(kQuadBlock, cell_min_waves(WIN)) void aai_cell_kern
         float sA[4] = {0.f, 0.f, 0.f, 0.f}, sVA[4] = {0.f, 0.f, 0.f, 0.f};
         int Zx = 0, Zy = 0;
         double dfx = 0.0, dfy = 0.0;
-        const bool live = cx <= r.dW && cell_anchor(r, z, cx, cy, Zx, Zy, dfx, dfy);
+        const bool live = cx <= r.dW && cell_anchor(r, col, cy, Zx, Zy, dfx, dfy);
         if (live) {
-            QuadSrc<T, WIN, SCALED> s;
+            QuadSrc<T, WIN, SCALED, true> s;
             s.img = img; s.m = &m; s.mW = r.mW; s.mH = r.mH; s.lds = window; s.tid = tid;
             cell_eval<float, WIN, false, HP>(q, z, Zx, Zy, dfx, dfy, r.mW, r.mH, s, sA, sVA);
         }
@@ -99,6 +107,7 @@ __global__ __launch_bounds__(kQuadBlock) void aai_cell_scan_kernel(RotLaunch r, 
     const int y0 = blockIdx.y * rowsPerStrip;
     const int y1 = min(y0 + rowsPerStrip, r.dH);
     const bool stores = lane < kCellCols && cx < r.dW;
+    const CellColumn col = cell_column(r, z, cx);
     float pendA = 0.f;
     int pendU = 0;
     for (int cy = y0; cy <= y1; ++cy) {
@@ -106,12 +115,12 @@ __global__ __launch_bounds__(kQuadBlock) void aai_cell_scan_kernel(RotLaunch r, 
         int Zx = 0, Zy = 0;
         double dfx = 0.0, dfy = 0.0;
         int unc = 0;
-        if (cx <= r.dW && cell_anchor(r, z, cx, cy, Zx, Zy, dfx, dfy)) {
+        if (cx <= r.dW && cell_anchor(r, col, cy, Zx, Zy, dfx, dfy)) {
             NoSrc s;
             unc = cell_eval<float, WIN, true, HP>(q, z, Zx, Zy, dfx, dfy, r.mW, r.mH, s, sA, sVA) ? 1 : 0;
         }
         const float wA = from_next_lane(sA[CELL_W]), nwA = from_next_lane(sA[CELL_NW]);
-        const int uNext = __shfl_down(unc, 1);
+        const int uNext = from_next_lane(unc);
         if (cy > y0 && stores) {
             const float A = pendA + (sA[CELL_N] + nwA);
             if (pendU | unc | uNext | ((A > 0.f && A < q.minArea) ? 1 : 0)) {

@@ -171,7 +171,7 @@ __global__ __launch_bounds__(kQuadBlock, quad_waves_per_simd(WIN) - (HP && quad_
     float value = 0.f;
     // a centre further than the window's reach from the lattice touches nothing (and stays inside int range)
     if (cx > -16.0 && cx < (double)r.mW + 16.0 && cy > -16.0 && cy < (double)r.mH + 16.0) {
-        QuadSrc<T, WIN, SCALED> s;
+        QuadSrc<T, WIN, SCALED, true> s;
         s.img = reinterpret_cast<const char *>(src + (int64_t)blockIdx.z * sv.imageStride + m.base);
         s.m = &m; s.mW = r.mW; s.mH = r.mH; s.lds = window; s.tid = tid;
         float sumA, sumVA[1];

@@ -311,7 +311,7 @@ static void emu_cells_win(const RotLaunch &r, const QuadConsts<float> &qc, const
         for (int x = 0; x <= r.dW; ++x) {
             const size_t at = (size_t)y * out.W1 + x;
             int Zx, Zy; double dfx, dfy;
-            if (!cell_anchor(r, zc, x, y, Zx, Zy, dfx, dfy)) continue;
+            if (!cell_anchor(r, cell_column(r, zc, x), y, Zx, Zy, dfx, dfy)) continue;
             EmuQuadSrc<WIN> qs{&r, img, stride, {}};
             float sA[4], sVA[4];
             bool u;
@@ -577,7 +577,7 @@ static void emu_cell_parts(const RotLaunch &r, const float *img, int dx, int dy,
     for (int t = 0; t < 4; ++t) {
         out[t] = out[4 + t] = 0;
         int Zx, Zy; double dfx, dfy;
-        if (!cell_anchor(r, z, cxs[t], cys[t], Zx, Zy, dfx, dfy)) continue;
+        if (!cell_anchor(r, cell_column(r, z, cxs[t]), cys[t], Zx, Zy, dfx, dfy)) continue;
         Src qs{&r, img, r.W, {}};
         F sA[4], sVA[4];
         if (q.hiPrec) cell_eval<F, WIN, false, true>(q, z, Zx, Zy, dfx, dfy, r.mW, r.mH, qs, sA, sVA);
