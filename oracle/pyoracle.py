@@ -170,3 +170,23 @@ def synth_image(W, H, seed=1):
         z = z ^ (z >> np.uint64(31))
         v = (z >> np.uint64(40)).astype(np.float32) * np.float32(2.0 ** -24)
     return v.reshape(H, W)
+
+
+def dose_image(W, H, seed=1, field=0.44, dmax=250.0):
+    """A film-dose-like test image (the kind of input the reference was written for, Source.cpp:1529): a flat-topped square
+    field with error-function penumbrae, scatter tails that fall to ~1e-4 of the maximum at the image border, and 1 % film
+    noise from the Appendix C.1 hash -- three to four decades of dynamic range next to each other, which uniform noise
+    never has.  Deterministic in (W, H, seed); float32, like every image the GPU path takes."""
+    from math import erf
+    y, x = np.mgrid[0:H, 0:W].astype(np.float64)
+    cx, cy = (W - 1) * 0.5 + 3.25, (H - 1) * 0.5 - 2.5            # field centre off the image centre
+    half = field * min(W, H) * 0.5
+    sigma = 0.012 * min(W, H)                                     # penumbra width
+    verf = np.vectorize(erf)
+    px = 0.5 * (verf((half - np.abs(x - cx)) / (sigma * 2 ** 0.5)) + 1.0)
+    py = 0.5 * (verf((half - np.abs(y - cy)) / (sigma * 2 ** 0.5)) + 1.0)
+    r = np.maximum(np.maximum(np.abs(x - cx), np.abs(y - cy)) - half, 0.0)
+    tail = 8e-3 * np.exp(-r / (0.05 * min(W, H))) + 1e-4          # out-of-field scatter and film base
+    noise = synth_image(W, H, seed).astype(np.float64)
+    dose = dmax * (px * py * (1.0 - tail) + tail) * (1.0 + 0.01 * (noise - 0.5))
+    return dose.astype(np.float32)

@@ -168,6 +168,14 @@ def axis_knife_golden():
     return z, manifest
 
 
+@pytest.fixture(scope="session")
+def refdefault_golden():
+    """the reference's own default call (Source.cpp:1528-1534: 150 -> 25.4 dpi about (455, 455), 1.5 degrees) on a 911 x 911
+    dose-like image, both modes, outputs of the UNMODIFIED reference (tests/golden/make_golden.py refdefault)"""
+    z = np.load(os.path.join(GOLDEN, "refdefault.npz"))
+    return z, json.loads(bytes(z["meta"]).decode())
+
+
 def load_full(name):
     z = np.load(os.path.join(GOLDEN, "full_%s.npz" % name))
     return z, json.loads(bytes(z["meta"]).decode())

@@ -13,6 +13,7 @@ source text.  Run from the repo root in the build container (the reference is ab
     python tests/golden/make_golden.py full cfg2      # tests/golden/full_cfg2.npz         (minutes, 1 core)
     python tests/golden/make_golden.py full all       # every BASELINE.json config that is CPU-feasible
     python tests/golden/make_golden.py oraclefull cfg5  # full-size config 5 through the CPU oracle (8 processes, minutes)
+    python tests/golden/make_golden.py refdefault     # tests/golden/refdefault.npz: the reference's own default call (Source.cpp:1528-1534)
 
 `full` stores, for the BASELINE-size runs, the long-double sum, the zero count, a strided sample
 grid of the output and a few complete rows (SURVEY.md Appendix C style known answers), not the
@@ -280,6 +281,32 @@ def gen_oracle_full(name, workers=8):
     print("wrote", path, os.path.getsize(path), "bytes")
 
 
+# The reference's own example call, Source.cpp:1528-1534: a ~911 x 911 film-dose image at 150 dpi resampled to 25.4 dpi
+# about isocenter (455, 455), rotated by 1.5 degrees, mode 2 (fast) by default.  The film (Test_film_dose.csv) is not
+# shipped, so the image is po.dose_image: flat field, penumbrae, tails down to 1e-4 of the maximum.
+REFDEFAULT = dict(W=911, H=911, seed=7, src_res=150.0, dst_res=25.4, iso=[455.0, 455.0], angle=1.5)
+
+
+def gen_refdefault():
+    c = REFDEFAULT
+    src = po.dose_image(c["W"], c["H"], c["seed"]).astype(np.float64)
+    store, meta = {}, dict(c)
+    meta["image"] = "oracle.pyoracle.dose_image(W, H, seed)"
+    for mode, tag in ((po.MODE_EXACT, "exact"), (po.MODE_FAST, "fast")):
+        t0 = time.time()
+        r = po.ref_run(mode, src, c["src_res"], c["dst_res"], c["iso"], c["angle"])        # the UNMODIFIED reference
+        assert r.ok, r.msg
+        store[tag] = r.dst
+        meta[tag] = dict(shape=list(r.dst.shape), dst_iso=list(r.dst_iso), ref_seconds=time.time() - t0,
+                         min=float(r.dst[r.dst != 0].min()), max=float(r.dst.max()), zeros=int((r.dst == 0).sum()))
+        print("refdefault", tag, r.dst.shape, meta[tag])
+    store["src_checksum"] = np.array([float(np.sum(src.astype(np.longdouble)))])
+    store["meta"] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
+    path = os.path.join(HERE, "refdefault.npz")
+    np.savez_compressed(path, **store)
+    print("wrote", path, os.path.getsize(path), "bytes")
+
+
 if __name__ == "__main__":
     if not po.have_ref():
         po.build()
@@ -292,6 +319,8 @@ if __name__ == "__main__":
         gen_axis_knife()
     elif what == "knife":
         gen_knife()
+    elif what == "refdefault":
+        gen_refdefault()
     elif what == "oraclefull":
         if not po.have_oracle():
             po.build()

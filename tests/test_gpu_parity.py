@@ -98,6 +98,24 @@ def test_baseline_configs_against_reference_known_answers(gpu, name):
 
 
 # ---- (b) oracle on the same seeded inputs -------------------------------------------------------------------
+def test_reference_default_call_on_a_dose_like_image(gpu, po, refdefault_golden):
+    """The reference's own example call (Source.cpp:1528-1534: a 911 x 911 film at 150 dpi to 25.4 dpi about (455, 455), rotated
+    by 1.5 degrees; mode 2 is its default) on a dose-like image -- flat field, penumbrae, tails at 1e-4 of the maximum, so
+    neighbouring values differ by decades -- against the UNMODIFIED reference's output.  1e-5 relative with an absolute floor
+    of 1e-6 (values run from 0.03 to 250), exact zeros exact; also through the double-precision policy."""
+    z, meta = refdefault_golden
+    src = po.dose_image(meta["W"], meta["H"], meta["seed"])
+    for mode, tag in ((1, "exact"), (2, "fast")):
+        for policy in (0, gpu.POLICY_DOUBLE_PRECISION):
+            rc, msg, dst, iso, lay = gpu.resample_host(src, meta["src_res"], meta["dst_res"], meta["iso"], meta["angle"], mode=mode, policy=policy)
+            assert rc == 0, msg
+            gold = z[tag]
+            assert dst.shape == gold.shape and list(iso) == meta[tag]["dst_iso"]
+            err = rel_err(dst, gold, floor=1e-6)
+            assert err.max() <= TOL, (tag, policy, gpu.last_kernel(), float(err.max()))
+            assert np.array_equal(dst == 0, gold == 0), (tag, policy)
+
+
 def test_random_geometries_against_oracle(gpu, po):
     rng = np.random.default_rng(11)
     for k in range(60):
@@ -244,6 +262,85 @@ def test_exact_policy_against_oracle(gpu, po):
         gold = po.oracle_run(po.MODE_EXACT, src.astype(np.float64), sr, dr, iso, ang, policy=po.POLICY_EXACT).dst
         dst, _, _ = _host(gpu, src, dict(src_res=sr, dst_res=dr, iso=iso, angle=ang), 1, policy=L.POLICY_EXACT)
         assert rel_err(dst, gold).max() <= TOL, (k, ang)
+
+
+def _clip_polygon(poly, x0, x1, y0, y1):
+    """Sutherland-Hodgman: convex polygon (list of (x, y)) clipped to the axis-aligned rectangle [x0, x1] x [y0, y1]."""
+    def clip(pts, inside, cross):
+        out = []
+        for i, p in enumerate(pts):
+            q = pts[(i + 1) % len(pts)]
+            if inside(p):
+                out.append(p)
+                if not inside(q):
+                    out.append(cross(p, q))
+            elif inside(q):
+                out.append(cross(p, q))
+        return out
+    def at_x(x):
+        return lambda p, q: (x, p[1] + (q[1] - p[1]) * (x - p[0]) / (q[0] - p[0]))
+    def at_y(y):
+        return lambda p, q: (p[0] + (q[0] - p[0]) * (y - p[1]) / (q[1] - p[1]), y)
+    for inside, cross in ((lambda p: p[0] >= x0, at_x(x0)), (lambda p: p[0] <= x1, at_x(x1)),
+                          (lambda p: p[1] >= y0, at_y(y0)), (lambda p: p[1] <= y1, at_y(y1))):
+        poly = clip(poly, inside, cross)
+        if len(poly) < 3:
+            return []
+    return poly
+
+
+def _polygon_area(poly):
+    return 0.5 * abs(sum(p[0] * q[1] - q[0] * p[1] for p, q in zip(poly, poly[1:] + poly[:1])))
+
+
+def test_exact_policy_against_polygon_clipping(gpu):
+    """AAI_POLICY_EXACT pinned by code that shares nothing with the product or the oracle: every dst pixel is the square
+    spanned by the steps between neighbouring dst centres (the reference's affine map restated in conftest.sample_points),
+    clipped against every source pixel of the ORIGINAL image with a Sutherland-Hodgman clip written here, areas by the
+    shoelace formula, value = sum(area x pixel) / sum(area) over the pixels inside the image (Source.cpp:426-429, 577).
+    20 geometries, all four quadrants, down- and up-sampling (replicated source pixels), off-centre isocenters."""
+    import math
+    import torch
+    rng = np.random.default_rng(21)
+    worst = 0.0
+    for k in range(20):
+        W, H = int(rng.integers(7, 22)), int(rng.integers(7, 22))
+        sr = float(rng.uniform(1.0, 4.0))
+        dr = 1.0 if k % 5 else float(rng.uniform(1.2, 2.6)) * sr             # every fifth case up-samples
+        ang = float(rng.uniform(2.0, 88.0)) + 90.0 * (k % 4)
+        iso = (float(rng.uniform(0, W - 1)), float(rng.uniform(0, H - 1))) if k % 3 else ((W - 1) / 2, (H - 1) / 2)
+        src = rng.random((H, W)).astype(np.float32)
+        rq = gpu.make_request(W, H, sr, dr, iso, ang, mode=1, policy=gpu.POLICY_EXACT)
+        rc, msg, lay = gpu.query(rq)
+        assert rc == 0, msg
+        rc, msg, dst, _, _ = gpu.resample_host(src, sr, dr, iso, ang, mode=1, policy=gpu.POLICY_EXACT)
+        assert rc == 0, msg
+        dH, dW = lay.dst_height, lay.dst_width
+        sx, sy = sample_points(rq, lay, list(range(dH + 1)), "cpu")
+        sx, sy = sx.numpy(), sy.numpy()
+        # affine map: the steps between neighbouring centres are the square's edge vectors
+        eax, eay = sx[0, 1] - sx[0, 0], sy[0, 1] - sy[0, 0]
+        ebx, eby = sx[1, 0] - sx[0, 0], sy[1, 0] - sy[0, 0]
+        gold = np.zeros((dH, dW))
+        for y in range(dH):
+            for x in range(dW):
+                cx, cy = sx[y, x], sy[y, x]
+                sq = [(cx + 0.5 * (sa * eax + sb * ebx), cy + 0.5 * (sa * eay + sb * eby)) for sa, sb in ((-1, -1), (1, -1), (1, 1), (-1, 1))]
+                xs, ys = [p[0] for p in sq], [p[1] for p in sq]
+                sa_, sva = 0.0, 0.0
+                for j in range(max(0, math.floor(min(ys) + 0.5)), min(H - 1, math.ceil(max(ys) - 0.5)) + 1):
+                    for i in range(max(0, math.floor(min(xs) + 0.5)), min(W - 1, math.ceil(max(xs) - 0.5)) + 1):
+                        a = _polygon_area(_clip_polygon(sq, i - 0.5, i + 0.5, j - 0.5, j + 0.5) or [(0, 0)] * 3)
+                        sa_ += a
+                        sva += a * float(src[j, i])
+                gold[y, x] = sva / sa_ if sa_ > 1e-12 else 0.0
+        # pixels that only graze the image (area below 1e-9 of a source pixel) are decided by rounding on either side
+        err = rel_err(dst, gold)
+        graze = (np.abs(gold) == 0) != (dst == 0)
+        assert graze.sum() <= 2, (k, int(graze.sum()))
+        worst = max(worst, float(err[~graze].max()))
+        assert err[~graze].max() <= TOL, (k, W, H, sr, dr, ang, float(err[~graze].max()))
+    assert worst > 0.0
 
 
 def test_comparison_samplers_against_cpu_restatement(gpu, po):
@@ -517,6 +614,26 @@ def test_samplers_at_full_size(gpu, cfg):
                 grid = torch.stack(((2 * sx + 1) / W - 1, (2 * sy + 1) / H - 1), dim=-1)[None]
                 ref = torch.nn.functional.grid_sample(x.double()[None, None], grid, mode="bilinear", padding_mode="border", align_corners=False)[0, 0]
                 assert float((got - ref)[inside].abs().max()) <= 1e-5, (cfg, rows[0])
+            else:
+                # Bicubic, pinned independently: Keys' cubic convolution kernel (a = -0.5) as published -- piecewise in the
+                # DISTANCE d from the sample point: (a + 2) d^3 - (a + 3) d^2 + 1 for d <= 1, a d^3 - 5a d^2 + 8a d - 4a for
+                # 1 < d < 2 -- evaluated in float64 torch at the 4 x 4 clamp-to-edge taps around the same sample points
+                def keys_kernel(d, a=-0.5):
+                    d = d.abs()
+                    near = ((a + 2.0) * d - (a + 3.0)) * d * d + 1.0
+                    far = ((a * d - 5.0 * a) * d + 8.0 * a) * d - 4.0 * a
+                    return torch.where(d <= 1.0, near, torch.where(d < 2.0, far, torch.zeros_like(d)))
+                x64 = x.double()
+                fx, fy = torch.floor(sx), torch.floor(sy)
+                ref = torch.zeros_like(sx)
+                for ky in range(-1, 3):
+                    wy = keys_kernel(sy - (fy + ky))
+                    iy = (fy + ky).clamp(0, H - 1).long()
+                    for kx in range(-1, 3):
+                        ix = (fx + kx).clamp(0, W - 1).long()
+                        ref += wy * keys_kernel(sx - (fx + kx)) * x64[iy, ix]
+                assert float((got - ref)[inside].abs().max()) <= 1e-5, (cfg, rows[0], float((got - ref)[inside].abs().max()))
+                del x64, fx, fy, ref
             del sx, sy, inside, got
         assert inside_total > 0
         # constant -> constant wherever the sample point lies inside the image extent, exact 0 elsewhere

@@ -554,6 +554,28 @@ def test_cell_fp32_replay_matches_reference_goldens(aai, hostemu, po, small_gold
         hostemu.aai_emu_use_cell(0)
 
 
+def test_fp32_replays_on_the_reference_default_call(aai, hostemu, po, refdefault_golden):
+    """The reference's own example (150 -> 25.4 dpi about (455, 455), 1.5 degrees: 5.9 : 1 within two degrees of an axis, so
+    hiPrec, 7 x 7 / 8 x 8 windows) on a dose-like image whose values span four decades next to each other: relative error
+    against the unmodified reference's output with an absolute floor of 1e-6 (values run from 0.03 to 250) -- the fp32
+    formulations' "value far below its neighbours" caveat (include/aai.h) is exactly what this image probes."""
+    z, meta = refdefault_golden
+    src = po.dose_image(meta["W"], meta["H"], meta["seed"])
+    for hook, modes in ((hostemu.aai_emu_use_cell, ((1, "exact"),)), (hostemu.aai_emu_use_quad, ((1, "exact"), (2, "fast")))):
+        hook(1)
+        try:
+            for mode, tag in modes:
+                rq = aai.make_request(meta["W"], meta["H"], meta["src_res"], meta["dst_res"], meta["iso"], meta["angle"], mode=mode)
+                out, axis = hostemu.resample(rq, src)
+                q, u = hostemu.quad_stats()
+                gold = z[tag]
+                assert not axis and q > 0.8 * out.size - meta[tag]["zeros"], (tag, q, u)
+                assert rel_err(out, gold, floor=1e-6).max() <= TOL, (tag, float(rel_err(out, gold, floor=1e-6).max()))
+                assert np.array_equal(gold == 0, out == 0)
+        finally:
+            hook(0)
+
+
 def test_cell_fp32_replay_against_oracle_at_larger_sizes(aai, hostemu, po):
     """... and against the oracle at sizes where border pixels no longer dominate: BASELINE config 3's and 5's geometries,
     all quadrants, both policies, near-axis rotations (hiPrec); few pixels left to the double-precision pass."""
