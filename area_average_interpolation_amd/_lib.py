@@ -80,6 +80,8 @@ SYMBOLS = {
     "aai_synth_device_f32": (ctypes.c_int, [_P, ctypes.c_int32, ctypes.c_int32, _I64, ctypes.c_uint64, _P]),
     "aai_synth_rows_device_f32": (ctypes.c_int, [_P, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, _I64, ctypes.c_uint64, _P]),
     "aai_prepare": (ctypes.c_int, [_RQ, ctypes.c_int32]),
+    "aai_plan_info": (ctypes.c_int, [_RQ, ctypes.c_int32, ctypes.c_char_p, ctypes.c_int32]),
+    "aai_shutdown": (ctypes.c_int, []),
     "aai_last_kernel": (ctypes.c_char_p, []),
 }
 

@@ -273,6 +273,21 @@ def resample_band_device(request, dst_row0, dst_row1, src_rows_ptr, src_stride, 
         raise AaiError(rc, last_error())
 
 
+def plan_shape(request, channels=1):
+    """aai_plan_info: one line describing the cached whole-image plan of this request on the current device ("" if none):
+    kernel family, K1 launch shape and its origin, flagged pixels, fp32 formulation, build time."""
+    buf = ctypes.create_string_buffer(512)
+    rc = L.load().aai_plan_info(ctypes.byref(request), int(channels), buf, 512)
+    if rc != L.OK:
+        raise AaiError(rc, last_error())
+    return buf.value.decode()
+
+
+def shutdown():
+    """aai_shutdown: drop every cached plan now (optional; a process may simply exit)."""
+    L.load().aai_shutdown()
+
+
 def prepare(request, channels=1):
     """aai_prepare: build (and cache) the plan of this request on the current device now -- K1 tables, the one-off
     scans of a rotated geometry -- instead of inside the first resampling call, which would then synchronise."""

@@ -273,12 +273,31 @@ int aai_prepare(const aai_request *req, int32_t channels)
     }
     rc = require_device();
     if (rc != AAI_OK) return rc;
-    std::lock_guard<std::mutex> lock(g_planMutex);
-    Plan *p = nullptr;
+    PlanRef p;
     // (the plan of a packed fp32 image: what the device entries build on their first call)
-    rc = get_plan(*req, -1, -1, channels, rot_form(*req, g, channels, aai::SRC_F32, (int64_t)g.W * channels), &p);
+    rc = acquire_plan(*req, -1, -1, channels, rot_form(*req, g, channels, aai::SRC_F32, (int64_t)g.W * channels), &p);
     if (rc == AAI_OK) g_lastError.clear();
     return rc;
+}
+
+int aai_plan_info(const aai_request *req, int32_t channels, char *text, int32_t capacity)
+{
+    int rc = check_request(req);
+    if (rc != AAI_OK) return rc;
+    if (!text || capacity <= 0) return fail(AAI_ERR_BAD_ARGUMENT, "Null text buffer.");
+    rc = require_device();
+    if (rc != AAI_OK) return rc;
+    const std::string d = plan_description(*req, channels);
+    snprintf(text, (size_t)capacity, "%s", d.c_str());
+    g_lastError.clear();
+    return AAI_OK;
+}
+
+int aai_shutdown(void)
+{
+    drop_plans();
+    g_lastError.clear();
+    return AAI_OK;
 }
 
 /* experiments only (tools/tune_axis.py); not declared in include/aai.h */
@@ -286,17 +305,9 @@ void aai_debug_axis_tune(const char *spec) { aai::set_axis_tune(spec); }
 
 const char *aai_debug_plan_shape(const aai_request *req)
 {
-    // "kernel=K rows=R nt=N swap=S flagged=F dense=D" of the cached whole-image plan of this request on the current device
-    // ("" when there is none)
+    // kept for tools/ written against round 2: the text of aai_plan_info
     static thread_local std::string text;
-    text.clear();
-    int dev = -1;
-    if (!req || hipGetDevice(&dev) != hipSuccess) return text.c_str();
-    std::lock_guard<std::mutex> lock(g_planMutex);
-    for (const Plan &p : g_plans)
-        if (p.device == dev && p.band0 < 0 && p.channels == 1 && same_request(p.key, *req))
-            text = "kernel=" + std::to_string(p.kernel) + " rows=" + std::to_string(p.tuneRows) + " nt=" + std::to_string(p.tuneNt) + " swap=" + std::to_string(p.tuneSwap) +
-                   " flagged=" + std::to_string(p.flaggedPixels) + " dense=" + std::to_string(p.dense ? 1 : 0);
+    text = req ? plan_description(*req, 1) : std::string();
     return text.c_str();
 }
 

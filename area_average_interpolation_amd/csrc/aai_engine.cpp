@@ -6,8 +6,12 @@
 // AAI_ERR_NO_DEVICE.  The CPU oracle under oracle/ is test infrastructure and is never linked or loaded.
 #include "aai_engine.hpp"
 
+#include <chrono>
 #include <climits>
 #include <cmath>
+#include <cstdio>
+#include <map>
+#include <tuple>
 #include <cstdlib>
 #include <cstring>
 #include <algorithm>
@@ -35,7 +39,20 @@ int hip_fail(hipError_t e, const char *what)
 
 // ---- plan cache ------------------------------------------------------------------------------------
 std::mutex g_planMutex;
-std::list<Plan> g_plans;              // most recently used first
+std::list<PlanRef> &plan_cache()
+{
+    static std::list<PlanRef> *cache = new std::list<PlanRef>();      // never destroyed: no HIP calls from static destructors
+    return *cache;
+}
+void drop_plans()
+{
+    std::list<PlanRef> gone;
+    {
+        std::lock_guard<std::mutex> lock(g_planMutex);
+        gone.swap(plan_cache());
+    }
+    gone.clear();                     // frees device memory of every plan nobody is launching from
+}
 constexpr size_t kMaxPlans = 32;       // per device
 constexpr unsigned kMaxListedPixels = 1u << 24;      // beyond 16 M flagged pixels the whole image takes the double-precision pass
 
@@ -121,11 +138,29 @@ static aai::AxisLaunch make_axis_launch(const Plan &p, int channels, int64_t dst
 }
 
 // K1 is HBM-bound and its best launch shape moves with the box by a few per cent (the same binary measured 5.8 to 6.9
-// TB/s across boxes of one pool: profiles/r01_axis_tune_sweep2.txt, profiles/r02_axis_autotune.txt), so a plan for a
-// large streaming geometry times the shapes that ever win -- output rows per workgroup, nontemporal or cached loads,
-// grid order -- once on this device, on scratch images larger than the Infinity Cache, and keeps the fastest.  Only the
-// common family (plain fp32 images, footprints of >= 4 source rows, un-transposed quadrants, whole image).
-static void tune_axis_plan(Plan &p, int channels, int band0)
+// TB/s across boxes of one pool: profiles/r01_axis_tune_sweep2.txt, profiles/r02_axis_autotune.txt), so the first plan of
+// a CLASS of large streaming geometries on a device times the shapes that ever win -- output rows per workgroup,
+// nontemporal or cached loads -- on scratch images larger than the Infinity Cache and keeps the fastest; later plans of
+// the class (same device, same rows per footprint, same row sharing, same width class) take the result from a cache.
+// Bounds: plain fp32 images, footprints of >= 4 source rows, un-transposed quadrants, whole image; scratch of at most
+// ~1.25 GiB of source copies plus their outputs (images too large for that take the class's cached shape or the built-in
+// one); a private stream; about 10 ms.  AAI_AXIS_AUTOTUNE=0 disables it.  (Documented in include/aai.h at aai_prepare.)
+struct TuneKey {
+    int device, rowSpan, rowsShared, widthClass;
+    bool operator<(const TuneKey &o) const
+    {
+        return std::tie(device, rowSpan, rowsShared, widthClass) < std::tie(o.device, o.rowSpan, o.rowsShared, o.widthClass);
+    }
+};
+struct TuneShape { int rows, nt, swap; };
+static std::mutex g_tuneMutex;
+static std::map<TuneKey, TuneShape> &tune_cache()
+{
+    static std::map<TuneKey, TuneShape> *m = new std::map<TuneKey, TuneShape>();
+    return *m;
+}
+
+static void tune_axis_plan(Plan &p, int channels, int band0, hipStream_t stream)
 {
     static const bool enabled = [] { const char *e = getenv("AAI_AXIS_AUTOTUNE"); return !(e && atoi(e) == 0); }();
     const aai::AxisTables &t = p.tabs;
@@ -134,26 +169,41 @@ static void tune_axis_plan(Plan &p, int channels, int band0)
     if (!enabled || channels != 1 || band0 >= 0 || t.wide || t.transposed || t.maxRowSpan < 4 || t.maxOutputsPerStrip > 64 ||
         srcBytes < ((size_t)64 << 20) || !dstBytes)
         return;
-    const int images = (int)std::min<size_t>(8, std::max<size_t>(2, (((size_t)1 << 30) + srcBytes - 1) / srcBytes));
+    int widthClass = 0;
+    while ((g.W >> widthClass) > 1) ++widthClass;
+    const TuneKey key{p.device, std::min(t.maxRowSpan, 64), t.rowsShared ? 1 : 0, widthClass};
+    {
+        std::lock_guard<std::mutex> lock(g_tuneMutex);
+        auto it = tune_cache().find(key);
+        if (it != tune_cache().end()) {
+            p.tuneRows = it->second.rows; p.tuneNt = it->second.nt; p.tuneSwap = it->second.swap; p.tuneSource = 2;
+            return;
+        }
+    }
+    constexpr size_t kScratchCap = (size_t)5 << 28;           // 1.25 GiB of source copies
+    if (2 * srcBytes > kScratchCap) return;                   // too large to measure within the cap: built-in shape
+    // at least two images and at least 512 MiB of source per launch: twice the 256 MiB Infinity Cache, so every launch streams
+    // from HBM (1 GiB, as bench.py uses, measured the same shapes; half the scratch halves the cost of this measurement)
+    const int images = (int)std::min<size_t>(8, std::max<size_t>(2, std::min((((size_t)1 << 29) + srcBytes - 1) / srcBytes, kScratchCap / srcBytes)));
     float *src = nullptr, *dst = nullptr;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     bool ok = hipMalloc((void **)&src, srcBytes * images) == hipSuccess && hipMalloc((void **)&dst, dstBytes * images) == hipSuccess &&
               hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess;
     for (int b = 0; b < images && ok; ++b)         // realistic data: the memory system's speed depends on what it moves
-        ok = aai::launch_synth(src + (size_t)b * g.W * g.H, g.W, g.H, g.W, (uint64_t)b + 1, nullptr) == hipSuccess;
+        ok = aai::launch_synth(src + (size_t)b * g.W * g.H, g.W, g.H, g.W, (uint64_t)b + 1, stream) == hipSuccess;
     struct Shape { int rows, nt, swap; float ms; };
     Shape shapes[] = {{1, 1, 0, 0.f}, {2, 1, 0, 0.f}, {1, 0, 0, 0.f}, {2, 0, 0, 0.f}, {4, 1, 0, 0.f}};
     const aai::ImageView sv{g.W, (int64_t)g.W * g.H}, dv{g.dW, (int64_t)g.dW * g.dH};
-    // the shapes take turns, three rounds, two launches per turn; each keeps its fastest turn
-    for (int round = 0; round < 4 && ok; ++round)
+    // the shapes take turns, two rounds after a warm-up round, two launches per turn; each keeps its faster turn
+    for (int round = 0; round < 3 && ok; ++round)
         for (Shape &sh : shapes) {
             p.tuneRows = sh.rows; p.tuneNt = sh.nt; p.tuneSwap = sh.swap;
             const aai::AxisLaunch a = make_axis_launch(p, 1, g.dW);
             float ms = 0.f;
-            ok = ok && hipEventRecord(e0, nullptr) == hipSuccess &&
-                 aai::launch_axis(a, src, aai::SRC_F32, sv, dst, dv, images, nullptr, nullptr) == hipSuccess &&
-                 aai::launch_axis(a, src, aai::SRC_F32, sv, dst, dv, images, nullptr, nullptr) == hipSuccess &&
-                 hipEventRecord(e1, nullptr) == hipSuccess && hipEventSynchronize(e1) == hipSuccess && hipEventElapsedTime(&ms, e0, e1) == hipSuccess;
+            ok = ok && hipEventRecord(e0, stream) == hipSuccess &&
+                 aai::launch_axis(a, src, aai::SRC_F32, sv, dst, dv, images, stream, nullptr) == hipSuccess &&
+                 aai::launch_axis(a, src, aai::SRC_F32, sv, dst, dv, images, stream, nullptr) == hipSuccess &&
+                 hipEventRecord(e1, stream) == hipSuccess && hipEventSynchronize(e1) == hipSuccess && hipEventElapsedTime(&ms, e0, e1) == hipSuccess;
             if (ok && round > 0 && (sh.ms == 0.f || ms < sh.ms)) sh.ms = ms;       // round 0 warms up
         }
     p.tuneRows = 0; p.tuneNt = 0; p.tuneSwap = 0;
@@ -161,7 +211,9 @@ static void tune_axis_plan(Plan &p, int channels, int band0)
         const Shape *best = &shapes[0];
         for (const Shape &sh : shapes)
             if (sh.ms < best->ms * 0.99f) best = &sh;          // a later shape must win by more than the timing noise
-        p.tuneRows = best->rows; p.tuneNt = best->nt; p.tuneSwap = best->swap;
+        p.tuneRows = best->rows; p.tuneNt = best->nt; p.tuneSwap = best->swap; p.tuneSource = 1;
+        std::lock_guard<std::mutex> lock(g_tuneMutex);
+        tune_cache()[key] = TuneShape{best->rows, best->nt, best->swap};
     }
     (void)hipGetLastError();
     if (e0) (void)hipEventDestroy(e0);
@@ -170,46 +222,25 @@ static void tune_axis_plan(Plan &p, int channels, int band0)
     if (dst) (void)hipFree(dst);
 }
 
-// Finds or builds the plan for (request, current device).  Returns a pointer valid until evicted; callers
-// hold g_planMutex for the duration of the launch (launches only enqueue, so this is short).
-int rot_form(const aai_request &rq, const aai::Geometry &g, int channels, int srcType, int64_t srcStride)
+// Everything a fresh plan needs from the device; the caller holds p.build, not the cache's lock.
+static int build_plan(Plan &p)
 {
-    if (pick_kernel(rq, g) != AAI_KERNEL_ROTATED) return aai::ROT_FORM_QUAD;
-    aai::RotLaunch r = aai::make_rot_launch(g, rq.mode, rq.policy);
-    r.chan = channels;
-    return aai::cell_can_serve(r, srcType, aai::ImageView{srcStride, 0}) ? aai::ROT_FORM_CELL : aai::ROT_FORM_QUAD;
-}
-
-int get_plan(const aai_request &rq, int band0, int band1, int channels, int form, Plan **out)
-{
-    int dev = -1;
-    AAI_HIP(hipGetDevice(&dev));
-    auto cached = [&](int b0, int b1, int ch) -> bool {
-        for (auto it = g_plans.begin(); it != g_plans.end(); ++it)
-            if (it->device == dev && it->band0 == b0 && it->band1 == b1 && it->channels == ch && it->form == form && same_request(it->key, rq)) {
-                g_plans.splice(g_plans.begin(), g_plans, it);
-                *out = &g_plans.front();
-                return true;
-            }
-        return false;
+    const aai_request &rq = p.key;
+    const aai::Geometry &g = p.g;
+    const int band0 = p.band0, band1 = p.band1, channels = p.channels, form = p.form;
+    // AAI_TRACE_PLAN=1: stage timings of every plan build on stderr (tools/plan_time.py)
+    static const bool trace = [] { const char *v = getenv("AAI_TRACE_PLAN"); return v && atoi(v) != 0; }();
+    auto tick = std::chrono::steady_clock::now();
+    auto stage = [&](const char *what) {
+        if (!trace) return;
+        const auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "[aai plan] %-28s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(now - tick).count());
+        tick = now;
     };
-    aai::Geometry g;
-    std::string msg;
-    int rc = aai::make_geometry(rq, g, msg);
-    if (rc != AAI_OK) return fail(rc, msg);
-    if (pick_kernel(rq, g) != AAI_KERNEL_ROTATED) form = aai::ROT_FORM_QUAD;
-    if (cached(band0, band1, channels)) return AAI_OK;
-    if (pick_kernel(rq, g) != AAI_KERNEL_AXIS && (band0 >= 0 || channels != 1)) {
-        // Only K1's tables depend on the row band.  The per-pixel kernels take the band as launch parameters and their
-        // one-off scans cover the whole image, so every band and every channel count of a rotated request shares one plan.
-        band0 = band1 = -1; channels = 1;
-        if (cached(band0, band1, channels)) return AAI_OK;
-    }
-
-    g_plans.emplace_front();
-    Plan &p = g_plans.front();
-    p.key = rq; p.band0 = band0; p.band1 = band1; p.channels = channels; p.form = form; p.device = dev; p.g = g; p.kernel = pick_kernel(rq, g);
-    p.srcRow0 = 0; p.srcRow1 = g.H;
+    hipStream_t bs = nullptr;                                        // a private stream: never the caller's, never the NULL stream
+    AAI_HIP(hipStreamCreateWithFlags(&bs, hipStreamNonBlocking));
+    stage("private stream");
+    struct StreamGuard { hipStream_t s; ~StreamGuard() { if (s) { (void)hipStreamSynchronize(s); (void)hipStreamDestroy(s); } } } guard{bs};
     if (p.kernel == AAI_KERNEL_AXIS) {
         aai::build_axis_tables(g, rq.mode, p.tabs, channels);
         if (band0 >= 0) aai::restrict_axis_tables_to_band(g, p.tabs, band0, band1, p.srcRow0, p.srcRow1, axis_band_margin(rq));
@@ -218,22 +249,45 @@ int get_plan(const aai_request &rq, int band0, int band1, int channels, int form
             if (!bytes) { *d = nullptr; return hipSuccess; }
             hipError_t e = hipMalloc(d, bytes);
             if (e != hipSuccess) return e;
-            return hipMemcpy(*d, h, bytes, hipMemcpyHostToDevice);
+            return hipMemcpyAsync(*d, h, bytes, hipMemcpyHostToDevice, bs);      // (p.tabs outlives the copy: synchronised below)
         };
         hipError_t e = upload(p.tabs.lane.data(), p.tabs.lane.size() * sizeof(aai::AxisEntry), (void **)&p.dLane);
         if (e == hipSuccess) e = upload(p.tabs.row.data(), p.tabs.row.size() * sizeof(aai::AxisEntry), (void **)&p.dRow);
         if (e == hipSuccess) e = upload(p.tabs.strips.data(), p.tabs.strips.size() * sizeof(aai::AxisStrip), (void **)&p.dStrips);
-        if (e != hipSuccess) { g_plans.pop_front(); return hip_fail(e, "uploading axis tables"); }
-        if (p.kernel == AAI_KERNEL_AXIS) tune_axis_plan(p, channels, band0);
+        if (e == hipSuccess) e = hipStreamSynchronize(bs);
+        if (e != hipSuccess) return hip_fail(e, "uploading axis tables");
+        stage("axis tables");
+        if (p.kernel == AAI_KERNEL_AXIS) tune_axis_plan(p, channels, band0, bs);
+        stage("launch-shape measurement");
     }
     const bool axisKernel = p.kernel == AAI_KERNEL_AXIS || p.kernel == AAI_KERNEL_AXIS_WIDE;
     // K1's separable model against the reference's classifier (aai_axis_verify.hpp).  Both policies: they differ in the
     // corner-triangle rule of a slanted left/right edge only, which does not exist at multiples of 90 degrees.
     const bool verifyAxis = axisKernel && axis_band_margin(rq) != 0;
     if (p.kernel == AAI_KERNEL_ROTATED || p.kernel == AAI_KERNEL_FAST || verifyAxis) {
-        // one-off scans of this geometry (rotated: aai_knife_scan_kernel, and aai_quad_scan_kernel where the fp32 quad
-        // kernels serve it; axis-aligned: aai_axis_verify_kernel); keeps the list of flagged pixels only if there are any
         const aai::RotLaunch r = aai::make_rot_launch(g, rq.mode, rq.policy);
+        // (AAI_MAX_LISTED_PIXELS: test hook, lowers the threshold so that small geometries exercise the dense form)
+        static const unsigned maxListed = [] { const char *v = getenv("AAI_MAX_LISTED_PIXELS"); return v ? (unsigned)strtoul(v, nullptr, 10) : kMaxListedPixels; }();
+        static const bool classVerify = [] { const char *v = getenv("AAI_AXIS_CLASS_VERIFY"); return !(v && atoi(v) == 0); }();
+        std::vector<std::pair<int, int>> hostPixels;
+        bool hostDense = false;
+        if (verifyAxis && classVerify && aai::axis_verify_by_class(r, hostPixels, hostDense, maxListed)) {
+            std::vector<uint2> hostList(hostPixels.size());
+            for (size_t i = 0; i < hostPixels.size(); ++i) hostList[i] = make_uint2((unsigned)hostPixels[i].first, (unsigned)hostPixels[i].second);
+            // exact arithmetic: one representative per (column class, row class) checked on the host
+            p.dense = hostDense;
+            p.flaggedPixels = (unsigned)hostList.size();
+            if (!hostList.empty()) {
+                hipError_t e = hipMalloc(&p.dList, hostList.size() * sizeof(uint2));
+                if (e == hipSuccess) e = hipMemcpyAsync(p.dList, hostList.data(), hostList.size() * sizeof(uint2), hipMemcpyHostToDevice, bs);
+                if (e == hipSuccess) e = hipStreamSynchronize(bs);
+                if (e != hipSuccess) return hip_fail(e, "axis model scan");
+            }
+            stage("axis model check (host)");
+            return AAI_OK;
+        }
+        // one-off scans of this geometry (rotated: aai_knife_scan_kernel, and the scan of the fp32 formulation that serves
+        // it; axis-aligned: aai_axis_verify_kernel); keeps the list of flagged pixels only if there are any
         const size_t waves = aai::rotated_flag_words(r);
         unsigned long long *dMasks = nullptr;
         unsigned *dCount = nullptr;
@@ -242,22 +296,23 @@ int get_plan(const aai_request &rq, int band0, int band1, int channels, int form
         if (waves) {
             e = hipMalloc((void **)&dMasks, waves * sizeof(unsigned long long));
             if (e == hipSuccess) e = hipMalloc((void **)&dCount, sizeof(unsigned));
-            if (e == hipSuccess) e = hipMemset(dCount, 0, sizeof(unsigned));
-            if (e == hipSuccess) e = verifyAxis ? aai::launch_axis_verify(r, dMasks, dCount, nullptr) : aai::launch_knife_scan(r, dMasks, dCount, nullptr);
-            if (e == hipSuccess && r.quad) e = form == aai::ROT_FORM_CELL ? aai::launch_cell_scan(r, dMasks, dCount, nullptr) : aai::launch_quad_scan(r, dMasks, dCount, nullptr);
-            if (e == hipSuccess) e = hipMemcpy(&count, dCount, sizeof(unsigned), hipMemcpyDeviceToHost);
-            // (AAI_MAX_LISTED_PIXELS: test hook, lowers the threshold so that small geometries exercise the dense form)
-            static const unsigned maxListed = [] { const char *v = getenv("AAI_MAX_LISTED_PIXELS"); return v ? (unsigned)strtoul(v, nullptr, 10) : kMaxListedPixels; }();
+            if (e == hipSuccess) e = hipMemsetAsync(dCount, 0, sizeof(unsigned), bs);
+            if (e == hipSuccess) e = verifyAxis ? aai::launch_axis_verify(r, dMasks, dCount, bs) : aai::launch_knife_scan(r, dMasks, dCount, bs);
+            if (e == hipSuccess && r.quad) e = form == aai::ROT_FORM_CELL ? aai::launch_cell_scan(r, dMasks, dCount, bs) : aai::launch_quad_scan(r, dMasks, dCount, bs);
+            if (e == hipSuccess) e = hipMemcpyAsync(&count, dCount, sizeof(unsigned), hipMemcpyDeviceToHost, bs);
+            if (e == hipSuccess) e = hipStreamSynchronize(bs);
+            stage("scans");
             if (e == hipSuccess && count > maxListed) { p.dense = true; count = 0; }
             if (e == hipSuccess && count) {
                 e = hipMalloc(&p.dList, (size_t)count * 2 * sizeof(unsigned));
-                if (e == hipSuccess) e = hipMemset(dCount, 0, sizeof(unsigned));
-                if (e == hipSuccess) e = aai::launch_flag_list(dMasks, waves, (unsigned)((g.dW + 15) / 16), p.dList, dCount, count, nullptr);
-                if (e == hipSuccess) e = hipDeviceSynchronize();
+                if (e == hipSuccess) e = hipMemsetAsync(dCount, 0, sizeof(unsigned), bs);
+                if (e == hipSuccess) e = aai::launch_flag_list(dMasks, waves, (unsigned)((g.dW + 15) / 16), p.dList, dCount, count, bs);
+                if (e == hipSuccess) e = hipStreamSynchronize(bs);
             }
             if (dCount) (void)hipFree(dCount);
+            stage("flag list");
             if (e == hipSuccess && count && r.quad) {
-                // keep the masks: the quad kernel skips the flagged pixels and the fix-up pass runs beside it
+                // keep the masks: the fp32 kernel skips the flagged pixels and the fix-up pass runs beside it
                 p.dMasks = dMasks;
                 dMasks = nullptr;
                 e = hipStreamCreateWithFlags(&p.side, hipStreamNonBlocking);
@@ -265,19 +320,100 @@ int get_plan(const aai_request &rq, int band0, int band1, int channels, int form
                 if (e == hipSuccess) e = hipEventCreateWithFlags(&p.join, hipEventDisableTiming);
             }
             if (dMasks) (void)hipFree(dMasks);
+            stage("side stream + events");
         }
-        if (e != hipSuccess) { g_plans.pop_front(); return hip_fail(e, verifyAxis ? "axis model scan" : "knife-edge scan"); }
+        if (e != hipSuccess) return hip_fail(e, verifyAxis ? "axis model scan" : "knife-edge scan");
         p.flaggedPixels = count;
     }
-    // the cache is sized per device: the least recently used plans of THIS device go first
-    size_t mine = 0;
-    for (const Plan &q : g_plans) mine += q.device == dev ? 1 : 0;
-    for (auto it = g_plans.end(); mine > kMaxPlans && it != g_plans.begin();) {
-        --it;
-        if (it->device == dev) { it = g_plans.erase(it); --mine; }
-    }
-    *out = &p;
     return AAI_OK;
+}
+
+int rot_form(const aai_request &rq, const aai::Geometry &g, int channels, int srcType, int64_t srcStride)
+{
+    if (pick_kernel(rq, g) != AAI_KERNEL_ROTATED) return aai::ROT_FORM_QUAD;
+    aai::RotLaunch r = aai::make_rot_launch(g, rq.mode, rq.policy);
+    r.chan = channels;
+    return aai::cell_can_serve(r, srcType, aai::ImageView{srcStride, 0}) ? aai::ROT_FORM_CELL : aai::ROT_FORM_QUAD;
+}
+
+int acquire_plan(const aai_request &rq, int band0, int band1, int channels, int form, PlanRef *out)
+{
+    int dev = -1;
+    AAI_HIP(hipGetDevice(&dev));
+    aai::Geometry g;
+    std::string msg;
+    int rc = aai::make_geometry(rq, g, msg);
+    if (rc != AAI_OK) return fail(rc, msg);
+    const int kernel = pick_kernel(rq, g);
+    if (kernel != AAI_KERNEL_ROTATED) form = aai::ROT_FORM_QUAD;
+    if (kernel != AAI_KERNEL_AXIS && (band0 >= 0 || channels != 1)) {
+        // Only K1's tables depend on the row band.  The per-pixel kernels take the band as launch parameters and their
+        // one-off scans cover the whole image, so every band and every channel count of a rotated request shares one plan.
+        band0 = band1 = -1; channels = 1;
+    }
+    PlanRef p;
+    {
+        std::lock_guard<std::mutex> lock(g_planMutex);
+        std::list<PlanRef> &plans = plan_cache();
+        for (auto it = plans.begin(); it != plans.end(); ++it) {
+            const Plan &q = **it;
+            if (q.device == dev && q.band0 == band0 && q.band1 == band1 && q.channels == channels && q.form == form && same_request(q.key, rq)) {
+                plans.splice(plans.begin(), plans, it);
+                p = plans.front();
+                break;
+            }
+        }
+        if (!p) {
+            p = std::make_shared<Plan>();
+            p->key = rq; p->band0 = band0; p->band1 = band1; p->channels = channels; p->form = form; p->device = dev; p->g = g; p->kernel = kernel;
+            p->srcRow0 = 0; p->srcRow1 = g.H;
+            plans.push_front(p);
+            // the cache is sized per device: the least recently used plans of THIS device go first (a plan somebody is still
+            // launching from lives on until its last reference is dropped)
+            size_t mine = 0;
+            for (const PlanRef &q : plans) mine += q->device == dev ? 1 : 0;
+            for (auto it = plans.end(); mine > kMaxPlans && it != plans.begin();) {
+                --it;
+                if ((*it)->device == dev && *it != p) { it = plans.erase(it); --mine; }
+            }
+        }
+    }
+    {
+        std::lock_guard<std::mutex> lock(p->build);
+        if (!p->built) {
+            const auto t0 = std::chrono::steady_clock::now();
+            p->buildRc = build_plan(*p);
+            p->buildMs = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+            p->buildError = p->buildRc == AAI_OK ? std::string() : g_lastError;
+            p->built = true;
+        }
+    }
+    if (p->buildRc != AAI_OK) {
+        std::lock_guard<std::mutex> lock(g_planMutex);
+        plan_cache().remove(p);               // a later call tries again
+        return fail(p->buildRc, p->buildError);
+    }
+    *out = p;
+    return AAI_OK;
+}
+
+std::string plan_description(const aai_request &rq, int channels)
+{
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess) return std::string();
+    std::lock_guard<std::mutex> lock(g_planMutex);
+    for (const PlanRef &q : plan_cache()) {
+        const Plan &p = *q;
+        const bool rotated = p.kernel != AAI_KERNEL_AXIS && p.kernel != AAI_KERNEL_AXIS_WIDE;
+        if (p.device == dev && p.band0 < 0 && (rotated || p.channels == channels) && p.built && same_request(p.key, rq)) {
+            char buf[256];
+            snprintf(buf, sizeof buf, "kernel=%d rows=%d nt=%d swap=%d tune=%s flagged=%u dense=%d form=%s build_ms=%.3f", p.kernel, p.tuneRows, p.tuneNt,
+                     p.tuneSwap, p.tuneSource == 1 ? "measured" : (p.tuneSource == 2 ? "cached" : "default"), p.flaggedPixels, p.dense ? 1 : 0,
+                     p.kernel == AAI_KERNEL_ROTATED ? (p.form == aai::ROT_FORM_CELL ? "cell" : "quad") : "-", p.buildMs);
+            return std::string(buf);
+        }
+    }
+    return std::string();
 }
 
 constexpr int kMaxGridZ = 65535;
@@ -292,17 +428,18 @@ static const void *src_at(const void *base, int srcType, int64_t elements)
 int enqueue(const aai_request &rq, int batch, const void *dSrc, int srcType, int64_t srcStride, int64_t srcImageStride,
             float *dDst, int64_t dstStride, int64_t dstImageStride, hipStream_t stream, int band0, int band1, int channels)
 {
-    std::lock_guard<std::mutex> lock(g_planMutex);
-    Plan *p = nullptr;
+    PlanRef p;
     int rc;
     {
         aai::Geometry g0;
         std::string msg;
         rc = aai::make_geometry(rq, g0, msg);
         if (rc != AAI_OK) return fail(rc, msg);
-        rc = get_plan(rq, band0, band1, channels, rot_form(rq, g0, channels, srcType, srcStride), &p);
+        rc = acquire_plan(rq, band0, band1, channels, rot_form(rq, g0, channels, srcType, srcStride), &p);
     }
     if (rc != AAI_OK) return rc;
+    // launches only enqueue; the plan's side stream and fork / join events are shared by its callers, hence the plan's lock
+    std::lock_guard<std::mutex> lock(p->launch);
     const aai::Geometry &g = p->g;
     // strides are in elements; an interleaved pixel takes `channels` of them
     if (srcStride < (int64_t)g.W * channels) return fail(AAI_ERR_BAD_ARGUMENT, "Source stride smaller than the image width.");

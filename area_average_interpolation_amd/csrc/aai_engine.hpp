@@ -4,6 +4,7 @@
 
 #include <cstdint>
 #include <list>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -38,17 +39,26 @@ struct Plan {
     aai::AxisTables tabs;
     aai::AxisEntry *dLane = nullptr, *dRow = nullptr;
     aai::AxisStrip *dStrips = nullptr;
-    int tuneRows = 0, tuneNt = 0, tuneSwap = 0;      // K1 launch shape measured on this device (0 rows = built-in default)
+    int tuneRows = 0, tuneNt = 0, tuneSwap = 0;      // K1 launch shape for this device (0 rows = built-in default)
+    int tuneSource = 0;                               // 0 = built-in default, 1 = measured for this plan, 2 = taken from the per-class cache
     // K2/K3: the dst pixels flagged by the one-off scans (knife edges of the reference's classifier; decisions the fp32
-    // quad kernel leaves to double precision) as a list of (dx, dy) the fix-up pass runs over; `dense` when there are
+    // kernels leave to double precision) as a list of (dx, dy) the fix-up pass runs over; `dense` when there are
     // so many that the whole image takes that pass instead
     void *dList = nullptr;
     unsigned flaggedPixels = 0;
     bool dense = false;
-    // quad kernel: the lane masks of the flagged pixels (it skips them) and the side stream the fix-up pass runs on
+    // fp32 rotated kernels: the lane masks of the flagged pixels (they skip them) and the side stream the fix-up pass runs on
     unsigned long long *dMasks = nullptr;
     hipStream_t side = nullptr;
     hipEvent_t fork = nullptr, join = nullptr;
+    double buildMs = 0.0;            // wall clock of build_plan (tables, scans, launch-shape measurement)
+    // Built once, by whoever gets here first, under `build` -- NOT under the cache's lock: other requests, other devices
+    // and other threads are not held up by this plan's scans or launch-shape measurement.  `launch` serialises the use of
+    // the plan's side stream and fork / join events between caller streams.
+    std::mutex build, launch;
+    bool built = false;
+    int buildRc = AAI_OK;
+    std::string buildError;
     ~Plan()
     {
         if (side) { (void)hipStreamSynchronize(side); (void)hipStreamDestroy(side); }
@@ -61,10 +71,13 @@ struct Plan {
         if (dStrips) (void)hipFree(dStrips);
     }
 };
+typedef std::shared_ptr<Plan> PlanRef;
 
-
-extern std::mutex g_planMutex;          // held while a plan is looked up, built and launched from (launches only enqueue)
-extern std::list<Plan> g_plans;         // most recently used first
+// The cache (most recently used first) lives on the heap and is never destroyed: a static destructor would call into HIP
+// after the runtime's own teardown.  aai_shutdown() empties it while the runtime is alive.
+extern std::mutex g_planMutex;          // guards the cache's structure only; never held across device work
+std::list<PlanRef> &plan_cache();
+void drop_plans();
 
 bool same_request(const aai_request &a, const aai_request &b);
 int check_request(const aai_request *rq);
@@ -74,9 +87,12 @@ int resolved_kernel(const aai_request &rq, const Geometry &g);      // pick_kern
 void fill_layout(const Geometry &g, int kernel, aai_layout *out);
 int require_device();
 
-// Finds or builds the plan for (request, current device); the caller holds g_planMutex.
+// Finds the plan for (request, current device) or inserts a fresh one, then builds it if nobody has (blocking: table
+// uploads, the one-off scans, K1's launch-shape measurement -- on a private stream).
 // form: aai::RotForm of a rotated request's launch (rot_form below); ignored by the other kernels
-int get_plan(const aai_request &rq, int band0, int band1, int channels, int form, Plan **out);
+int acquire_plan(const aai_request &rq, int band0, int band1, int channels, int form, PlanRef *out);
+// "kernel=K rows=R nt=N swap=S tune=T flagged=F dense=D form=M build_ms=B" of the cached whole-image plan ("" when there is none)
+std::string plan_description(const aai_request &rq, int channels);
 // which fp32 formulation serves a launch of this request: the cell formulation takes plain images below 4 GiB in area mode
 int rot_form(const aai_request &rq, const Geometry &g, int channels, int srcType, int64_t srcStride);
 

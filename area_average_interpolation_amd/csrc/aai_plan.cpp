@@ -4,6 +4,7 @@
 #include "aai_rot_quad.hpp"
 #include "aai_rot_cell.hpp"
 #include "aai_axis_verify.hpp"
+#include "aai_axis_verify.hpp"
 
 #include <algorithm>
 #include <cfloat>
@@ -461,5 +462,74 @@ void restrict_axis_tables_to_band(const Geometry &g, AxisTables &t, int row0, in
     srcRow0 = lo; srcRow1 = hi + 1;
     finalize_axis_tables(g, t);
 }
+
+// K1's separable model against the reference's classifier, on the HOST, for geometries whose arithmetic is exact.
+// aai_axis_verify_kernel asks, for every dst pixel with a knife edge, whether the strict replay of the reference's
+// classifier and the product of the two clipped extents agree pair by pair -- 6.6 ms at config 2, where EVERY pixel has
+// a knife edge (every edge on a pixel boundary).  But at reduced angle 0 that answer depends on dst pixel (dx, dy) only
+// through the position of column dx and of row dy RELATIVE to the source lattice and through whether their windows
+// are clipped by the image: columns whose centre has the same fractional part and the same clipping are
+// indistinguishable, as long as every coordinate is computed without rounding.  That holds when the side is a multiple
+// of 1/256 and the offsets are multiples of 2^-20 of moderate size (integer and simple ratios with isocenters on
+// half / quarter pixels: configs 1, 2, 4): then one representative per (column class, row class) is checked here -- a
+// handful of evaluations instead of dW x dH -- and the flagged pixels are the products of the classes that differ.
+// Returns false when the geometry does not qualify (the device scan runs instead).
+static bool dyadic(double v, double scale, double limit)
+{
+    const double w = v * scale;
+    return std::fabs(v) < limit && w == std::floor(w);
+}
+bool axis_verify_by_class(const RotLaunch &r, std::vector<std::pair<int, int>> &flagged, bool &dense, unsigned maxListed)
+{
+    const double two20 = 1048576.0;
+    if (!(dyadic(r.side, 256.0, 256.0) && dyadic(r.fracX, two20, 2.0) && dyadic(r.fracY, two20, 2.0) && dyadic(r.isoX, two20, two20) &&
+          dyadic(r.isoY, two20, two20) && dyadic(r.offX, two20, two20) && dyadic(r.offY, two20, two20)))
+        return false;
+    if (r.dW > 65536 || r.dH > 65536) return false;           // (index + offset) x side stays within 53 bits
+    const double hb = r.h * (r.c + r.s);
+    struct Cls { double frac; int clipLo, clipHi, last; int rep, count; };
+    auto classes = [&](int n, int m, bool alongX, std::vector<Cls> &out, std::vector<int> &of) {
+        of.resize(n);
+        for (int i = 0; i < n; ++i) {
+            double px, py;
+            pixel_centre(r, alongX ? i : 0, alongX ? 0 : i, px, py);
+            const double pc = alongX ? px : py;
+            const double f = pc - std::floor(pc);
+            // the window [pc - hb, pc + hb] against the lattice [0, m - 1]: how far it is clipped (0 = not at all)
+            const int lo = (int)std::floor(pc - hb + 0.5 - AAI_KNIFE_GUARD), hi = (int)std::ceil(pc + hb - 0.5 + AAI_KNIFE_GUARD);
+            const int clipLo = lo < 0 ? -lo : 0, clipHi = hi > m - 1 ? hi - (m - 1) : 0;
+            int k = 0;
+            for (; k < (int)out.size(); ++k)
+                if (out[k].frac == f && out[k].clipLo == clipLo && out[k].clipHi == clipHi && out[k].last == (i == n - 1)) break;
+            if (k == (int)out.size()) {
+                if (out.size() >= 64) return false;
+                out.push_back(Cls{f, clipLo, clipHi, i == n - 1 ? 1 : 0, i, 0});      // (the last column / row has its own edge formula)
+            }
+            ++out[k].count;
+            of[i] = k;
+        }
+        return true;
+    };
+    std::vector<Cls> cx, cy;
+    std::vector<int> ofx, ofy;
+    if (!classes(r.dW, r.mW, true, cx, ofx) || !classes(r.dH, r.mH, false, cy, ofy)) return false;
+    std::vector<char> differs(cx.size() * cy.size(), 0);
+    uint64_t total = 0;
+    for (size_t j = 0; j < cy.size(); ++j)
+        for (size_t i = 0; i < cx.size(); ++i) {
+            const bool d = r.mode == AAI_MODE_FAST ? axis_pixel_differs_fast(r, cx[i].rep, cy[j].rep) : axis_pixel_differs(r, cx[i].rep, cy[j].rep);
+            differs[j * cx.size() + i] = d ? 1 : 0;
+            if (d) total += (uint64_t)cx[i].count * cy[j].count;
+        }
+    flagged.clear();
+    dense = total > maxListed;
+    if (dense || !total) return true;
+    flagged.reserve((size_t)total);
+    for (int y = 0; y < r.dH; ++y)
+        for (int x = 0; x < r.dW; ++x)
+            if (differs[(size_t)ofy[y] * cx.size() + ofx[x]]) flagged.emplace_back(x, y);
+    return true;
+}
+
 
 }  // namespace aai

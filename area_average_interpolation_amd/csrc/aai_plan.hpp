@@ -9,6 +9,7 @@
 
 #include <cstdint>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "../../include/aai.h"
@@ -111,6 +112,11 @@ struct AxisTables {
 // mode: AAI_MODE_AREA (overlap lengths) or AAI_MODE_FAST (centre counts).  Only for g.axisAligned.
 void build_axis_tables(const Geometry &g, int mode, AxisTables &t, int channels = 1);
 void restrict_axis_tables_to_band(const Geometry &g, AxisTables &t, int row0, int row1, int &srcRow0, int &srcRow1, int extraRows = 0);
+
+// K1's separable model checked on the host, one representative per (column class, row class), where the geometry's
+// arithmetic is exact (aai_plan.cpp); false = does not qualify, run the device scan.  flagged: (dx, dy) of the dst pixels
+// the fix-up pass must recompute; dense: more than maxListed of them.
+bool axis_verify_by_class(const RotLaunch &r, std::vector<std::pair<int, int>> &flagged, bool &dense, unsigned maxListed);
 
 // Source rows [srcRow0, srcRow1) that dst rows [row0,row1) of a rotated-lattice request can touch (conservative).
 void rotated_band_source_rows(const Geometry &g, int row0, int row1, bool sampler, int &srcRow0, int &srcRow1);

@@ -498,7 +498,14 @@ static hipError_t launch_rotated_typed(const RotLaunch &r, const QuadMap &m, con
     // pass on the same stream -- or, when the production kernel is the quad kernel and skips those pixels, beside it on
     // the plan's side stream: fork before, join after.
     const bool fixup = !sampler && flags.count != 0;
-    const bool beside = fixup && flags.masks && flags.side && (quad_serves(r, srcType, sv) || cell_serves(r, srcType, sv, flags));
+    bool beside = fixup && flags.masks && flags.side && (quad_serves(r, srcType, sv) || cell_serves(r, srcType, sv, flags));
+    if (beside) {
+        // a caller's stream that is being captured into a graph must not pull the plan's shared side stream into the
+        // capture (another thread may use it meanwhile): the fix-up pass then follows the production pass in-stream
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(stream, &cap) != hipSuccess) (void)hipGetLastError();
+        if (cap != hipStreamCaptureStatusNone) beside = false;
+    }
     hipError_t e = hipSuccess;
     if (beside) {
         e = hipEventRecord(flags.fork, stream);
@@ -506,18 +513,22 @@ static hipError_t launch_rotated_typed(const RotLaunch &r, const QuadMap &m, con
         if (e != hipSuccess) return e;
         launch_rotated_fixup(r, batch, src, srcType, sv, dst, dv, static_cast<const uint2 *>(flags.list), flags.count, flags.side);
         e = hipEventRecord(flags.join, flags.side);
-        if (e != hipSuccess) return e;
+        if (e != hipSuccess) return e;           // (nothing was enqueued on the side stream after the fork that the caller could race with)
     }
-    for (int y0 = r.dyBase; y0 < r.dyEnd; y0 += maxRows) {
+    for (int y0 = r.dyBase; y0 < r.dyEnd && e == hipSuccess; y0 += maxRows) {
         RotLaunch rb = r;
         rb.dyBase = y0;
         rb.dyEnd = r.dyEnd - y0 > maxRows ? y0 + maxRows : r.dyEnd;
         RotFlags fb = flags;
         if (!beside) fb.masks = nullptr;
         e = launch_rotated_band(rb, m, src, srcType, sv, dst + (int64_t)(y0 - r.dyBase) * dv.rowStride, dv, batch, fb, stream, kernelName);
-        if (e != hipSuccess) return e;
     }
-    if (beside) return hipStreamWaitEvent(stream, flags.join, 0);
+    if (beside) {
+        // whatever happened above, the side stream's writes to dst are ordered before anything the caller enqueues next
+        const hipError_t j = hipStreamWaitEvent(stream, flags.join, 0);
+        return e != hipSuccess ? e : j;
+    }
+    if (e != hipSuccess) return e;
     if (fixup) launch_rotated_fixup(r, batch, src, srcType, sv, dst, dv, static_cast<const uint2 *>(flags.list), flags.count, stream);
     return hipGetLastError();
 }

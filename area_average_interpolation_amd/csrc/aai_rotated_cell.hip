@@ -96,7 +96,7 @@ __global__ __launch_bounds__(kQuadBlock, cell_min_waves(WIN)) void aai_cell_kern
 // lane masks of the 16 x 16 tiling (on top of the knife-edge scan's bits) and counts the newly set bits in counter[0].
 template <int WIN, bool HP>
 __global__ __launch_bounds__(kQuadBlock) void aai_cell_scan_kernel(RotLaunch r, QuadConsts<float> q, CellConsts<float> z, unsigned long long *__restrict__ laneMasks,
-                                                                  unsigned *__restrict__ counter, int tilesX, int rowsPerStrip)
+                                                                  unsigned *__restrict__ counter, int tilesX, int rowsPerStrip, int band0)
 {
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -104,7 +104,7 @@ __global__ __launch_bounds__(kQuadBlock) void aai_cell_scan_kernel(RotLaunch r, 
     const int x0 = (blockIdx.x * (kQuadBlock / 64) + wave) * kCellCols;
     if (x0 >= r.dW) return;
     const int cx = x0 + lane;
-    const int y0 = blockIdx.y * rowsPerStrip;
+    const int y0 = (band0 + blockIdx.y) * rowsPerStrip;
     const int y1 = min(y0 + rowsPerStrip, r.dH);
     const bool stores = lane < kCellCols && cx < r.dW;
     const CellColumn col = cell_column(r, z, cx);
@@ -217,16 +217,19 @@ hipError_t launch_cell_scan(const RotLaunch &r, unsigned long long *laneMasks, u
     const int strips = (r.dW + kCellCols - 1) / kCellCols;
     const int tilesX = (r.dW + 15) / 16;
     const int bands = (r.dH + rows - 1) / rows;
-    if (bands > 65535) return hipErrorInvalidValue;            // (over a million dst rows: such plans keep the quad scan)
-    const dim3 grid((strips + 3) / 4, bands, 1);
-#define AAI_CELL_SCAN(W)                                                                                                                           \
-    case W:                                                                                                                                        \
-        if (q.hiPrec) hipLaunchKernelGGL((aai_cell_scan_kernel<W, true>), grid, dim3(kQuadBlock), 0, stream, r, q, z, laneMasks, counter, tilesX, rows); \
-        else hipLaunchKernelGGL((aai_cell_scan_kernel<W, false>), grid, dim3(kQuadBlock), 0, stream, r, q, z, laneMasks, counter, tilesX, rows);    \
+    for (int b0 = 0; b0 < bands; b0 += 65535) {                // grid.y carries at most 65535 bands
+        const dim3 grid((strips + 3) / 4, bands - b0 < 65535 ? bands - b0 : 65535, 1);
+#define AAI_CELL_SCAN(W)                                                                                                                               \
+    case W:                                                                                                                                            \
+        if (q.hiPrec) hipLaunchKernelGGL((aai_cell_scan_kernel<W, true>), grid, dim3(kQuadBlock), 0, stream, r, q, z, laneMasks, counter, tilesX, rows, b0); \
+        else hipLaunchKernelGGL((aai_cell_scan_kernel<W, false>), grid, dim3(kQuadBlock), 0, stream, r, q, z, laneMasks, counter, tilesX, rows, b0);    \
         break;
-    switch (z.win) {
-        AAI_CELL_SCAN(2) AAI_CELL_SCAN(3) AAI_CELL_SCAN(4) AAI_CELL_SCAN(5) AAI_CELL_SCAN(6) AAI_CELL_SCAN(7) AAI_CELL_SCAN(8)
-    default: return hipErrorInvalidValue;
+        switch (z.win) {
+            AAI_CELL_SCAN(2) AAI_CELL_SCAN(3) AAI_CELL_SCAN(4) AAI_CELL_SCAN(5) AAI_CELL_SCAN(6) AAI_CELL_SCAN(7) AAI_CELL_SCAN(8)
+        default: return hipErrorInvalidValue;
+        }
+        const hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return e;
     }
 #undef AAI_CELL_SCAN
     return hipGetLastError();

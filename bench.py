@@ -9,9 +9,17 @@ four times the 256 MiB Infinity Cache), so every step streams its source from HB
 
 Timing: W warm-up steps, then the block of K steps is run `repeats` times back to back between two fences
 (barrier + device synchronize); `repeats` is chosen from the warm-up so that the timed GPU leg lasts about
-`--min-seconds` (an outside telemetry probe can then see it); ms_per_step = elapsed / (repeats * K), taken as the
-MAX over ranks.  Every step is also bracketed by HIP events on the launch stream: their mean is the kernel time
-behind `roofline`, their min / median / max are reported as `step_ms`.
+`--min-seconds` (6 s by default: a 5-second telemetry sampler then sees the GPU busy); ms_per_step = elapsed /
+(repeats * K), taken as the MAX over ranks.  Nothing but the launches runs inside that wall-clock window: ONE pair of
+HIP events on the launch stream brackets the whole timed region, and its elapsed time / launches is the average launch
+duration behind `roofline` (rocprofv3 --kernel-trace of the same command agrees: profiles/).  Per-step min / median /
+max (`timed.step_ms`) come from a separate pass of at most 512 steps with an event pair each.
+
+Default invocation (one GPU, config 2): `roofline.traffic` is measured by this run -- two short child passes under
+rocprofv3 (--pmc FETCH_SIZE, --pmc WRITE_SIZE; MI355X_MICROARCH.md HBM section, FETCH_SIZE x2 on gfx950) started before
+this process touches the GPU; where rocprofv3 is missing the figure committed under profiles/ is quoted and says so --
+and a `configs` block follows the headline: every BASELINE.json configuration (plus the reference's own default call),
+kernel-only, with the plan's launch shape, its cold `prepare_ms` and the unmodified reference timed on this host's cores.
 
 Multi-GPU: `python bench.py --gpus N` starts N worker processes itself (one per GPU; the parent makes no GPU call
 and relays rank 0's single JSON line), or run it under `python -m torch.distributed.run --nproc-per-node N`.
@@ -47,7 +55,20 @@ WORKLOADS = {
     "cfg5": (4096, 4096, 1.0, 4.0, 45.0, MODE_AREA, "4096x4096 fp32 -> 23170x23170 (x4 up), rotation 45"),
     "cfg5bilinear": (4096, 4096, 1.0, 4.0, 45.0, MODE_BILINEAR, "4096x4096 fp32 -> 23170x23170, rotation 45, bilinear"),
     "cfg5bicubic": (4096, 4096, 1.0, 4.0, 45.0, MODE_BICUBIC, "4096x4096 fp32 -> 23170x23170, rotation 45, bicubic"),
+    # the reference's own example call, Source.cpp:1528-1534 (isocenter (455, 455), mode 2 = fast is its default)
+    "refdefault": (911, 911, 150.0, 25.4, 1.5, MODE_AREA, "911x911 fp32 at 150 dpi -> 25.4 dpi (158x158), rotation 1.5, isocenter (455,455)"),
+    "refdefaultfast": (911, 911, 150.0, 25.4, 1.5, MODE_FAST, "911x911 fp32 at 150 dpi -> 25.4 dpi (158x158), rotation 1.5, isocenter (455,455), fast mode"),
 }
+ISOCENTER = {"refdefault": (455.0, 455.0), "refdefaultfast": (455.0, 455.0)}      # default: the image centre
+
+
+def isocenter(name, W, H):
+    return ISOCENTER.get(name, ((W - 1) / 2, (H - 1) / 2))
+
+
+# the `configs` block of the default invocation: (workload, images per launch)
+CONFIG_SET = [("cfg1", 4), ("cfg2", 1), ("cfg3", 1), ("cfg3fast", 1), ("cfg4", 64), ("cfg5", 1), ("cfg5bilinear", 1), ("cfg5bicubic", 1),
+              ("refdefault", 1), ("refdefaultfast", 1)]
 
 
 # ---- CPU baseline -----------------------------------------------------------------------------------------------
@@ -100,7 +121,15 @@ def cpu_baseline(name, budget_s=15.0, procs=0, pool=None):
             return r.dst.size, dt
 
         L = sr / dr
-        if ang == 0.0:
+        if name in ISOCENTER:
+            src = po.synth_image(W, H, 1).astype(np.float64)
+            t0 = time.perf_counter()
+            r = po.ref_run(omode, src, sr, dr, ISOCENTER[name], ang)
+            t = time.perf_counter() - t0
+            assert r.ok, r.msg
+            n, rows_src = r.dst.size, H
+            sample = "unmodified reference (Source.cpp via oracle/_ref) on the whole %dx%d image: %d output pixels, %.2f s" % (W, H, n, t)
+        elif ang == 0.0:
             unit = max(1, int(round(8 * L)))                 # source rows for 8 output rows
             n, t = run_crop(W, unit)
             rows_src = int(min(H, max(unit, unit * (budget_s / max(t, 1e-6)))))
@@ -165,37 +194,183 @@ def _free_port():
     return p
 
 
-def spawn_ranks(n, argv):
+def under_profiler():
+    """rocprofv3 (and rocprof) preload a tool library that initialises the GPU in THIS process before main() runs."""
+    env = os.environ
+    return any(k in env for k in ("ROCP_TOOL_LIBRARIES", "ROCPROFILER_REGISTER_FORCE_LOAD")) or "rocprof" in env.get("LD_PRELOAD", "")
+
+
+def spawn_ranks(n, argv, deadline_s):
     """`python bench.py --gpus N` without a launcher: start one fresh worker process per GPU (RANK / LOCAL_RANK /
     WORLD_SIZE / MASTER_* in their environment, like torch.distributed.run sets them) and relay rank 0's single JSON
-    line.  This parent never touches the GPU (children are new processes, never an exec of one that has)."""
+    line.  This parent never touches the GPU (children are new processes, never an exec of one that has) -- which is why
+    it refuses to run under a profiler's preload, where the GPU is already initialised here.  The workers get a session
+    of their own: SIGTERM / SIGINT / the overall deadline kill exactly those process groups, so no rank outlives us
+    holding a GPU, and a rank stuck in a rendezvous cannot block us for ever."""
+    import signal
+    if under_profiler():
+        sys.stderr.write("bench.py: refusing to self-launch %d ranks under a profiler preload (the GPU is already initialised in this "
+                         "process); profile a single rank, or start the ranks with torch.distributed.run\n" % n)
+        sys.exit(2)
     port = os.environ.get("MASTER_PORT") or str(_free_port())
     procs = []
+
+    def kill_all():
+        for p in procs:
+            if p.poll() is None:
+                try:
+                    os.killpg(p.pid, signal.SIGKILL)          # exactly the sessions started below
+                except (ProcessLookupError, PermissionError):
+                    pass
+
+    def on_signal(signum, frame):
+        kill_all()
+        sys.exit(128 + signum)
+
+    old = {sig: signal.signal(sig, on_signal) for sig in (signal.SIGTERM, signal.SIGINT)}
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=port, AAI_BENCH_CHILD="1")
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env, start_new_session=True,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=(r == 0)))
     # wait for all of them; a rank that dies takes the others (blocked in a rendezvous or a collective) with it
+    t_end = time.monotonic() + deadline_s
+    timed_out = False
     while True:
         codes = [p.poll() for p in procs]
         if any(c not in (None, 0) for c in codes):
-            for p in procs:
-                if p.poll() is None:
-                    p.kill()              # exactly the processes started above
+            kill_all()
             break
         if all(c == 0 for c in codes):
+            break
+        if time.monotonic() > t_end:
+            timed_out = True
+            kill_all()
             break
         time.sleep(0.05)
     out0 = procs[0].stdout.read() if procs[0].stdout else ""
     codes = [p.wait() for p in procs]
+    for sig, h in old.items():
+        signal.signal(sig, h)
     lines = [l for l in (out0 or "").splitlines() if l.startswith("{")]
-    if any(codes) or len(lines) != 1:
-        sys.stderr.write("bench.py: worker exit codes %r, %d JSON line(s) from rank 0\n" % (codes, len(lines)))
+    if timed_out or any(codes) or len(lines) != 1:
+        sys.stderr.write("bench.py: %sworker exit codes %r, %d JSON line(s) from rank 0\n" %
+                         ("deadline of %.0f s passed; " % deadline_s if timed_out else "", codes, len(lines)))
         sys.exit(1)
     print(lines[0], flush=True)
     sys.exit(0)
+
+
+# ---- HBM traffic of the dominant kernel, measured by this run ---------------------------------------------------------------
+def measure_traffic(argv_child, timeout_s=240.0):
+    """Two child passes of the same workload under rocprofv3, one counter each (FETCH_SIZE takes 3 of the 4 TCC slots,
+    WRITE_SIZE 2: MI355X_MICROARCH.md "rocprofv3 PMC slots"), started BEFORE this process touches the GPU.  Returns
+    (bytes per launch of the kernel with the most launches, description) or (None, reason).  FETCH_SIZE / WRITE_SIZE are in
+    KiB; on gfx950 FETCH_SIZE reports exactly half of a wide coalesced stream (same guide, HBM section): bytes =
+    (2 FETCH_SIZE + WRITE_SIZE) * 1024."""
+    import csv
+    import glob
+    import shutil
+    import tempfile
+    from collections import defaultdict
+    exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if exe is None:
+        return None, "rocprofv3 not found"
+    if under_profiler():
+        return None, "already under a profiler"
+    got = {}
+    tmp = tempfile.mkdtemp(prefix="aai_pmc_", dir="/tmp")
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            out = os.path.join(tmp, counter)
+            cmd = [exe, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", out, "--",
+                   sys.executable, os.path.abspath(__file__)] + argv_child
+            try:
+                r = subprocess.run(cmd, env=dict(os.environ, TMPDIR="/tmp", AAI_BENCH_CHILD="1"), stdout=subprocess.DEVNULL, stderr=subprocess.PIPE,
+                                   text=True, timeout=timeout_s)
+            except subprocess.TimeoutExpired:
+                return None, "rocprofv3 --pmc %s pass timed out" % counter
+            if r.returncode != 0:
+                return None, "rocprofv3 --pmc %s pass failed (%d): %s" % (counter, r.returncode, (r.stderr or "")[-200:].replace("\n", " "))
+            acc = defaultdict(list)
+            for f in glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True):
+                for row in csv.DictReader(open(f)):
+                    if row.get("Counter_Name") == counter and "aai_" in row.get("Kernel_Name", "") and "synth" not in row["Kernel_Name"]:
+                        acc[(row["Kernel_Name"], row.get("Grid_Size"), row.get("Workgroup_Size"))].append(float(row["Counter_Value"]))
+            if not acc:
+                return None, "no %s rows in the rocprofv3 output" % counter
+            key = max(acc, key=lambda k: len(acc[k]))            # the steady launch shape: the one with most launches
+            got[counter] = (key[0], len(acc[key]), sum(acc[key]) / len(acc[key]))
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    (kf, nf, fetch), (kw, nw, write) = got["FETCH_SIZE"], got["WRITE_SIZE"]
+    if kf != kw:
+        return None, "the two passes disagree on the dominant kernel"
+    nbytes = (2.0 * fetch + write) * 1024.0
+    return nbytes, ("measured by this run: rocprofv3 --pmc FETCH_SIZE (mean of %d launches: %.0f KiB, x2 on gfx950) and --pmc WRITE_SIZE (%d launches: %.0f KiB) "
+                    "in two child passes of the same workload, kernel %s" % (nf, fetch, nw, write, kf.split("(")[0][-60:]))
+
+
+# ---- the other BASELINE configurations, kernel-only ------------------------------------------------------------------------
+def config_block(aai, torch, policy, cfg2_cpu, cpu_procs, cpu_pool, with_cpu):
+    """Every BASELINE.json configuration (CONFIG_SET) on this GPU: device-resident synthetic images, `prepare_ms` = wall
+    clock of aai_prepare on a geometry this process has not seen (config 2: the headline already built its plan -- its
+    cold figure is `plan.first_call_ms` of the headline), then a block of launches between two HIP events on the launch
+    stream.  Algorithmic bytes as in SURVEY.md 8(d): source read once + output written once.  CPU: the unmodified reference
+    on a bounded sample of the same workload on this host (cpu_baseline); config 4 additionally as N processes."""
+    stream = torch.cuda.current_stream().cuda_stream
+    out = []
+    for name, B in CONFIG_SET:
+        W, H, sr, dr, ang, mode, desc = WORKLOADS[name]
+        rq = aai.make_request(W, H, sr, dr, isocenter(name, W, H), ang, mode=mode, policy=policy)
+        rc, msg, lay = aai.query(rq)
+        assert rc == 0, msg
+        dW, dH = lay.dst_width, lay.dst_height
+        src = torch.empty((B, H, W), dtype=torch.float32, device="cuda")
+        dst = torch.empty((B, dH, dW), dtype=torch.float32, device="cuda")
+        for b in range(B):
+            aai.synth_device(src[b].data_ptr(), W, H, W, b + 1, stream)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        aai.prepare(rq)
+        torch.cuda.synchronize()
+        prepare_ms = (time.perf_counter() - t0) * 1e3
+
+        def launch():
+            aai.resample_device(rq, src.data_ptr(), W, dst.data_ptr(), dW, stream, batch=B, src_image_stride=W * H, dst_image_stride=dW * dH)
+
+        launch()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        launch()
+        torch.cuda.synchronize()
+        one = max(time.perf_counter() - t0, 1e-5)
+        n = int(max(5, min(2000, 0.4 / one)))                      # about 0.4 s of launches per configuration
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(n):
+            launch()
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / n
+        alg = B * (4 * W * H + 4 * dW * dH)
+        entry = {"workload": "%s: %s" % (name, desc), "images_per_launch": B, "dst": [dW, dH], "kernel": aai.last_kernel(),
+                 "kernel_ms_per_launch": ms, "launches_timed": n, "value": B * dW * dH / (ms * 1e-3) / 1e6, "unit": "Mpixels/s (output)",
+                 "algorithmic_bytes_per_launch": alg, "achieved_gbps": alg / (ms * 1e-3) / 1e9, "frac": alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                 "plan_shape": aai.plan_shape(rq), "prepare_ms": prepare_ms, "prepare": "warm (built by the headline)" if name == "cfg2" else "cold"}
+        del src, dst
+        torch.cuda.empty_cache()
+        if with_cpu and mode in (MODE_AREA, MODE_FAST):
+            if name == "cfg2" and cfg2_cpu:
+                cpu = dict(cfg2_cpu)
+                cpu.pop("gpu_over_cpu", None)
+            else:
+                cpu = cpu_baseline(name, budget_s=6.0, procs=cpu_procs if name == "cfg4" else 0, pool=cpu_pool)
+            entry["cpu_baseline"] = cpu
+            entry["gpu_over_cpu"] = entry["value"] / cpu["value"]
+        out.append(entry)
+    return out
 
 
 # ---- one rank -----------------------------------------------------------------------------------------------------
@@ -214,7 +389,9 @@ def worker(args):
     if args.mock_fail_rank == rank:
         sys.exit(3)
     # the worker processes of the multi-process CPU baseline (config 4) are started BEFORE this process touches the GPU
-    cpu_procs = args.cpu_procs if args.cpu_procs >= 0 else (min(16, os.cpu_count() or 1) if args.workload == "cfg4" else 0)
+    want_configs = args.configs == "on" or (args.configs == "auto" and world == 1 and args.workload == "cfg2" and not args.custom and
+                                            not mock and not args.traffic_child and args.shard == "batch" and args.src_dtype == "f32")
+    cpu_procs = args.cpu_procs if args.cpu_procs >= 0 else (min(16, os.cpu_count() or 1) if (args.workload == "cfg4" or want_configs) else 0)
     cpu_pool = None
     if cpu_procs > 1 and world == 1 and not args.no_cpu_baseline and not mock:
         from multiprocessing import get_context
@@ -256,7 +433,7 @@ def worker(args):
         args.workload = "custom"
     W, H, sr, dr, ang, mode, desc = WORKLOADS[args.workload]
     policy = aai.POLICY_REFERENCE if args.policy == "reference" else aai.POLICY_EXACT
-    rq = aai.make_request(W, H, sr, dr, ((W - 1) / 2, (H - 1) / 2), ang, mode=mode, policy=policy)
+    rq = aai.make_request(W, H, sr, dr, isocenter(args.workload, W, H), ang, mode=mode, policy=policy)
     rq = D.broadcast_request(rq, src=0, device=cdev, force=args.force_dist)           # the only collective the path needs
     rc, msg, lay = aai.query(rq)
     assert rc == 0, msg
@@ -320,43 +497,60 @@ def worker(args):
         if not mock:
             torch.cuda.synchronize()
 
-    def events(n):
-        if mock:
-            return None
-        return [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n)]
-
     # warm-up (also builds the plan), then a short probe that sizes `repeats`
-    for _ in range(max(args.warmup, 1)):
+    t_prep = time.perf_counter()
+    step()
+    fence()
+    first_call_ms = (time.perf_counter() - t_prep) * 1e3         # plan creation (scans / tables / launch-shape measurement) + one launch
+    for _ in range(max(args.warmup, 1) - 1):
         step()
     fence()
+    if args.traffic_child:
+        # a counter pass of measure_traffic(): a few launches of the steady shape, nothing to report
+        for _ in range(args.steps):
+            step()
+        fence()
+        return
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     fence()
     probe = max(time.perf_counter() - t0, 1e-6)
-    repeats = args.repeats if args.repeats > 0 else max(1, min(100000, int(args.min_seconds / probe + 0.999)))
+    repeats = args.repeats if args.repeats > 0 else max(1, min(1000000, int(args.min_seconds / probe + 0.999)))
     if dist.is_initialized():
         t = torch.tensor([repeats], dtype=torch.int64, device=cdev)
         dist.broadcast(t, src=0)
         repeats = int(t.item())
 
+    # the timed region: launches only; ONE event pair on the launch stream brackets it
     n_timed = repeats * args.steps
-    evs = events(n_timed)
+    e0 = e1 = None
+    if not mock:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     fence()
     t0 = time.perf_counter()
-    for i in range(n_timed):
-        if evs:
-            evs[i][0].record()
+    if e0:
+        e0.record()
+    for _ in range(n_timed):
         step()
-        if evs:
-            evs[i][1].record()
+    if e1:
+        e1.record()
     fence()
     elapsed = time.perf_counter() - t0
-    if evs:
-        per_step = sorted(a.elapsed_time(b) for a, b in evs)            # HIP events on the launch stream, ms
+    kernel_ms = e0.elapsed_time(e1) / n_timed if e0 else elapsed / n_timed * 1e3        # average launch duration on the stream
+    # per-step spread, outside the timed region: at most 512 steps with an event pair each
+    n_stat = min(n_timed, 512)
+    if mock:
+        per_step = [elapsed / n_timed * 1e3] * n_stat
     else:
-        per_step = [elapsed / n_timed * 1e3] * n_timed
-    kernel_ms = sum(per_step) / len(per_step)
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n_stat)]
+        for a, b in evs:
+            a.record()
+            step()
+            b.record()
+        fence()
+        per_step = sorted(a.elapsed_time(b) for a, b in evs)
+        del evs
     kernel_name = "mock" if mock else aai.last_kernel()
 
     t = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
@@ -390,15 +584,17 @@ def worker(args):
         out_pix = total_images * dW * dH * n_timed
         alg_bytes = B * (esz * W * src_rows + 4 * dW * out_rows)              # per launch on this GPU
         achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
-        traffic, traffic_source = None, None                                  # measured HBM bytes per launch (rocprofv3 PMC)
-        try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json"))).get(args.workload)
-            if pmc and pmc["batch"] == B and args.src_dtype == "f32" and not rows_mode:
-                traffic = pmc["bytes_per_launch"]
-                traffic_source = "profiles/pmc_traffic.json: rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE) committed with the repository, " \
-                                 "NOT collected by this run (%s)" % pmc.get("measured", "see profiles/README.md")
-        except Exception:
-            pass
+        plan_shape = "" if mock else aai.plan_shape(rq)                         # "kernel=K rows=R nt=N swap=S flagged=F dense=D"
+        traffic, traffic_source = args.traffic_bytes, args.traffic_note          # HBM bytes per launch: this run's rocprofv3 PMC passes
+        if traffic is None:
+            try:
+                pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json"))).get(args.workload)
+                if pmc and pmc["batch"] == B and args.src_dtype == "f32" and not rows_mode:
+                    traffic = pmc["bytes_per_launch"]
+                    traffic_source = "profiles/pmc_traffic.json: rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE) committed with the repository, " \
+                                     "NOT collected by this run (%s; this run: %s)" % (pmc.get("measured", "see profiles/README.md"), args.traffic_note or "not attempted")
+            except Exception:
+                pass
         mid = len(per_step) // 2
         line = {
             "metric": "Mpixels/s (output) and achieved HBM GB/s, 8192^2->2048^2 fp32, 1/2/4/8 GPU",
@@ -413,7 +609,10 @@ def worker(args):
                        "images_per_gpu_per_step": B if not rows_mode else 1.0 / world, "src_bytes_per_gpu": esz * W * src_rows * B,
                        "parallelism": ("one image in %d row bands" if rows_mode else "batch-sharded x%d") % world},
             "timed": {"repeats": repeats, "steps_timed": n_timed, "seconds": elapsed,
-                      "step_ms": {"min": per_step[0], "median": per_step[mid], "max": per_step[-1]}},
+                      "step_ms": {"min": per_step[0], "median": per_step[mid], "max": per_step[-1], "steps": len(per_step),
+                                  "note": "separate pass with one HIP event pair per step; the timed region itself holds launches only"}},
+            "plan": {"shape": plan_shape, "first_call_ms": first_call_ms,
+                     "note": "first_call_ms = plan creation (tables, one-off scans, K1 launch-shape measurement) + one launch, wall clock"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_source,
                          "kernel": kernel_name, "kernel_ms_per_launch": kernel_ms, "algorithmic_bytes_per_launch": alg_bytes},
@@ -427,8 +626,12 @@ def worker(args):
             line["distributed"]["gather_ms"] = gather_ms
             line["distributed"]["value_with_gather"] = total_images * dW * dH / (elapsed / n_timed + gather_ms * 1e-3) / 1e6
         if world == 1 and not args.no_cpu_baseline and not mock and mode in (MODE_AREA, MODE_FAST):
-            line["cpu_baseline"] = cpu_baseline(args.workload, procs=cpu_procs, pool=cpu_pool)
+            line["cpu_baseline"] = cpu_baseline(args.workload, procs=cpu_procs if args.workload == "cfg4" else 0, pool=cpu_pool)
             line["cpu_baseline"]["gpu_over_cpu"] = line["value"] / line["cpu_baseline"]["value"]
+        if want_configs:
+            del src, dst
+            torch.cuda.empty_cache()
+            line["configs"] = config_block(aai, torch, policy, line.get("cpu_baseline"), cpu_procs, cpu_pool, not args.no_cpu_baseline)
         if saved_stdout is not None:
             sys.stdout.flush()
             ctypes.CDLL(None).fflush(None)          # whatever C stdio still holds goes to stderr, not after the JSON line
@@ -458,7 +661,14 @@ def main():
                     help="source element type (the headline metric is f32; u8/u16 exercise the typed entry points)")
     ap.add_argument("--shard", default="batch", choices=["batch", "rows"],
                     help="batch: every rank resamples its own images (weak scaling); rows: ONE image split into dst row bands (strong scaling)")
-    ap.add_argument("--min-seconds", type=float, default=1.5, help="the timed leg repeats the block of --steps until it lasts about this long")
+    ap.add_argument("--min-seconds", type=float, default=6.0, help="the timed leg repeats the block of --steps until it lasts about this long "
+                    "(default 6 s: longer than a 5-second telemetry sampling period)")
+    ap.add_argument("--configs", default="auto", choices=["auto", "on", "off"],
+                    help="append the per-configuration block (every BASELINE config, kernel-only, with CPU baselines): auto = the default one-GPU config-2 run")
+    ap.add_argument("--traffic", default="auto", choices=["auto", "off"],
+                    help="measure roofline.traffic in this run (two rocprofv3 --pmc child passes before the GPU is touched): auto = one GPU, no launcher")
+    ap.add_argument("--deadline", type=float, default=1500.0, help="--gpus N self-launch: kill the ranks and fail after this many seconds")
+    ap.add_argument("--traffic-child", action="store_true", help=argparse.SUPPRESS)     # a counter pass of measure_traffic()
     ap.add_argument("--repeats", type=int, default=0, help="fix the number of repeats of the --steps block (0 = from --min-seconds)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-procs", type=int, default=-1, help="processes of the extra multi-process CPU baseline (default: min(16, cores) for cfg4, else none)")
@@ -473,7 +683,13 @@ def main():
 
     # No launcher around us and more than one GPU asked for: become the launcher (and never touch the GPU ourselves).
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
-        spawn_ranks(args.gpus, sys.argv[1:])
+        spawn_ranks(args.gpus, sys.argv[1:], args.deadline)
+    args.traffic_bytes, args.traffic_note = None, None
+    if (args.traffic == "auto" and args.gpus == 1 and "WORLD_SIZE" not in os.environ and not args.mock_device and not args.traffic_child and
+            not args.force_dist and args.shard == "batch" and os.environ.get("AAI_BENCH_TRAFFIC", "1") != "0"):
+        child = ["--traffic-child", "--traffic", "off", "--configs", "off", "--no-cpu-baseline", "--workload", args.workload, "--batch", str(args.batch),
+                 "--steps", "8", "--warmup", "2", "--policy", args.policy, "--src-dtype", args.src_dtype] + (["--custom", args.custom] if args.custom else [])
+        args.traffic_bytes, args.traffic_note = measure_traffic(child)
     worker(args)
 
 

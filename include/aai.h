@@ -149,6 +149,26 @@ int aai_resample_f64(const aai_request *req, const double *src, int64_t src_stri
  * device and must not run inside a stream capture.  aai_prepare takes that cost up front; plans are cached per
  * process (32 most recently used), shared by batches, row bands (rotated requests) and streams. */
 int aai_prepare(const aai_request *req, int32_t channels /* 1 for plain images; 2..4: interleaved */);
+/* What building a plan does on the device (inside aai_prepare, or inside the first resampling call of a request):
+ *   - K1 (rotation by a multiple of 90 degrees): uploads the weight tables; checks the separable model against the
+ *     reference's classifier -- on the host where the geometry's arithmetic is exact (integer and simple ratios), else by
+ *     one scan kernel over the output; and, for the FIRST large plain-fp32 geometry of a class (same device, same source
+ *     rows per output row, same width class) measures which launch shape streams fastest on this device: transient
+ *     scratch of 2..8 source-sized images (at most 1.25 GiB; larger sources skip the measurement) plus their outputs,
+ *     ~40 launches on a private stream, ~10 ms.  Later plans of the class reuse the result.  AAI_AXIS_AUTOTUNE=0 in the
+ *     environment disables the measurement (built-in shape).
+ *   - rotated area / fast requests: one or two scan kernels over the output (pixels left to the double-precision pass).
+ * All of it runs on a private stream and blocks only the calling thread: plans of other requests, devices and threads are
+ * built and launched from concurrently.
+ *
+ * aai_plan_info writes a one-line description of the cached whole-image plan of `req` on the current device into `text`
+ * ("" when there is none yet): "kernel=K rows=R nt=N swap=S tune=measured|cached|default flagged=F dense=D form=cell|quad|-
+ * build_ms=B" -- the kernel family (AAI_KERNEL_*), K1's launch shape and where it came from, the dst pixels the
+ * double-precision pass owns, the fp32 formulation of a rotated area request, and what building the plan cost. */
+int aai_plan_info(const aai_request *req, int32_t channels, char *text, int32_t capacity);
+/* Drops every cached plan (device tables, flag lists, side streams) while the HIP runtime is alive.  Optional: the cache is
+ * never torn down from a static destructor, so a process may also simply exit. */
+int aai_shutdown(void);
 int aai_resample_device_f32(const aai_request *req, const float *d_src, int64_t src_stride,
                             float *d_dst, int64_t dst_stride, void *stream);
 

@@ -120,6 +120,8 @@ def hostemu(aai):
     lib.aai_emu_skip_axis_fixup.argtypes = [ctypes.c_int]
     lib.aai_emu_use_quad.restype = None
     lib.aai_emu_use_quad.argtypes = [ctypes.c_int]
+    lib.aai_emu_axis_class_verify.restype = ctypes.c_long
+    lib.aai_emu_axis_class_verify.argtypes = [ctypes.POINTER(L.Request), ctypes.POINTER(ctypes.c_long), ctypes.POINTER(ctypes.c_long)]
     lib.aai_emu_use_cell.restype = None
     lib.aai_emu_use_cell.argtypes = [ctypes.c_int]
     lib.aai_emu_quad_stats.restype = None

@@ -686,6 +686,30 @@ void aai_emu_force_general(int on) { g_forceGeneral = on; }
 void aai_emu_use_quad(int on) { g_useQuad = on; }
 void aai_emu_use_cell(int on) { g_useCell = on; }
 
+// The host-side class verification of an axis-aligned plan (aai_plan.cpp: axis_verify_by_class) against the per-pixel scan
+// it replaces (aai_axis_verify_kernel = axis_pixel_differs for every dst pixel).  Returns -1 when the geometry does not
+// qualify (inexact arithmetic), else the number of dst pixels on which the two disagree; counts of flagged pixels out.
+long aai_emu_axis_class_verify(const aai_request *rq, long *byClass, long *byScan)
+{
+    Geometry g; std::string msg;
+    if (make_geometry(*rq, g, msg) != AAI_OK || !g.axisAligned) return -2;
+    const RotLaunch r = make_rot_launch(g, rq->mode, rq->policy);
+    std::vector<std::pair<int, int>> flagged;
+    bool dense = false;
+    if (!axis_verify_by_class(r, flagged, dense, 1u << 30)) return -1;
+    std::vector<char> a((size_t)r.dW * r.dH, 0);
+    for (auto &f : flagged) a[(size_t)f.second * r.dW + f.first] = 1;
+    long bad = 0, n = 0;
+    for (int y = 0; y < r.dH; ++y)
+        for (int x = 0; x < r.dW; ++x) {
+            const bool d = rq->mode == AAI_MODE_FAST ? axis_pixel_differs_fast(r, x, y) : axis_pixel_differs(r, x, y);
+            n += d ? 1 : 0;
+            if (d != (a[(size_t)y * r.dW + x] != 0)) ++bad;
+        }
+    *byClass = (long)flagged.size(); *byScan = n;
+    return bad;
+}
+
 int aai_emu_cell_parts(const aai_request *rq, int dx, int dy, const float *img, double *out32, double *out64)
 {
     Geometry g; std::string msg;

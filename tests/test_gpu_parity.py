@@ -187,7 +187,8 @@ def test_rows_as_runs_kernel_against_oracle(gpu, po):
             gold = po.oracle_run(po.MODE_EXACT, src.astype(np.float64), sr, dr, iso, ang, policy=policy)
             rc, msg, dst, giso, lay = gpu.resample_host(src, sr, dr, iso, ang, mode=1, policy=policy)
             assert rc == 0, msg
-            assert "aai_rotated_runs_kernel" in gpu.last_kernel() or "aai_quad_kernel" in gpu.last_kernel(), (k, gpu.last_kernel())
+            # (footprints whose window still fits the fp32 formulations -- up to about 5.5 : 1 -- take the cell kernel)
+            assert "aai_rotated_runs_kernel" in gpu.last_kernel() or "aai_cell_kernel" in gpu.last_kernel(), (k, gpu.last_kernel())
             kernels.add(gpu.last_kernel())
             assert dst.shape == gold.dst.shape and tuple(giso) == gold.dst_iso
             assert rel_err(dst, gold.dst).max() <= TOL, (k, policy, W, H, sr, ang)
@@ -858,6 +859,56 @@ def test_multi_device_entry_and_prepare(gpu):
         assert torch.equal(out, whole[1]), (sr, ang)
 
 
+def test_plans_are_built_outside_the_cache_lock(gpu):
+    """Building a plan (tables, scans, K1's launch-shape measurement: ~10 ms for a config-2-sized geometry) blocks only the
+    thread that asked for it: while one thread prepares a large axis-aligned request, another prepares and runs small
+    rotated requests on its own stream and finishes long before.  Also: aai_plan_info describes what was built, a second
+    geometry of the same class takes the launch shape from the cache, and aai_shutdown drops the plans."""
+    import threading
+    import time
+    import torch
+    big = gpu.make_request(8192, 8192, 4.0, 1.0, (4095.5, 4095.5), 0.0, mode=1)
+    done = {}
+
+    def slow():
+        gpu.set_device(0)
+        t0 = time.perf_counter()
+        gpu.prepare(big)
+        done["big"] = (t0, time.perf_counter())
+
+    def quick():
+        gpu.set_device(0)
+        s = torch.cuda.Stream()
+        src = torch.rand((96, 128), dtype=torch.float32, device="cuda")
+        time.sleep(0.002)                       # let the other thread get going
+        t0 = time.perf_counter()
+        for k in range(4):
+            rq = gpu.make_request(128, 96, 3.0, 1.0, (63.5, 47.5), 10.0 + 7.0 * k, mode=1)
+            rc, msg, lay = gpu.query(rq)
+            out = torch.empty((lay.dst_height, lay.dst_width), dtype=torch.float32, device="cuda")
+            gpu.resample_device(rq, src.data_ptr(), 128, out.data_ptr(), lay.dst_width, s.cuda_stream)
+        s.synchronize()
+        done["small"] = (t0, time.perf_counter())
+
+    gpu.shutdown()                              # cold: no plan, but possibly a cached launch shape from earlier tests
+    torch.cuda.synchronize()
+    a, b = threading.Thread(target=slow), threading.Thread(target=quick)
+    a.start(); b.start(); a.join(); b.join()
+    big_t, small_t = done["big"], done["small"]
+    text = gpu.plan_shape(big)
+    assert "kernel=" in text and "build_ms=" in text and "tune=" in text, text
+    build_ms = float(text.split("build_ms=")[1].split()[0])
+    if build_ms > 4.0 and small_t[0] < big_t[1]:
+        # the two really overlapped: the quick thread must not have waited for the big plan to finish
+        assert small_t[1] - small_t[0] < 0.75 * (big_t[1] - big_t[0]) or small_t[1] < big_t[1], (big_t, small_t, text)
+    # same class, other geometry: the launch shape comes from the cache (or was never measured: autotune disabled)
+    other = gpu.make_request(8192, 8064, 4.0, 1.0, (4095.5, 4031.5), 0.0, mode=1)
+    gpu.prepare(other)
+    assert "tune=cached" in gpu.plan_shape(other) or "tune=default" in gpu.plan_shape(other), gpu.plan_shape(other)
+    gpu.shutdown()
+    assert gpu.plan_shape(big) == ""
+
+
 def test_pinned_array_views_outlive_close(gpu):
     """PinnedArray.close() drops the owner's reference only: a view held elsewhere keeps the page-locked block alive."""
     import gc
@@ -941,12 +992,12 @@ def test_double_precision_policy(gpu, po):
             gold = po.oracle_run(omode, src.astype(np.float64), sr, dr, iso, ang, policy=policy).dst
             rc, msg, dst, _, lay = gpu.resample_host(src, sr, dr, iso, ang, mode=mode, policy=policy)
             # (this geometry replicates its source pixels: fast mode keeps the line-walking kernel)
-            assert rc == 0 and ("quad" in gpu.last_kernel()) == (mode == 1) and rel_err(dst, gold).max() <= TOL
+            assert rc == 0 and ("aai_cell_kernel" in gpu.last_kernel()) == (mode == 1) and rel_err(dst, gold).max() <= TOL
             rc, msg, dst, _, lay = gpu.resample_host(src, sr, dr, iso, ang, mode=mode, policy=policy | flag)
-            assert rc == 0 and "quad" not in gpu.last_kernel(), gpu.last_kernel()
+            assert rc == 0 and "quad" not in gpu.last_kernel() and "cell" not in gpu.last_kernel(), gpu.last_kernel()
             assert rel_err(dst, gold).max() <= 1.5e-7 and np.array_equal(gold == 0, dst == 0)
         rc, msg, idst, ilay = gpu.resample_interleaved_host(isrc, sr, dr, iso, ang, mode=mode, policy=1 | flag)
-        assert rc == 0 and "quad" not in gpu.last_kernel()
+        assert rc == 0 and "quad" not in gpu.last_kernel() and "cell" not in gpu.last_kernel()
         for c in range(3):
             g = po.oracle_run(omode, isrc[:, :, c].astype(np.float64), sr, dr, iso, ang, policy=1).dst
             assert rel_err(idst[:, :, c], g).max() <= 1.5e-7

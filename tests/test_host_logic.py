@@ -361,6 +361,52 @@ def test_axis_aligned_knife_geometries_take_the_model_scan(aai, hostemu, axis_kn
     assert hostemu.aai_emu_axis_fixups() > 0 and rel_err(a, z["a000_exact"]).max() <= 1e-6
 
 
+def test_axis_class_verification_equals_the_per_pixel_scan(aai, hostemu, axis_knife_golden):
+    """Plans of axis-aligned requests whose arithmetic is exact check K1's separable model on the host, one representative
+    per (column class, row class) -- csrc/aai_plan.cpp: axis_verify_by_class -- instead of scanning every dst pixel on the
+    device (6.6 ms at config 2).  On all 576 reference-generated axis knife geometries x both modes, and on the BASELINE
+    shapes, the flagged set must equal the per-pixel scan's exactly; geometries with inexact arithmetic must decline."""
+    import ctypes
+    z, manifest = axis_knife_golden
+    qualified = flagged = 0
+    for i, c in enumerate(manifest):
+        for mode in (1, 2):
+            rq = aai.make_request(c["W"], c["H"], c["src_res"], c["dst_res"], c["iso"], c["angle"], mode=mode)
+            a, b = ctypes.c_long(), ctypes.c_long()
+            bad = hostemu.aai_emu_axis_class_verify(ctypes.byref(rq), ctypes.byref(a), ctypes.byref(b))
+            assert bad in (0, -1), (i, c, mode, bad, a.value, b.value)
+            if bad == 0:
+                qualified += 1
+                flagged += a.value
+                assert a.value == b.value
+    # (only dyadic ratios / isocenters qualify -- 2 : 1 of the nine ratios there; the geometries that need the fix-up pass are
+    # the 3 : 1, 5 : 1 ... ones, whose coordinates round and which therefore keep the per-pixel device scan)
+    assert qualified >= 96, (qualified, flagged)
+    # a sweep of dyadic geometries (the side must be a power of two for 1 / side to be exact): isocenters on eighth pixels, odd
+    # and even sizes, every quadrant, both modes
+    swept = 0
+    for (W, H) in ((12, 7), (9, 8)):
+        for (sr, dr) in ((1, 1), (2, 1), (4, 1), (8, 1), (4, 2), (8, 4)):
+            for fx in (0, 0.125, 0.5, 0.75):
+                for ang in (0.0, 90.0, 180.0, 270.0):
+                    for mode in (1, 2):
+                        rq = aai.make_request(W, H, float(sr), float(dr), (W // 2 + fx, H // 2 + 0.25), ang, mode=mode)
+                        a, b = ctypes.c_long(), ctypes.c_long()
+                        bad = hostemu.aai_emu_axis_class_verify(ctypes.byref(rq), ctypes.byref(a), ctypes.byref(b))
+                        assert bad == 0 and a.value == b.value, (W, H, sr, dr, fx, ang, mode, bad, a.value, b.value)
+                        swept += 1
+    assert swept == 384
+    for (W, H, sr, dr, iso, ang, mode) in ((512, 512, 2.0, 1.0, (255.5, 255.5), 0.0, 1), (1024, 768, 4.0, 1.0, (511.5, 383.5), 90.0, 1),
+                                           (1024, 768, 4.0, 1.0, (511.5, 383.5), 180.0, 2), (300, 200, 4.0, 2.0, (100.25, 50.0), 270.0, 1)):
+        rq = aai.make_request(W, H, sr, dr, iso, ang, mode=mode)
+        a, b = ctypes.c_long(), ctypes.c_long()
+        assert hostemu.aai_emu_axis_class_verify(ctypes.byref(rq), ctypes.byref(a), ctypes.byref(b)) == 0 and a.value == b.value
+    # 8192 : 2731 is not a dyadic ratio: the device scan keeps such plans
+    rq = aai.make_request(600, 400, 8192.0, 2731.0, (299.5, 199.5), 0.0, mode=1)
+    a, b = ctypes.c_long(), ctypes.c_long()
+    assert hostemu.aai_emu_axis_class_verify(ctypes.byref(rq), ctypes.byref(a), ctypes.byref(b)) == -1
+
+
 def test_structured_sweeps_of_the_replay_against_the_oracle(aai, hostemu):
     """tools/replay_sweep.py, bounded: randomised structured geometries (integer / rational ratios, isocenters on centres,
     corners, half and quarter pixels) at multiples of 90 degrees and at atan(p/q) / 15-degree / hair-breadth rotations, both
