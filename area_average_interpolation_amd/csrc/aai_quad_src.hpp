@@ -106,12 +106,15 @@ struct QuadSrc {
             }
 #pragma unroll
             for (int k = 0; k < WIN; ++k) {
-                // line k: fixed row (alongX) or fixed column, its WIN elements ascending in memory from `first`
+                // line k: fixed row (alongX) or fixed column, its WIN elements ascending in memory from `first`; the values
+                // stay in the registers they arrive in (reg()), so the arrangement is a per-element select here
+                const unsigned first = alongX ? rowOff[k] + min(colOff[0], colOff[WIN - 1]) : colOff[k] + min(rowOff[0], rowOff[WIN - 1]);
+                const bool back = alongX ? colOff[0] > colOff[WIN - 1] : rowOff[0] > rowOff[WIN - 1];
                 float seg[WIN];
-                load_line<WIN>(reinterpret_cast<const float *>(img + ((alongX ? rowOff[k] : colOff[k]) + first0)), seg);
+                load_line<WIN>(reinterpret_cast<const float *>(img + first), seg);
 #pragma unroll
                 for (int e = 0; e < WIN; ++e) {
-                    const float val = rev ? seg[WIN - 1 - e] : seg[e];
+                    const float val = back ? seg[WIN - 1 - e] : seg[e];
                     if (alongX) v[k * WIN + e] = (T)val; else v[e * WIN + k] = (T)val;
                 }
             }

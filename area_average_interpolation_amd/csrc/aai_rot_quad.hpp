@@ -55,6 +55,11 @@ struct QuadConsts {
     F minArea;                        // SCAN: pixels whose total area is below this (and not zero) are reported
     int ref;                          // 1 = AAI_POLICY_REFERENCE
     int win;                          // window positions per axis, <= kQuadMaxWin
+    // fast mode only looks at pixel CENTRES inside the closed square: they lie within h (c + s) of its centre along either
+    // lattice axis, i.e. at most floor(2 h (c + s)) + 1 positions per axis -- one fewer than the area mode's window, which
+    // also holds the pixels the square merely touches (config 3: 4 x 4 instead of 5 x 5)
+    F hbf;                            // h (c + s) + guard
+    int winFast;
     // Close to an axis (min(c,s) small) the reference's corner-triangle rule has slope ~1/(2 min(c,s)) in t, far too
     // steep for fp32 coordinates, and under either policy the thin corner triangles (area t^2 / (2 c s), t tiny) need t to
     // a RELATIVE accuracy fp32 differences of numbers near 1 do not have: hiPrec evaluates both edges' t = h + k - |a|,
@@ -116,6 +121,8 @@ AAI_HD QuadConsts<F> make_quad_consts(double side, double c, double s, int polic
     q.minArea = (F)(side * side < 4.0 ? 0.25 * side * side : 1.0);
     q.ref = policy == AAI_POLICY_REFERENCE ? 1 : 0;
     q.win = (int)floor(2.0 * (hb - 0.5 + 1e-5)) + 3;
+    q.hbf = (F)(hb + 1e-5);
+    q.winFast = (int)floor(2.0 * (hb + 1e-5)) + 1;
     // ... and with replicated source pixels (up-sampling): a dst pixel then covers one or two source pixels and a dst value is
     // nearly a copy of a source value, so on noisy data it can be a hundred times smaller than its neighbours -- where the
     // 1e-7 absolute error of an fp32 area shows as several 1e-6 relative (7e-6 on 8-bit noise; 4e-7 with hiPrec)
@@ -418,7 +425,7 @@ AAI_HD bool quad_pixel(const QuadConsts<F> &q, int Xc, int Yc, double dfx, doubl
 }
 
 // Fast mode (Source.cpp:868-907 + 837-864): the mean of the virtual pixels whose CENTRES lie in the closed dst square
-// (SURVEY.md B.3).  Same window and the same up-front fetch as quad_pixel; membership is two compares per position,
+// (SURVEY.md B.3).  WIN = QuadConsts::winFast; the same up-front fetch as quad_pixel; membership is two compares per position,
 // and the values are summed straight from the registers they were fetched into -- no LDS, no passes.
 //   src.issue(xg0, yg0, valid), src.reg(slot) = the fetched value of a (compile-time) slot.
 // Returns sum and count; the dst value is sum / count, or 0 when count is 0 (Source.cpp:905).
@@ -430,7 +437,7 @@ AAI_HD bool quad_fast_pixel(const QuadConsts<F> &q, int Xc, int Yc, double dfx, 
     typedef typename QuadMask<WIN>::type mask_t;
     const F fpx = (F)dfx, fpy = (F)dfy;
     sum = F(0); count = 0;
-    const F fi0 = floor(fpx - q.hbm), fj0 = floor(fpy - q.hbm);
+    const F fi0 = ceil(fpx - q.hbf), fj0 = ceil(fpy - q.hbf);          // first lattice point a centre of the square can be
     const int i0 = (int)fi0, j0 = (int)fj0;
     const int xg0 = Xc + i0, yg0 = Yc + j0;
     // window columns ia..ib and rows ja..jb lie inside the lattice

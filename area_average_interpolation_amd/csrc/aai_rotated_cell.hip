@@ -37,8 +37,9 @@ __device__ __forceinline__ int from_next_lane(int v) { return __builtin_amdgcn_u
 
 // waves per SIMD the staged windows leave room for: WIN * WIN KiB of LDS per 256-lane block, 160 KiB per CU
 constexpr int cell_waves_per_simd(int win) { return 160 / (win * win) >= 8 ? 8 : 160 / (win * win); }
-// ... and the register budget that goes with it: 80 registers (6 waves) up to 4 x 4 windows, 96 (5 waves) at 5 x 5 where 80 spill
-constexpr int cell_min_waves(int win) { return win <= 4 ? 6 : (cell_waves_per_simd(win) > 5 ? 5 : cell_waves_per_simd(win)); }
+// ... and the register budget that goes with it: 80 registers (6 waves) up to 4 x 4 windows; from 5 x 5 (25 staged values per
+// lane) 128 registers (4 waves): 96 still spill there
+constexpr int cell_min_waves(int win) { return win <= 4 ? 6 : (cell_waves_per_simd(win) > 4 ? 4 : cell_waves_per_simd(win)); }
 
 // flag word / bit of dst pixel (dx, dy) in the 16 x 16 tiling of the plan's scans (one 64-bit word per 16 x 4 pixels)
 __device__ __forceinline__ size_t flag_word(int dx, int dy, int tilesX) { return ((size_t)(dy >> 4) * tilesX + (dx >> 4)) * 4 + ((dy & 15) >> 2); }

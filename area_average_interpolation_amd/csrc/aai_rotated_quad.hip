@@ -381,7 +381,8 @@ hipError_t launch_quad_typed(const RotLaunch &r, const QuadMap &m, const T *src,
         default: return launch_quad_multi_win<T, 8>(r, q, m, src, sv, dst, dv, batch, skipMasks, stream);
         }
     }
-    switch (q.win) {
+    switch (r.mode == AAI_MODE_FAST ? q.winFast : q.win) {
+    case 2: return launch_quad_win<T, 2>(r, q, m, src, sv, dst, dv, batch, skipMasks, stream);
     case 3: return launch_quad_win<T, 3>(r, q, m, src, sv, dst, dv, batch, skipMasks, stream);
     case 4: return launch_quad_win<T, 4>(r, q, m, src, sv, dst, dv, batch, skipMasks, stream);
     case 5: return launch_quad_win<T, 5>(r, q, m, src, sv, dst, dv, batch, skipMasks, stream);
@@ -448,8 +449,8 @@ hipError_t launch_quad_scan(const RotLaunch &r, unsigned long long *laneMasks, u
         else if (q.hiPrec) hipLaunchKernelGGL((aai_quad_scan_kernel<W, true>), grid, dim3(kQuadBlock), 0, stream, r, q, laneMasks, counter, t0); \
         else hipLaunchKernelGGL((aai_quad_scan_kernel<W, false>), grid, dim3(kQuadBlock), 0, stream, r, q, laneMasks, counter, t0);            \
         break;
-        switch (q.win < 3 ? 3 : (q.win > 8 ? 8 : q.win)) {
-            AAI_SCAN_WIN(3) AAI_SCAN_WIN(4) AAI_SCAN_WIN(5) AAI_SCAN_WIN(6) AAI_SCAN_WIN(7) AAI_SCAN_WIN(8)
+        switch (r.mode == AAI_MODE_FAST ? q.winFast : (q.win < 3 ? 3 : (q.win > 8 ? 8 : q.win))) {
+            AAI_SCAN_WIN(2) AAI_SCAN_WIN(3) AAI_SCAN_WIN(4) AAI_SCAN_WIN(5) AAI_SCAN_WIN(6) AAI_SCAN_WIN(7) AAI_SCAN_WIN(8)
         }
 #undef AAI_SCAN_WIN
         const hipError_t e = hipGetLastError();

@@ -263,7 +263,7 @@ def spawn_ranks(n, argv, deadline_s):
 
 
 # ---- HBM traffic of the dominant kernel, measured by this run ---------------------------------------------------------------
-def measure_traffic(argv_child, timeout_s=240.0):
+def measure_traffic(argv_child, steady, timeout_s=240.0):
     """Two child passes of the same workload under rocprofv3, one counter each (FETCH_SIZE takes 3 of the 4 TCC slots,
     WRITE_SIZE 2: MI355X_MICROARCH.md "rocprofv3 PMC slots"), started BEFORE this process touches the GPU.  Returns
     (bytes per launch of the kernel with the most launches, description) or (None, reason).  FETCH_SIZE / WRITE_SIZE are in
@@ -273,7 +273,6 @@ def measure_traffic(argv_child, timeout_s=240.0):
     import glob
     import shutil
     import tempfile
-    from collections import defaultdict
     exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
     if exe is None:
         return None, "rocprofv3 not found"
@@ -293,15 +292,20 @@ def measure_traffic(argv_child, timeout_s=240.0):
                 return None, "rocprofv3 --pmc %s pass timed out" % counter
             if r.returncode != 0:
                 return None, "rocprofv3 --pmc %s pass failed (%d): %s" % (counter, r.returncode, (r.stderr or "")[-200:].replace("\n", " "))
-            acc = defaultdict(list)
+            rows = []
             for f in glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True):
                 for row in csv.DictReader(open(f)):
                     if row.get("Counter_Name") == counter and "aai_" in row.get("Kernel_Name", "") and "synth" not in row["Kernel_Name"]:
-                        acc[(row["Kernel_Name"], row.get("Grid_Size"), row.get("Workgroup_Size"))].append(float(row["Counter_Value"]))
-            if not acc:
+                        rows.append((int(row["Dispatch_Id"]), row["Kernel_Name"], row.get("Grid_Size"), float(row["Counter_Value"])))
+            if not rows:
                 return None, "no %s rows in the rocprofv3 output" % counter
-            key = max(acc, key=lambda k: len(acc[k]))            # the steady launch shape: the one with most launches
-            got[counter] = (key[0], len(acc[key]), sum(acc[key]) / len(acc[key]))
+            # the steady state: the LAST dispatches of the pass (the child runs `steady` timed launches after its warm-up; a
+            # fresh plan's launch-shape measurement comes first and uses other shapes and fewer images)
+            rows.sort()
+            tail = [r for r in rows[-steady:] if r[1] == rows[-1][1] and r[2] == rows[-1][2]]
+            if len(tail) < max(2, steady // 2):
+                return None, "the last dispatches of the %s pass do not share one launch shape" % counter
+            got[counter] = (tail[-1][1], len(tail), sum(r[3] for r in tail) / len(tail))
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
     (kf, nf, fetch), (kw, nw, write) = got["FETCH_SIZE"], got["WRITE_SIZE"]
@@ -689,7 +693,7 @@ def main():
             not args.force_dist and args.shard == "batch" and os.environ.get("AAI_BENCH_TRAFFIC", "1") != "0"):
         child = ["--traffic-child", "--traffic", "off", "--configs", "off", "--no-cpu-baseline", "--workload", args.workload, "--batch", str(args.batch),
                  "--steps", "8", "--warmup", "2", "--policy", args.policy, "--src-dtype", args.src_dtype] + (["--custom", args.custom] if args.custom else [])
-        args.traffic_bytes, args.traffic_note = measure_traffic(child)
+        args.traffic_bytes, args.traffic_note = measure_traffic(child, steady=8)
     worker(args)
 
 

@@ -399,13 +399,25 @@ static void emu_rotated(const Geometry &g, const aai_request &rq, const float *i
                 // the GPU's production pass for generic pixels: fp32, relative to the nearest virtual pixel
                 float value = 0.f;
                 bool done;
-                switch (qc.win) {
-                case 3: done = fastQuad ? emu_quad_fast_pixel<3>(qc, r, img, srcStride, px, py, value) : emu_quad_pixel<3>(qc, r, img, srcStride, px, py, value); break;
-                case 4: done = fastQuad ? emu_quad_fast_pixel<4>(qc, r, img, srcStride, px, py, value) : emu_quad_pixel<4>(qc, r, img, srcStride, px, py, value); break;
-                case 5: done = fastQuad ? emu_quad_fast_pixel<5>(qc, r, img, srcStride, px, py, value) : emu_quad_pixel<5>(qc, r, img, srcStride, px, py, value); break;
-                case 6: done = fastQuad ? emu_quad_fast_pixel<6>(qc, r, img, srcStride, px, py, value) : emu_quad_pixel<6>(qc, r, img, srcStride, px, py, value); break;
-                case 7: done = fastQuad ? emu_quad_fast_pixel<7>(qc, r, img, srcStride, px, py, value) : emu_quad_pixel<7>(qc, r, img, srcStride, px, py, value); break;
-                default: done = fastQuad ? emu_quad_fast_pixel<8>(qc, r, img, srcStride, px, py, value) : emu_quad_pixel<8>(qc, r, img, srcStride, px, py, value); break;
+                if (fastQuad) {
+                    switch (qc.winFast) {
+                    case 2: done = emu_quad_fast_pixel<2>(qc, r, img, srcStride, px, py, value); break;
+                    case 3: done = emu_quad_fast_pixel<3>(qc, r, img, srcStride, px, py, value); break;
+                    case 4: done = emu_quad_fast_pixel<4>(qc, r, img, srcStride, px, py, value); break;
+                    case 5: done = emu_quad_fast_pixel<5>(qc, r, img, srcStride, px, py, value); break;
+                    case 6: done = emu_quad_fast_pixel<6>(qc, r, img, srcStride, px, py, value); break;
+                    case 7: done = emu_quad_fast_pixel<7>(qc, r, img, srcStride, px, py, value); break;
+                    default: done = emu_quad_fast_pixel<8>(qc, r, img, srcStride, px, py, value); break;
+                    }
+                } else {
+                    switch (qc.win) {
+                    case 3: done = emu_quad_pixel<3>(qc, r, img, srcStride, px, py, value); break;
+                    case 4: done = emu_quad_pixel<4>(qc, r, img, srcStride, px, py, value); break;
+                    case 5: done = emu_quad_pixel<5>(qc, r, img, srcStride, px, py, value); break;
+                    case 6: done = emu_quad_pixel<6>(qc, r, img, srcStride, px, py, value); break;
+                    case 7: done = emu_quad_pixel<7>(qc, r, img, srcStride, px, py, value); break;
+                    default: done = emu_quad_pixel<8>(qc, r, img, srcStride, px, py, value); break;
+                    }
                 }
                 if (done) { *out = value; ++g_quadPixels; continue; }
                 ++g_quadUncertain;
