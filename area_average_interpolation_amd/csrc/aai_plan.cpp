@@ -206,12 +206,15 @@ QuadMap make_quad_map(const Geometry &g, int64_t rowStride, int srcRow0, int cha
 void rotated_band_source_rows(const Geometry &g, int row0, int row1, bool sampler, int &srcRow0, int &srcRow1)
 {
     // virtual-lattice bounding box of the band: centres are affine in (dx,dy), so its four corner pixels bound it
-    // area / fast kernels reach half a rotated dst pixel (+1); the samplers' taps reach 2 original pixels
-    const double hb = 0.5 * g.side * (std::fabs(g.cs) + std::fabs(g.sn)) + 1.0 + (sampler ? 3.0 * g.scale : 0.0);
+    // area / fast kernels reach half a rotated dst pixel (+1); the samplers' taps reach 2 original pixels.
+    // The cell kernel (aai_rot_cell.hpp) also evaluates the cells of dst row `row1` and dst column dW (their N / W parts
+    // belong to the band's last row / column) and fetches whole lattice windows around ZONE centres, which sit up to
+    // (c + s) / 2 < 0.71 beside the pixel centre: the box therefore spans cells [0, dW] x [row0, row1] and reaches one more pixel.
+    const double hb = 0.5 * g.side * (std::fabs(g.cs) + std::fabs(g.sn)) + 2.0 + (sampler ? 3.0 * g.scale : 0.0);
     double minX = 1e300, maxX = -1e300, minY = 1e300, maxY = -1e300;
     for (int c = 0; c < 4; ++c) {
         double px, py;
-        dst_centre(g, (c & 1) ? g.dW - 1 : 0, (c & 2) ? row1 - 1 : row0, px, py);
+        dst_centre(g, (c & 1) ? (sampler ? g.dW - 1 : g.dW) : 0, (c & 2) ? (sampler ? row1 - 1 : row1) : row0, px, py);
         minX = std::min(minX, px); maxX = std::max(maxX, px); minY = std::min(minY, py); maxY = std::max(maxY, py);
     }
     auto clampi = [](double v, int lo, int hi) { return (int)std::min((double)hi, std::max((double)lo, v)); };

@@ -698,6 +698,36 @@ void aai_emu_force_general(int on) { g_forceGeneral = on; }
 void aai_emu_use_quad(int on) { g_useQuad = on; }
 void aai_emu_use_cell(int on) { g_useCell = on; }
 
+// Do the source rows aai_band_source_rows reports for dst rows [r0, r1) hold every pixel the cell kernel FETCHES for that band
+// (the staged windows of cells [0, dW] x [r0, r1], clamped to the lattice like QuadSrc::issue clamps them)?  Returns the number
+// of window pixels outside [srcRow0, srcRow1), or -1 when the cell formulation does not serve the request.
+long aai_emu_cell_band_cover(const aai_request *rq, int r0, int r1)
+{
+    Geometry g; std::string msg;
+    if (make_geometry(*rq, g, msg) != AAI_OK) return -2;
+    const RotLaunch r = make_rot_launch(g, rq->mode, rq->policy);
+    if (!r.cell) return -1;
+    int a = 0, b = 0;
+    rotated_band_source_rows(g, r0, r1, false, a, b);
+    const CellConsts<float> z = make_cell_consts<float>(r.side, r.c, r.s);
+    long outside = 0;
+    for (int cy = r0; cy <= r1; ++cy)
+        for (int cx = 0; cx <= r.dW; ++cx) {
+            int Zx, Zy; double dfx, dfy;
+            if (!cell_anchor(r, cell_column(r, z, cx), cy, Zx, Zy, dfx, dfy)) continue;
+            const int xg0 = Zx + (int)std::ceil((float)dfx - z.hbz), yg0 = Zy + (int)std::ceil((float)dfy - z.hbz);
+            if (xg0 > r.mW - 1 || xg0 + z.win - 1 < 0 || yg0 > r.mH - 1 || yg0 + z.win - 1 < 0) continue;      // whole window off the lattice: nothing is fetched
+            for (int j = 0; j < z.win; ++j)
+                for (int i = 0; i < z.win; ++i) {
+                    const int X = std::min(std::max(xg0 + i, 0), r.mW - 1), Y = std::min(std::max(yg0 + j, 0), r.mH - 1);
+                    const int64_t off = virt_offset(r, X, Y, /*rowStride*/ 1 << 20);
+                    const int row = (int)(off >> 20);
+                    if (row < a || row >= b) ++outside;
+                }
+        }
+    return outside;
+}
+
 // The host-side class verification of an axis-aligned plan (aai_plan.cpp: axis_verify_by_class) against the per-pixel scan
 // it replaces (aai_axis_verify_kernel = axis_pixel_differs for every dst pixel).  Returns -1 when the geometry does not
 // qualify (inexact arithmetic), else the number of dst pixels on which the two disagree; counts of flagged pixels out.

@@ -622,6 +622,33 @@ def test_fp32_replays_on_the_reference_default_call(aai, hostemu, po, refdefault
             hook(0)
 
 
+def test_band_source_rows_hold_every_window_the_cell_kernel_fetches(aai, hostemu):
+    """Row bands hand the kernels a buffer with only the source rows aai_band_source_rows reports.  The cell
+    kernel evaluates one more cell row and column than the band has dst rows and columns, and fetches whole lattice windows
+    around zone centres: every pixel of those windows must lie inside the reported rows (a GPU fuzz run of round 3 faulted
+    on exactly that).  All quadrants, up- and down-sampling, bands at the top, in the middle and at the bottom."""
+    import ctypes
+    rng = np.random.default_rng(8)
+    checked = 0
+    for k in range(160):
+        W, H = int(rng.integers(20, 140)), int(rng.integers(20, 140))
+        sr = float(rng.uniform(0.5, 5.0))
+        dr = float(rng.uniform(0.5, 2.5))
+        ang = float(rng.uniform(1.0, 89.0)) + 90.0 * (k % 4)
+        iso = (float(rng.uniform(-3, W + 3)), float(rng.uniform(-3, H + 3)))
+        rq = aai.make_request(W, H, sr, dr, iso, ang, mode=1)
+        rc, msg, lay = aai.query(rq)
+        if rc != 0 or lay.dst_height < 32:
+            continue
+        for _ in range(3):
+            r0 = 16 * int(rng.integers(0, lay.dst_height // 16))
+            r1 = int(rng.integers(r0 + 1, lay.dst_height + 1))
+            out = hostemu.aai_emu_cell_band_cover(ctypes.byref(rq), r0, r1)
+            assert out in (0, -1), (W, H, sr, dr, ang, iso, r0, r1, out)
+            checked += out == 0
+    assert checked > 150, checked
+
+
 def test_cell_fp32_replay_against_oracle_at_larger_sizes(aai, hostemu, po):
     """... and against the oracle at sizes where border pixels no longer dominate: BASELINE config 3's and 5's geometries,
     all quadrants, both policies, near-axis rotations (hiPrec); few pixels left to the double-precision pass."""
@@ -711,20 +738,21 @@ def test_quad_accuracy_where_dst_values_are_far_below_their_neighbours(aai, host
         (119, 58, 0.8158969581426692, 1.7949733079138723, 287.5, (59.0, 28.5), 0),
         (128, 128, 1.0, 4.0, 45.0, None, 0),
     ]
-    hostemu.aai_emu_use_quad(1)
-    try:
-        for (W, H, sr, dr, ang, iso, policy) in cases:
-            iso = iso or ((W - 1) / 2, (H - 1) / 2)
-            worst = 0.0
-            for seed in range(6):
-                src = np.random.default_rng(seed).integers(0, 256, size=(H, W)).astype(np.float32)      # 8-bit noise: a 1 beside a 255
-                gold = po.oracle_run(po.MODE_EXACT, src.astype(np.float64), sr, dr, iso, ang, policy=policy).dst
-                out, _ = hostemu.resample(aai.make_request(W, H, sr, dr, iso, ang, mode=1, policy=policy), src)
-                assert hostemu.quad_stats()[0] > 0
-                worst = max(worst, float(rel_err(out, gold, floor=0.256).max()))
-            assert worst <= 4e-6, (W, H, sr, dr, ang, worst)
-    finally:
-        hostemu.aai_emu_use_quad(0)
+    for hook in (hostemu.aai_emu_use_quad, hostemu.aai_emu_use_cell):            # both fp32 formulations
+        hook(1)
+        try:
+            for (W, H, sr, dr, ang, iso, policy) in cases:
+                iso = iso or ((W - 1) / 2, (H - 1) / 2)
+                worst = 0.0
+                for seed in range(6):
+                    src = np.random.default_rng(seed).integers(0, 256, size=(H, W)).astype(np.float32)      # 8-bit noise: a 1 beside a 255
+                    gold = po.oracle_run(po.MODE_EXACT, src.astype(np.float64), sr, dr, iso, ang, policy=policy).dst
+                    out, _ = hostemu.resample(aai.make_request(W, H, sr, dr, iso, ang, mode=1, policy=policy), src)
+                    assert hostemu.quad_stats()[0] > 0
+                    worst = max(worst, float(rel_err(out, gold, floor=0.256).max()))
+                assert worst <= 4e-6, (W, H, sr, dr, ang, worst)
+        finally:
+            hook(0)
 
 
 def test_quad_serves_the_baseline_rotated_configs(aai, hostemu):

@@ -1,5 +1,5 @@
 for cell in 0 1; do for b in 1 2 4 8; do
-AAI_CELL=$cell timeout -k 10 240 python bench.py --workload cfg3 --no-cpu-baseline --steps 5 --warmup 1 --batch $b --min-seconds 0.5 2>/dev/null | python -c "
+AAI_CELL=$cell timeout -k 10 240 python bench.py --workload cfg3 --no-cpu-baseline --traffic off --configs off --steps 5 --warmup 1 --batch $b --min-seconds 0.5 2>/dev/null | python -c "
 import json,sys
 d=json.loads(sys.stdin.read()); r=d['roofline']
 print('cfg3 cell=$cell batch=$b  %9.1f us/launch  %9.1f us/image  %s' % (r['kernel_ms_per_launch']*1e3, r['kernel_ms_per_launch']*1e3/$b, r['kernel']))"

@@ -21,10 +21,10 @@ worst, bad, tail = 0.0, 0, 0
 
 
 def fp32_tail(e, kernel, run_double):
-    """An error between 1e-5 and 3e-5 from an fp32 quad kernel on a dst value far below its neighbours is the documented
+    """An error between 1e-5 and 3e-5 from an fp32 quad / cell kernel on a dst value far below its neighbours is the documented
     tail of the fp32 formulation (include/aai.h: AAI_POLICY_DOUBLE_PRECISION), provided the double-precision request
     of the same case is exact to 1e-6."""
-    return e <= 3e-5 and "quad" in kernel and run_double() <= 1e-6
+    return e <= 3e-5 and ("quad" in kernel or "cell" in kernel) and run_double() <= 1e-6
 
 
 for k in range(N):
@@ -62,9 +62,9 @@ for k in range(N):
             rc2, _, d2, _, _ = aai.resample_host(src, sr, dr, iso, ang, mode=mode, policy=policy | L.POLICY_DOUBLE_PRECISION)
             return (np.abs(d2 - gold.dst) / np.maximum(np.abs(gold.dst), 1e-3 * scale)).max() if rc2 == 0 else 1.0
         if 1e-5 < e and not zm and mode in (1, 2) and fp32_tail(e, aai.last_kernel(), again):
+            # counted separately AND as a failure: include/aai.h promises 1e-5, and a case past it is a miss whatever the cause
             tail += 1
-            print("fp32 tail case", k, dict(W=W, H=H, sr=sr, dr=dr, ang=ang, mode=mode, policy=policy, dt=str(dt)), "err", e)
-            e = 0.0
+            print("fp32 tail case (exact under AAI_POLICY_DOUBLE_PRECISION)", k, dict(W=W, H=H, sr=sr, dr=dr, ang=ang, mode=mode, policy=policy, dt=str(dt)), "err", e)
         worst = max(worst, e)
         if e > REPORT:
             print("near the bar: case", k, dict(W=W, H=H, sr=sr, dr=dr, ang=ang, iso=iso, mode=mode, policy=policy, dt=str(dt)), "err", e, aai.last_kernel())
@@ -89,8 +89,7 @@ for k in range(N):
                     return (np.abs(d2[:, :, c] - g) / np.maximum(np.abs(g), 1e-3 * scale)).max() if rc2 == 0 else 1.0
                 if 1e-5 < e and fp32_tail(e, aai.last_kernel(), again):
                     tail += 1
-                    print("fp32 tail case", k, dict(W=W, H=H, sr=sr, dr=dr, ang=ang, mode=mode, policy=policy, dt=str(dt), C=C, c=c), "err", e)
-                    e = 0.0
+                    print("fp32 tail case (exact under AAI_POLICY_DOUBLE_PRECISION)", k, dict(W=W, H=H, sr=sr, dr=dr, ang=ang, mode=mode, policy=policy, dt=str(dt), C=C, c=c), "err", e)
                 worst = max(worst, e)
                 if e > REPORT:
                     print("near the bar: case", k, dict(W=W, H=H, sr=sr, dr=dr, ang=ang, iso=iso, mode=mode, policy=policy, dt=str(dt), C=C, c=c), "err", e, aai.last_kernel())
@@ -111,5 +110,5 @@ for k in range(N):
         if not np.array_equal(bd.cpu().numpy(), dst[r0:r1]):
             bad += 1
             print("BAND MISMATCH case", k, dict(W=W, H=H, sr=sr, dr=dr, ang=ang, iso=iso, mode=mode), r0, r1, a, b)
-print("cases", N, "mismatching", bad, "worst relative error", worst, "| fp32-tail cases (1e-5 < err <= 3e-5, exact under AAI_POLICY_DOUBLE_PRECISION):", tail)
+print("cases", N, "mismatching", bad, "worst relative error", worst, "| of the mismatches, fp32-tail cases (1e-5 < err <= 3e-5, exact under AAI_POLICY_DOUBLE_PRECISION):", tail)
 sys.exit(1 if bad else 0)

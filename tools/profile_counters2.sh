@@ -1,11 +1,13 @@
 #!/bin/bash
 # SQ counters (two passes) of one bench.py workload; prints per-kernel means.  usage: tools/profile_counters2.sh <tag> <bench args...>
+# (a profiler preload initialises the GPU in the process it wraps: bench.py must not self-launch ranks from there)
+for a in "$@"; do if [ "$a" = "--gpus" ]; then echo "$0 refuses --gpus: profile one rank (bench.py would have to exec workers from a GPU-initialised process)" >&2; exit 2; fi; done
 TAG=$1; shift
 OUT=gpurun_out/pmc2_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
-rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_LEVEL_WAVES SQ_IFETCH --kernel-trace --output-format csv -d $OUT/a -- python3 bench.py --no-cpu-baseline --steps 3 --warmup 1 --repeats 1 "$@" > $OUT/a.json 2> $OUT/a.err
-rocprofv3 --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_SCA SQ_INST_CYCLES_SALU SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_LDS SQ_THREAD_CYCLES_VALU --kernel-trace --output-format csv -d $OUT/b -- python3 bench.py --no-cpu-baseline --steps 3 --warmup 1 --repeats 1 "$@" > $OUT/b.json 2> $OUT/b.err
+rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_LEVEL_WAVES SQ_IFETCH --kernel-trace --output-format csv -d $OUT/a -- python3 bench.py --no-cpu-baseline --traffic off --configs off --steps 3 --warmup 1 --repeats 1 "$@" > $OUT/a.json 2> $OUT/a.err
+rocprofv3 --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_SCA SQ_INST_CYCLES_SALU SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_LDS SQ_THREAD_CYCLES_VALU --kernel-trace --output-format csv -d $OUT/b -- python3 bench.py --no-cpu-baseline --traffic off --configs off --steps 3 --warmup 1 --repeats 1 "$@" > $OUT/b.json 2> $OUT/b.err
 python3 - $OUT <<'PY'
 import csv, glob, sys, collections
 out = sys.argv[1]

@@ -1,5 +1,7 @@
 #!/bin/bash
 # rocprofv3 --kernel-trace of one bench.py workload; prints the per-kernel average durations.  usage: tools/trace_one.sh <tag> <bench args...>
+# (a profiler preload initialises the GPU in the process it wraps: bench.py must not self-launch ranks from there)
+for a in "$@"; do if [ "$a" = "--gpus" ]; then echo "$0 refuses --gpus: profile one rank (bench.py would have to exec workers from a GPU-initialised process)" >&2; exit 2; fi; done
 TAG=$1; shift
 OUT=gpurun_out/trace_$TAG
 mkdir -p $OUT
