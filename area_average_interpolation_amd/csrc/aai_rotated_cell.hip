@@ -4,13 +4,20 @@
 // Replaces Source.cpp:413-579 + 986-1431.  One lane per CELL of the dst grid (a dst pixel plus its top-left grid vertex):
 // the lane evaluates the virtual source pixels whose centres lie in the cell's zone -- L^2 of them, every source pixel of
 // the image exactly once -- and splits each one's area between the (up to four) dst pixels around the vertex.  A wave owns
-// 64 consecutive cells of a dst row and walks DOWN the rows of its strip:
+// a tile of TW x (64 / TW) cells per iteration and walks DOWN the rows of its strip:
 //   dst (x, y) = own(x, y) + W(x + 1, y) + N(x, y + 1) + NW(x + 1, y + 1)
-// so the W / NW parts come from the next lane (one cross-lane shift each) and the N / NW parts from the next iteration (the
-// own + W sum waits in two registers); lanes 0..62 store, i.e. a wave yields 63 columns x `rows` rows from 64 x (rows + 1)
-// cell evaluations.  No barrier, no atomics; the window of pixel values is staged per lane exactly as in the quad kernel
-// (aai_quad_src.hpp).  Rows of a strip whose cells all miss the image (the corners of a rotated canvas) cost one
-// wave-uniform test.
+// so the W / NW parts come from the next lane (one DPP shift each), the N / NW parts from the tile's next row (lane + TW) or,
+// for the tile's last row, from the next iteration (the own + W sum waits in two registers); the last lane of every tile row
+// only feeds its left neighbour, i.e. a wave yields TW - 1 columns x `rows` rows from TW x (rows + 1) cell evaluations.
+// No barrier, no atomics; the window of pixel values is staged per lane exactly as in the quad kernel (aai_quad_src.hpp).
+// Rows whose cells all miss the image (the corners of a rotated canvas) cost one wave-uniform test.
+// Tile shape: the walk is written for TW x (64 / TW) tiles; 64 x 1 ships.  With 64 x 1 a wave's footprint at config 3 is a
+// slanted line 190 source columns long and every 128-byte line of it is touched again in each of the next ~5 iterations, by
+// which time the ~900 waves of an XCD have pushed it out of the 4 MiB L2: 8.4 M 128-byte requests on the memory side = 4.0 x
+// the source.  16 x 4 tiles cut that to 3.0 M requests (1.46 x, below the quad kernel's 1.8 x) -- and run no faster (222 vs 216
+// us; 5.6 vs 4.4 ms at config 5): the kernel is bound by vector-instruction issue (1.3e8 instructions x ~4 cycles / 1024
+// SIMDs = its duration), the Infinity Cache absorbs the re-reads, and 16-wide rows lose one column in 16 to the halo instead
+// of one in 64.  AAI_CELL_TW=16 at build time (-DAAI_CELL_TILE16) brings the variant back; profiles/r03_cell_kernel.txt.
 //
 // Decisions are left to double precision as in the quad kernel: aai_cell_scan_kernel runs the same code without pixel loads
 // once per geometry and flags every dst pixel fed by a cell with a decision too close to its threshold (or with too little
@@ -25,15 +32,16 @@ namespace aai {
 
 namespace {
 
-constexpr int kCellCols = 63;        // dst columns a wave completes (its 64th cell only feeds column 62)
-
-// lane i <- lane i + 1 (lane 63 gets 0: it never stores): one DPP move across the whole wave (wave_shl:1, a gfx9 control)
-// instead of a round trip through the LDS crossbar (ds_bpermute) at the end of every row
-__device__ __forceinline__ float from_next_lane(float v)
+// lane i <- lane i + 1 within a tile row of TW lanes (the row's last lane gets 0: it never stores): one DPP move
+// (wave_shl:1 across the wave, a gfx9 control; row_shl:1 within 16 lanes) instead of a round trip through the LDS crossbar
+template <int TW>
+__device__ __forceinline__ int from_next_lane_bits(int v)
 {
-    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x130, 0xf, 0xf, false));
+    if (TW == 64) return __builtin_amdgcn_update_dpp(0, v, 0x130, 0xf, 0xf, false);      // wave_shl:1
+    return __builtin_amdgcn_update_dpp(0, v, 0x101, 0xf, 0xf, false);                     // row_shl:1 (rows of 16 lanes)
 }
-__device__ __forceinline__ int from_next_lane(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x130, 0xf, 0xf, false); }
+template <int TW> __device__ __forceinline__ float from_next_lane(float v) { return __int_as_float(from_next_lane_bits<TW>(__float_as_int(v))); }
+template <int TW> __device__ __forceinline__ int from_next_lane(int v) { return from_next_lane_bits<TW>(v); }
 
 // waves per SIMD the staged windows leave room for: WIN * WIN KiB of LDS per 256-lane block, 160 KiB per CU
 constexpr int cell_waves_per_simd(int win) { return 160 / (win * win) >= 8 ? 8 : 160 / (win * win); }
@@ -45,7 +53,47 @@ constexpr int cell_min_waves(int win) { return win <= 4 ? 6 : (cell_waves_per_si
 __device__ __forceinline__ size_t flag_word(int dx, int dy, int tilesX) { return ((size_t)(dy >> 4) * tilesX + (dx >> 4)) * 4 + ((dy & 15) >> 2); }
 __device__ __forceinline__ int flag_bit(int dx, int dy) { return ((dy & 3) << 4) | (dx & 15); }
 
-template <typename T, int WIN, bool SCALED, bool HP>
+// The walk both kernels share.  Per iteration every lane evaluates one cell (eval(cx, cy, sA, sVA) -> this cell is
+// uncertain, SCAN only) and finishes at most one dst pixel: emit(px, py, A, VA, uncertain).  rowsPerStrip is a multiple of
+// TR = 64 / TW.
+template <int TW, typename Eval, typename Emit>
+__device__ __forceinline__ void cell_walk(int dW, int x0, int y0, int y1, int lane, Eval eval, Emit emit)
+{
+    constexpr int TR = 64 / TW;
+    const int lx = lane & (TW - 1), ly = lane / TW;
+    const int cx = x0 + lx;
+    const bool column = lx < TW - 1 && cx < dW;                 // this lane's column is one the wave completes
+    float carryA = 0.f, carryVA = 0.f;                           // own + W of the tile's last row, waiting for the next iteration
+    int carryU = 0;
+    for (int yb = y0; yb <= y1; yb += TR) {
+        const int cy = yb + ly;
+        float sA[4] = {0.f, 0.f, 0.f, 0.f}, sVA[4] = {0.f, 0.f, 0.f, 0.f};
+        int unc = 0;
+        if (cx <= dW && cy <= y1) unc = eval(cx, cy, sA, sVA) ? 1 : 0;
+        const float ownA = sA[CELL_O] + from_next_lane<TW>(sA[CELL_W]), ownVA = sVA[CELL_O] + from_next_lane<TW>(sVA[CELL_W]);
+        const float belowA = sA[CELL_N] + from_next_lane<TW>(sA[CELL_NW]), belowVA = sVA[CELL_N] + from_next_lane<TW>(sVA[CELL_NW]);
+        const int rowU = unc | from_next_lane<TW>(unc);          // the two cells of this tile row that feed column cx
+        if (TR == 1) {
+            // the row above is finished by this iteration's N / NW parts
+            if (yb > y0 && column) emit(cx, cy - 1, carryA + belowA, carryVA + belowVA, carryU | rowU);
+            carryA = ownA; carryVA = ownVA; carryU = rowU;
+        } else {
+            // the tile's last row of the PREVIOUS iteration (held by the lanes of row TR - 1) is finished by this iteration's
+            // first row; every other row by the row below it in this tile
+            const int up = (lane + 64 - (TR - 1) * TW) & 63, down = (lane + TW) & 63;
+            const float topA = __shfl(belowA, up), topVA = __shfl(belowVA, up);
+            const int topU = __shfl(rowU, up);
+            const float nextA = __shfl(belowA, down), nextVA = __shfl(belowVA, down);
+            const int nextU = __shfl(rowU, down);
+            if (ly == TR - 1) {
+                if (yb > y0 && column) emit(cx, yb - 1, carryA + topA, carryVA + topVA, carryU | topU);
+                carryA = ownA; carryVA = ownVA; carryU = rowU;
+            } else if (column && cy < y1) emit(cx, cy, ownA + nextA, ownVA + nextVA, rowU | nextU);
+        }
+    }
+}
+
+template <typename T, int WIN, bool SCALED, bool HP, int TW>
 __global__ __launch_bounds__(kQuadBlock, cell_min_waves(WIN)) void aai_cell_kernel(
     RotLaunch r, QuadConsts<float> q, CellConsts<float> z, QuadMap m, const T *__restrict__ src, ImageView sv, float *__restrict__ dst, ImageView dv,
     const unsigned long long *__restrict__ skipMasks, int tilesX, int rowsPerStrip)
@@ -54,42 +102,30 @@ __global__ __launch_bounds__(kQuadBlock, cell_min_waves(WIN)) void aai_cell_kern
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int x0 = (blockIdx.x * (kQuadBlock / 64) + wave) * kCellCols;
+    const int x0 = (blockIdx.x * (kQuadBlock / 64) + wave) * (TW - 1);
     if (x0 >= r.dW) return;                                   // wave-uniform; no barrier below
-    const int cx = x0 + lane;
     // (row bands in launch order: dealing them from the middle outwards, so that the launch's tail is made of the cheap
     // corner bands, measured 5 % SLOWER at config 3 -- profiles/r03_cell_kernel.txt)
     const int y0 = r.dyBase + blockIdx.y * rowsPerStrip;
     const int y1 = min(y0 + rowsPerStrip, r.dyEnd);           // dst rows [y0, y1); cells rows y0 .. y1
-    const bool stores = lane < kCellCols && cx < r.dW;
-    float *outCol = dst + (int64_t)blockIdx.z * dv.imageStride + cx;
+    float *image = dst + (int64_t)blockIdx.z * dv.imageStride;
     const char *img = reinterpret_cast<const char *>(src + (int64_t)blockIdx.z * sv.imageStride + m.base);
-
-    const CellColumn col = cell_column(r, z, cx);
-    float pendA = 0.f, pendVA = 0.f;
-    for (int cy = y0; cy <= y1; ++cy) {
-        // the row above is finished in this iteration: is its pixel one the plan's scans left to the fix-up pass?
-        bool skip = false;
-        if (skipMasks && cy > y0 && stores) skip = (skipMasks[flag_word(cx, cy - 1, tilesX)] >> flag_bit(cx, cy - 1)) & 1ull;
-
-        float sA[4] = {0.f, 0.f, 0.f, 0.f}, sVA[4] = {0.f, 0.f, 0.f, 0.f};
-        int Zx = 0, Zy = 0;
-        double dfx = 0.0, dfy = 0.0;
-        const bool live = cx <= r.dW && cell_anchor(r, col, cy, Zx, Zy, dfx, dfy);
-        if (live) {
+    const CellColumn col = cell_column(r, z, x0 + (lane & (TW - 1)));
+    cell_walk<TW>(r.dW, x0, y0, y1, lane,
+        [&](int cx, int cy, float (&sA)[4], float (&sVA)[4]) -> bool {
+            int Zx, Zy;
+            double dfx, dfy;
+            if (!cell_anchor(r, col, cy, Zx, Zy, dfx, dfy)) return false;
             QuadSrc<T, WIN, SCALED, true> s;
             s.img = img; s.m = &m; s.mW = r.mW; s.mH = r.mH; s.lds = window; s.tid = tid;
             cell_eval<float, WIN, false, HP>(q, z, Zx, Zy, dfx, dfy, r.mW, r.mH, s, sA, sVA);
-        }
-        const float wA = from_next_lane(sA[CELL_W]), wVA = from_next_lane(sVA[CELL_W]);
-        const float nwA = from_next_lane(sA[CELL_NW]), nwVA = from_next_lane(sVA[CELL_NW]);
-        if (cy > y0 && stores && !skip) {
-            const float A = pendA + (sA[CELL_N] + nwA), VA = pendVA + (sVA[CELL_N] + nwVA);
-            outCol[(int64_t)(cy - 1 - r.dyBase) * dv.rowStride] = A > 0.f ? VA / A : 0.f;         // Source.cpp:577
-        }
-        pendA = sA[CELL_O] + wA;
-        pendVA = sVA[CELL_O] + wVA;
-    }
+            return false;
+        },
+        [&](int px, int py, float A, float VA, int) {
+            // a pixel the plan's scans left to the fix-up pass is not written here
+            if (skipMasks && ((skipMasks[flag_word(px, py, tilesX)] >> flag_bit(px, py)) & 1ull)) return;
+            image[(int64_t)(py - r.dyBase) * dv.rowStride + px] = A > 0.f ? VA / A : 0.f;         // Source.cpp:577
+        });
 }
 
 // Once per geometry: the same walk without pixel loads.  Sets the bit of every dst pixel one of whose four cells has a
@@ -99,51 +135,52 @@ template <int WIN, bool HP>
 __global__ __launch_bounds__(kQuadBlock) void aai_cell_scan_kernel(RotLaunch r, QuadConsts<float> q, CellConsts<float> z, unsigned long long *__restrict__ laneMasks,
                                                                   unsigned *__restrict__ counter, int tilesX, int rowsPerStrip, int band0)
 {
+    constexpr int TW = 64;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int x0 = (blockIdx.x * (kQuadBlock / 64) + wave) * kCellCols;
+    const int x0 = (blockIdx.x * (kQuadBlock / 64) + wave) * (TW - 1);
     if (x0 >= r.dW) return;
-    const int cx = x0 + lane;
     const int y0 = (band0 + blockIdx.y) * rowsPerStrip;
     const int y1 = min(y0 + rowsPerStrip, r.dH);
-    const bool stores = lane < kCellCols && cx < r.dW;
-    const CellColumn col = cell_column(r, z, cx);
-    float pendA = 0.f;
-    int pendU = 0;
-    for (int cy = y0; cy <= y1; ++cy) {
-        float sA[4] = {0.f, 0.f, 0.f, 0.f}, sVA[4] = {0.f, 0.f, 0.f, 0.f};
-        int Zx = 0, Zy = 0;
-        double dfx = 0.0, dfy = 0.0;
-        int unc = 0;
-        if (cx <= r.dW && cell_anchor(r, col, cy, Zx, Zy, dfx, dfy)) {
+    const CellColumn col = cell_column(r, z, x0 + lane);
+    cell_walk<TW>(r.dW, x0, y0, y1, lane,
+        [&](int cx, int cy, float (&sA)[4], float (&sVA)[4]) -> bool {
+            int Zx, Zy;
+            double dfx, dfy;
+            if (!cell_anchor(r, col, cy, Zx, Zy, dfx, dfy)) return false;
             NoSrc s;
-            unc = cell_eval<float, WIN, true, HP>(q, z, Zx, Zy, dfx, dfy, r.mW, r.mH, s, sA, sVA) ? 1 : 0;
-        }
-        const float wA = from_next_lane(sA[CELL_W]), nwA = from_next_lane(sA[CELL_NW]);
-        const int uNext = from_next_lane(unc);
-        if (cy > y0 && stores) {
-            const float A = pendA + (sA[CELL_N] + nwA);
-            if (pendU | unc | uNext | ((A > 0.f && A < q.minArea) ? 1 : 0)) {
-                const unsigned long long bit = 1ull << flag_bit(cx, cy - 1);
-                const unsigned long long old = atomicOr(laneMasks + flag_word(cx, cy - 1, tilesX), bit);
+            return cell_eval<float, WIN, true, HP>(q, z, Zx, Zy, dfx, dfy, r.mW, r.mH, s, sA, sVA);
+        },
+        [&](int px, int py, float A, float, int uncertain) {
+            if (uncertain | ((A > 0.f && A < q.minArea) ? 1 : 0)) {
+                const unsigned long long bit = 1ull << flag_bit(px, py);
+                const unsigned long long old = atomicOr(laneMasks + flag_word(px, py, tilesX), bit);
                 if (!(old & bit)) atomicAdd(counter, 1u);
             }
-        }
-        pendA = sA[CELL_O] + wA;
-        pendU = unc | uNext;
-    }
+        });
 }
 
-template <typename T, int WIN>
-hipError_t launch_cell_win(const RotLaunch &r, const QuadConsts<float> &q, const CellConsts<float> &z, const QuadMap &m, const T *src, ImageView sv,
-                           float *dst, ImageView dv, int batch, const unsigned long long *skipMasks, int rowsPerStrip, hipStream_t stream)
+// tile width per wave (see the header): 64; a build with -DAAI_CELL_TILE16 also holds the 16 x 4 variant, chosen by AAI_CELL_TW=16
+static int cell_tile_width(const QuadMap &)
 {
-    const int strips = (r.dW + kCellCols - 1) / kCellCols;
+#if defined(AAI_CELL_TILE16)
+    static const int forced = [] { const char *e = getenv("AAI_CELL_TW"); return e ? atoi(e) : 0; }();
+    if (forced == 16) return 16;
+#endif
+    return 64;
+}
+
+template <typename T, int WIN, int TW>
+hipError_t launch_cell_tile(const RotLaunch &r, const QuadConsts<float> &q, const CellConsts<float> &z, const QuadMap &m, const T *src, ImageView sv,
+                            float *dst, ImageView dv, int batch, const unsigned long long *skipMasks, hipStream_t stream)
+{
+    const int rowsPerStrip = cell_rows_per_strip(r.dW, r.dyEnd - r.dyBase, batch, TW);
+    const int strips = (r.dW + TW - 2) / (TW - 1);
     const dim3 grid((strips + 3) / 4, (r.dyEnd - r.dyBase + rowsPerStrip - 1) / rowsPerStrip, batch);
     const int tilesX = (r.dW + 15) / 16;
 #define AAI_CELL_LAUNCH(SCALED, HP) \
-    hipLaunchKernelGGL((aai_cell_kernel<T, WIN, SCALED, HP>), grid, dim3(kQuadBlock), 0, stream, r, q, z, m, src, sv, dst, dv, skipMasks, tilesX, rowsPerStrip)
+    hipLaunchKernelGGL((aai_cell_kernel<T, WIN, SCALED, HP, TW>), grid, dim3(kQuadBlock), 0, stream, r, q, z, m, src, sv, dst, dv, skipMasks, tilesX, rowsPerStrip)
     if (m.scale > 1) {
         if (q.hiPrec) AAI_CELL_LAUNCH(true, true); else AAI_CELL_LAUNCH(true, false);
     } else {
@@ -153,34 +190,45 @@ hipError_t launch_cell_win(const RotLaunch &r, const QuadConsts<float> &q, const
     return hipGetLastError();
 }
 
+template <typename T, int WIN>
+hipError_t launch_cell_win(const RotLaunch &r, const QuadConsts<float> &q, const CellConsts<float> &z, const QuadMap &m, const T *src, ImageView sv,
+                           float *dst, ImageView dv, int batch, const unsigned long long *skipMasks, hipStream_t stream)
+{
+#if defined(AAI_CELL_TILE16)
+    if (cell_tile_width(m) == 16) return launch_cell_tile<T, WIN, 16>(r, q, z, m, src, sv, dst, dv, batch, skipMasks, stream);
+#endif
+    (void)cell_tile_width;
+    return launch_cell_tile<T, WIN, 64>(r, q, z, m, src, sv, dst, dv, batch, skipMasks, stream);
+}
+
 template <typename T>
 hipError_t launch_cell_typed(const RotLaunch &r, const QuadMap &m, const T *src, ImageView sv, float *dst, ImageView dv, int batch,
                              const unsigned long long *skipMasks, hipStream_t stream)
 {
     const QuadConsts<float> q = make_quad_consts<float>(r.side, r.c, r.s, r.policy, r.scale);
     const CellConsts<float> z = make_cell_consts<float>(r.side, r.c, r.s);
-    const int rows = cell_rows_per_strip(r.dW, r.dyEnd - r.dyBase, batch);
     switch (z.win) {
-    case 2: return launch_cell_win<T, 2>(r, q, z, m, src, sv, dst, dv, batch, skipMasks, rows, stream);
-    case 3: return launch_cell_win<T, 3>(r, q, z, m, src, sv, dst, dv, batch, skipMasks, rows, stream);
-    case 4: return launch_cell_win<T, 4>(r, q, z, m, src, sv, dst, dv, batch, skipMasks, rows, stream);
-    case 5: return launch_cell_win<T, 5>(r, q, z, m, src, sv, dst, dv, batch, skipMasks, rows, stream);
-    case 6: return launch_cell_win<T, 6>(r, q, z, m, src, sv, dst, dv, batch, skipMasks, rows, stream);
-    case 7: return launch_cell_win<T, 7>(r, q, z, m, src, sv, dst, dv, batch, skipMasks, rows, stream);
-    case 8: return launch_cell_win<T, 8>(r, q, z, m, src, sv, dst, dv, batch, skipMasks, rows, stream);
+    case 2: return launch_cell_win<T, 2>(r, q, z, m, src, sv, dst, dv, batch, skipMasks, stream);
+    case 3: return launch_cell_win<T, 3>(r, q, z, m, src, sv, dst, dv, batch, skipMasks, stream);
+    case 4: return launch_cell_win<T, 4>(r, q, z, m, src, sv, dst, dv, batch, skipMasks, stream);
+    case 5: return launch_cell_win<T, 5>(r, q, z, m, src, sv, dst, dv, batch, skipMasks, stream);
+    case 6: return launch_cell_win<T, 6>(r, q, z, m, src, sv, dst, dv, batch, skipMasks, stream);
+    case 7: return launch_cell_win<T, 7>(r, q, z, m, src, sv, dst, dv, batch, skipMasks, stream);
+    case 8: return launch_cell_win<T, 8>(r, q, z, m, src, sv, dst, dv, batch, skipMasks, stream);
     default: return hipErrorInvalidValue;
     }
 }
 
 }  // namespace
 
-// dst rows a wave walks: a strip of R rows costs R + 1 cell rows, so taller is cheaper -- as long as the launch still has
-// several waves for every SIMD of the chip (1024 SIMDs x ~6 wave slots)
-int cell_rows_per_strip(int dW, int rows, int batch)
+// dst rows a wave walks: a strip of R rows costs R + 1 cell rows (R + 64 / tileWidth for tiles of several rows), so taller is
+// cheaper -- as long as the launch still has several waves for every SIMD of the chip (1024 SIMDs x ~6 wave slots)
+int cell_rows_per_strip(int dW, int rows, int batch, int tileWidth)
 {
     static const int forced = [] { const char *e = getenv("AAI_CELL_ROWS"); return e ? atoi(e) : 0; }();
-    if (forced > 0) return forced;
-    const int64_t strips = ((int64_t)dW + kCellCols - 1) / kCellCols * batch;
+    const int tr = 64 / tileWidth;
+    if (forced > 0) return (forced + tr - 1) / tr * tr;
+    const int64_t strips = ((int64_t)dW + tileWidth - 2) / (tileWidth - 1) * batch;
     int R = 32;
     while (R > 8 && strips * ((rows + R - 1) / R) < 24576) R >>= 1;
     while ((rows + R - 1) / R > 65535) R <<= 1;               // grid.y
@@ -215,7 +263,7 @@ hipError_t launch_cell_scan(const RotLaunch &r, unsigned long long *laneMasks, u
     const QuadConsts<float> q = make_quad_consts<float>(r.side, r.c, r.s, r.policy, r.scale);
     const CellConsts<float> z = make_cell_consts<float>(r.side, r.c, r.s);
     const int rows = 16;
-    const int strips = (r.dW + kCellCols - 1) / kCellCols;
+    const int strips = (r.dW + 62) / 63;                       // the scan walks 64 x 1 tiles
     const int tilesX = (r.dW + 15) / 16;
     const int bands = (r.dH + rows - 1) / rows;
     for (int b0 = 0; b0 < bands; b0 += 65535) {                // grid.y carries at most 65535 bands
