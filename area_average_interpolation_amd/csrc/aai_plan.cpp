@@ -9,6 +9,7 @@
 #include <algorithm>
 #include <cfloat>
 #include <cmath>
+#include <cstdlib>
 
 namespace aai {
 
@@ -158,7 +159,10 @@ RotLaunch make_rot_launch(const Geometry &g, int mode, int policy)
     // Fast mode with replication stays on the line-walking kernel: a dst square then holds one to four centres and that
     // kernel fetches just those, where the window kernel fetches its whole 3 x 3 ... 5 x 5 window (x2 up-sampling at 30
     // degrees 0.69 vs 0.96 ms, x4 at 45 degrees 2.75 vs 4.33 ms: profiles/r02_fast_envelope.txt).
-    if (mode == AAI_MODE_FAST && g.scale > 1) r.quad = 0;
+    {
+        static const bool fastScaled = [] { const char *e = getenv("AAI_FAST_SCALED"); return e && atoi(e) != 0; }();      // experiment
+        if (mode == AAI_MODE_FAST && g.scale > 1 && !fastScaled) r.quad = 0;
+    }
     // Area mode: the cell formulation (aai_rot_cell.hpp) evaluates every (dst, src) pair once instead of once per dst pixel
     r.cell = (r.quad && mode == AAI_MODE_AREA && cell_supported(g.side, c, s)) ? 1 : 0;
     {

@@ -38,11 +38,20 @@ struct QuadSrc {
     T v[WIN * WIN];
     int arranged;                    // STAGED: 0 = v[] is in slot order; else 1 + arrangement of the vector-loaded lines (commit)
 
-    __device__ __forceinline__ void issue(int xg0, int yg0, unsigned long long)
+    // allInside: the caller has established (by a wave vote) that every lane's window lies inside the lattice
+    __device__ __forceinline__ void issue(int xg0, int yg0, unsigned long long, bool allInside = false)
     {
         unsigned colOff[WIN], rowOff[WIN];            // source indices along virtual X / Y first, byte offsets below
         const unsigned sxb = (unsigned)m->strideX * (unsigned)sizeof(T), syb = (unsigned)m->strideY * (unsigned)sizeof(T);
-        if (!SCALED) {
+        if (!SCALED && allInside) {
+            const int bx = m->flipX ? m->nX - 1 - xg0 : xg0, by = m->flipY ? m->nY - 1 - yg0 : yg0;
+            const int sx = m->flipX ? -1 : 1, sy = m->flipY ? -1 : 1;
+#pragma unroll
+            for (int i = 0; i < WIN; ++i) {
+                colOff[i] = (unsigned)(bx + sx * i);
+                rowOff[i] = (unsigned)(by + sy * i);
+            }
+        } else if (!SCALED) {
 #pragma unroll
             for (int i = 0; i < WIN; ++i) {
                 const int X = min(max(xg0 + i, 0), mW - 1), Y = min(max(yg0 + i, 0), mH - 1);
@@ -84,9 +93,8 @@ struct QuadSrc {
         // virtual Y in 1 / 3): fetch each of its WIN lines with one or two vector loads instead of WIN scalar ones -- lanes
         // are L source pixels apart, so every load instruction touches a dozen cache lines and their NUMBER is what the
         // texture path charges for.  Only where no lane of the wave has a clamped (off-image) column or row.
-        const bool inside = xg0 >= 0 && xg0 + WIN <= mW && yg0 >= 0 && yg0 + WIN <= mH;
         arranged = 0;
-        if (!SCALED && sizeof(T) == 4 && __all(inside)) {
+        if (!SCALED && sizeof(T) == 4 && (allInside || __all(xg0 >= 0 && xg0 + WIN <= mW && yg0 >= 0 && yg0 + WIN <= mH))) {
             // (every condition below is wave-uniform: the map is a kernel argument)
             const bool alongX = sxb == (unsigned)sizeof(T);
             const bool rev = alongX ? m->flipX != 0 : m->flipY != 0;      // the window axis runs against memory
@@ -162,7 +170,7 @@ struct QuadSrc {
 
 struct NoSrc {
     __device__ __forceinline__ float reg(int) const { return 1.f; }
-    __device__ __forceinline__ void issue(int, int, unsigned long long) {}
+    __device__ __forceinline__ void issue(int, int, unsigned long long, bool = false) {}
     __device__ __forceinline__ void commit() {}
     __device__ __forceinline__ void at(int, float (&vals)[1]) const { vals[0] = 1.f; }
 };

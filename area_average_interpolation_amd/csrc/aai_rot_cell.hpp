@@ -41,6 +41,13 @@
 
 namespace aai {
 
+// a vote over the lanes of the wave on the GPU; the CPU replay evaluates one cell at a time
+#if defined(__HIP_DEVICE_COMPILE__)
+#define AAI_WAVE_ALL(x) (__all(x) != 0)
+#else
+#define AAI_WAVE_ALL(x) (x)
+#endif
+
 enum CellTarget { CELL_O = 0, CELL_W = 1, CELL_N = 2, CELL_NW = 3 };     // own dst pixel (x, y); (x-1, y); (x, y-1); (x-1, y-1)
 
 template <typename F>
@@ -95,9 +102,11 @@ AAI_HD void cell_cut_small(const QuadConsts<F> &q, F tp, F &exact, F &ref)
 // [-1/2, 1/2].  Source protocol as in quad_pixel (issue / commit / at).  sA[t], sVA[t] = sums of areas and of area x value
 // this cell contributes to target t (CellTarget).  SCAN: src is never touched, every value counts as 1, and the return
 // value says whether a decision of this cell is too close to its threshold for fp32.
+// upOnly: only the parts for the dst pixels ABOVE the cell's row are wanted (the extra cell row below a strip): the interior and
+// left-edge zones, which feed this row only, are skipped (the own / W sums are then incomplete and must not be used).
 template <typename F, int WIN, bool SCAN, bool HP, typename Src>
 AAI_HD bool cell_eval(const QuadConsts<F> &q, const CellConsts<F> &z, int Zx, int Zy, double dfx, double dfy, int mW, int mH, Src &src,
-                      F (&sA)[4], F (&sVA)[4])
+                      F (&sA)[4], F (&sVA)[4], bool upOnly = false)
 {
     typedef typename QuadMask<WIN>::type u64;
     static_assert(WIN >= 1 && WIN <= kQuadMaxWin, "window size");
@@ -116,8 +125,11 @@ AAI_HD bool cell_eval(const QuadConsts<F> &q, const CellConsts<F> &z, int Zx, in
     const F fi0 = ceil(fpx - z.hbz), fj0 = ceil(fpy - z.hbz);
     const int i0 = (int)fi0, j0 = (int)fj0;
     const int xg0 = Zx + i0, yg0 = Zy + j0;
-    u64 valid;
-    {
+    // Away from the image border the whole wave's windows lie inside the lattice: one vote replaces the validity masks here and
+    // the clamps in the loads
+    const bool interior = AAI_WAVE_ALL(xg0 >= 0 && xg0 + WIN <= mW && yg0 >= 0 && yg0 + WIN <= mH);
+    u64 valid = WIN * WIN >= 64 ? ~(u64)0 : (((u64)1 << (WIN * WIN >= 64 ? 0 : WIN * WIN)) - 1);
+    if (!interior) {
         const int ia = xg0 < 0 ? -xg0 : 0, ib = (mW - 1 - xg0 < WIN - 1) ? mW - 1 - xg0 : WIN - 1;
         const int ja = yg0 < 0 ? -yg0 : 0, jb = (mH - 1 - yg0 < WIN - 1) ? mH - 1 - yg0 : WIN - 1;
         if (ia > ib || ja > jb) return false;                                 // the whole window misses the image
@@ -127,7 +139,7 @@ AAI_HD bool cell_eval(const QuadConsts<F> &q, const CellConsts<F> &z, int Zx, in
         for (int j = 0; j < WIN; ++j)
             if (j >= ja && j <= jb) valid |= (u64)cols << (j * WIN);
     }
-    if (!SCAN) src.issue(xg0, yg0, valid);
+    if (!SCAN) src.issue(xg0, yg0, valid, interior);
 
     // zone coordinates (dst frame, relative to the zone's centre) of lattice point (Zx, Zy)
     const F ac = qfma(fpy, q.s, -(fpx * q.c)), bc = -qfma(fpx, q.s, fpy * q.c);
@@ -206,6 +218,7 @@ AAI_HD bool cell_eval(const QuadConsts<F> &q, const CellConsts<F> &z, int Zx, in
         }
     }
 
+    if (upOnly) { mIn = 0; mLeft = 0; }
     // ---- interior: area 1 to the cell's own dst pixel --------------------------------------------------------------------
     while (mIn) {
         const int slot = quad_ctz(mIn);
@@ -308,6 +321,33 @@ AAI_HD bool cell_anchor(const RotLaunch &r, const CellColumn &col, int dy, int &
     if (!(cx > -16.0 && cx < (double)r.mW + 16.0 && cy > -16.0 && cy < (double)r.mH + 16.0)) return false;
     Zx = (int)cx; Zy = (int)cy; dfx = zx - cx; dfy = zy - cy;
     return true;
+}
+
+// Rows of cells that can touch the lattice at all, for the cell columns [xa, xb]: the zone centre is affine in (dx, dy) with
+// positive coefficients L cos, L sin (reduced angle), so each of the four lattice bounds limits dy from one side at one end of
+// the column range.  Conservative (a superset, with a margin of one row): rows outside [lo, hi] contribute nothing to any dst
+// pixel and the kernel does not even compute their anchors -- the corners of a rotated canvas are 36 % of config 3's cells and
+// 50 % of config 5's.  lo > hi: none.
+template <typename F>
+AAI_HD void cell_live_rows(const RotLaunch &r, const CellConsts<F> &z, int xa, int xb, int &lo, int &hi)
+{
+    const double reach = (double)z.hbz + 17.0;                     // the window's half extent, the anchor's slack of 16, rounding
+    const double Lc = r.side * r.cs, Ls = r.side * r.sn;
+    // zone centre of cell (dx, dy): (A0 + dx Lc + dy Ls, B0 - dx Ls + dy Lc)
+    const double u0 = r.fracX * r.side - r.isoX + r.offX, v0 = r.fracY * r.side - r.isoY + r.offY;
+    const double A0 = u0 * r.cs + v0 * r.sn + r.isoX + z.zx, B0 = -u0 * r.sn + v0 * r.cs + r.isoY + z.zy;
+    double a = -1e300, b = 1e300;
+    if (Ls > 0.0) {
+        a = fmax(a, (-reach - A0 - xb * Lc) / Ls);
+        b = fmin(b, ((double)r.mW - 1.0 + reach - A0 - xa * Lc) / Ls);
+    }
+    if (Lc > 0.0) {
+        a = fmax(a, (-reach - B0 + xa * Ls) / Lc);
+        b = fmin(b, ((double)r.mH - 1.0 + reach - B0 + xb * Ls) / Lc);
+    }
+    a = floor(a) - 1.0; b = ceil(b) + 1.0;
+    lo = a < -2147483000.0 ? -2147483000 : (a > 2147483000.0 ? 2147483000 : (int)a);
+    hi = b < -2147483000.0 ? -2147483000 : (b > 2147483000.0 ? 2147483000 : (int)b);
 }
 
 // dst pixel (x, y) from the parts of its four cells, in the order the kernel adds them

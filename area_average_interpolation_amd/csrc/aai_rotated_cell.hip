@@ -46,7 +46,8 @@ template <int TW> __device__ __forceinline__ int from_next_lane(int v) { return 
 // waves per SIMD the staged windows leave room for: WIN * WIN KiB of LDS per 256-lane block, 160 KiB per CU
 constexpr int cell_waves_per_simd(int win) { return 160 / (win * win) >= 8 ? 8 : 160 / (win * win); }
 // ... and the register budget that goes with it: 80 registers (6 waves) up to 4 x 4 windows; from 5 x 5 (25 staged values per
-// lane) 128 registers (4 waves): 96 still spill there
+// lane) 128 registers (4 waves): 96 still spill there.  (8 waves / 64 registers for the small windows: 12-44 bytes of scratch per
+// lane and 14 % SLOWER at config 3, 11 % at config 5.)
 constexpr int cell_min_waves(int win) { return win <= 4 ? 6 : (cell_waves_per_simd(win) > 4 ? 4 : cell_waves_per_simd(win)); }
 
 // flag word / bit of dst pixel (dx, dy) in the 16 x 16 tiling of the plan's scans (one 64-bit word per 16 x 4 pixels)
@@ -56,8 +57,11 @@ __device__ __forceinline__ int flag_bit(int dx, int dy) { return ((dy & 3) << 4)
 // The walk both kernels share.  Per iteration every lane evaluates one cell (eval(cx, cy, sA, sVA) -> this cell is
 // uncertain, SCAN only) and finishes at most one dst pixel: emit(px, py, A, VA, uncertain).  rowsPerStrip is a multiple of
 // TR = 64 / TW.
-template <int TW, typename Eval, typename Emit>
-__device__ __forceinline__ void cell_walk(int dW, int x0, int y0, int y1, int lane, Eval eval, Emit emit)
+// Cell rows outside [liveLo, liveHi] cannot touch the image (cell_live_rows): their iterations only finish the pixels waiting above.
+// look(px, py) runs at the top of the iteration that will finish pixel (px, py) and its result is handed to emit: whatever emit
+// needs from memory (the flag word of the pixel) is requested before the cell is evaluated, not waited for after it.
+template <int TW, typename Look, typename Eval, typename Emit>
+__device__ __forceinline__ void cell_walk(int dW, int x0, int y0, int y1, int liveLo, int liveHi, int lane, Look look, Eval eval, Emit emit)
 {
     constexpr int TR = 64 / TW;
     const int lx = lane & (TW - 1), ly = lane / TW;
@@ -67,6 +71,17 @@ __device__ __forceinline__ void cell_walk(int dW, int x0, int y0, int y1, int la
     int carryU = 0;
     for (int yb = y0; yb <= y1; yb += TR) {
         const int cy = yb + ly;
+        // the pixel this lane finishes in this iteration (if any): the carried row for the tile's last row of lanes
+        const int py = ly == TR - 1 ? yb - 1 : cy;
+        const bool finishes = column && (ly == TR - 1 ? yb > y0 : cy < y1);
+        const auto seen = look(cx, finishes ? py : y0, finishes);
+        if (yb > liveHi || yb + TR - 1 < liveLo) {               // wave-uniform: every cell of this iteration misses the image
+            if (ly == TR - 1) {
+                if (finishes) emit(cx, py, carryA, carryVA, carryU, seen);
+                carryA = 0.f; carryVA = 0.f; carryU = 0;
+            } else if (finishes) emit(cx, py, 0.f, 0.f, 0, seen);
+            continue;
+        }
         float sA[4] = {0.f, 0.f, 0.f, 0.f}, sVA[4] = {0.f, 0.f, 0.f, 0.f};
         int unc = 0;
         if (cx <= dW && cy <= y1) unc = eval(cx, cy, sA, sVA) ? 1 : 0;
@@ -75,7 +90,7 @@ __device__ __forceinline__ void cell_walk(int dW, int x0, int y0, int y1, int la
         const int rowU = unc | from_next_lane<TW>(unc);          // the two cells of this tile row that feed column cx
         if (TR == 1) {
             // the row above is finished by this iteration's N / NW parts
-            if (yb > y0 && column) emit(cx, cy - 1, carryA + belowA, carryVA + belowVA, carryU | rowU);
+            if (finishes) emit(cx, py, carryA + belowA, carryVA + belowVA, carryU | rowU, seen);
             carryA = ownA; carryVA = ownVA; carryU = rowU;
         } else {
             // the tile's last row of the PREVIOUS iteration (held by the lanes of row TR - 1) is finished by this iteration's
@@ -86,9 +101,9 @@ __device__ __forceinline__ void cell_walk(int dW, int x0, int y0, int y1, int la
             const float nextA = __shfl(belowA, down), nextVA = __shfl(belowVA, down);
             const int nextU = __shfl(rowU, down);
             if (ly == TR - 1) {
-                if (yb > y0 && column) emit(cx, yb - 1, carryA + topA, carryVA + topVA, carryU | topU);
+                if (finishes) emit(cx, py, carryA + topA, carryVA + topVA, carryU | topU, seen);
                 carryA = ownA; carryVA = ownVA; carryU = rowU;
-            } else if (column && cy < y1) emit(cx, cy, ownA + nextA, ownVA + nextVA, rowU | nextU);
+            } else if (finishes) emit(cx, py, ownA + nextA, ownVA + nextVA, rowU | nextU, seen);
         }
     }
 }
@@ -111,19 +126,25 @@ __global__ __launch_bounds__(kQuadBlock, cell_min_waves(WIN)) void aai_cell_kern
     float *image = dst + (int64_t)blockIdx.z * dv.imageStride;
     const char *img = reinterpret_cast<const char *>(src + (int64_t)blockIdx.z * sv.imageStride + m.base);
     const CellColumn col = cell_column(r, z, x0 + (lane & (TW - 1)));
-    cell_walk<TW>(r.dW, x0, y0, y1, lane,
+    int liveLo, liveHi;
+    cell_live_rows(r, z, x0, x0 + TW - 1, liveLo, liveHi);     // wave-uniform
+    cell_walk<TW>(r.dW, x0, y0, y1, liveLo, liveHi, lane,
+        [&](int px, int py, bool wanted) -> bool {
+            // is the pixel one the plan's scans left to the fix-up pass?  (requested here, used after the cell is evaluated)
+            return skipMasks && wanted && ((skipMasks[flag_word(px, py, tilesX)] >> flag_bit(px, py)) & 1ull);
+        },
         [&](int cx, int cy, float (&sA)[4], float (&sVA)[4]) -> bool {
             int Zx, Zy;
             double dfx, dfy;
             if (!cell_anchor(r, col, cy, Zx, Zy, dfx, dfy)) return false;
             QuadSrc<T, WIN, SCALED, true> s;
             s.img = img; s.m = &m; s.mW = r.mW; s.mH = r.mH; s.lds = window; s.tid = tid;
-            cell_eval<float, WIN, false, HP>(q, z, Zx, Zy, dfx, dfy, r.mW, r.mH, s, sA, sVA);
+            // (the extra cell row below the strip only feeds the strip's last pixel row: its interior / left-edge zones are skipped)
+            cell_eval<float, WIN, false, HP>(q, z, Zx, Zy, dfx, dfy, r.mW, r.mH, s, sA, sVA, TW == 64 && cy == y1);
             return false;
         },
-        [&](int px, int py, float A, float VA, int) {
-            // a pixel the plan's scans left to the fix-up pass is not written here
-            if (skipMasks && ((skipMasks[flag_word(px, py, tilesX)] >> flag_bit(px, py)) & 1ull)) return;
+        [&](int px, int py, float A, float VA, int, bool skip) {
+            if (skip) return;                                  // a pixel the plan's scans left to the fix-up pass is not written here
             image[(int64_t)(py - r.dyBase) * dv.rowStride + px] = A > 0.f ? VA / A : 0.f;         // Source.cpp:577
         });
 }
@@ -144,7 +165,10 @@ __global__ __launch_bounds__(kQuadBlock) void aai_cell_scan_kernel(RotLaunch r, 
     const int y0 = (band0 + blockIdx.y) * rowsPerStrip;
     const int y1 = min(y0 + rowsPerStrip, r.dH);
     const CellColumn col = cell_column(r, z, x0 + lane);
-    cell_walk<TW>(r.dW, x0, y0, y1, lane,
+    int liveLo, liveHi;
+    cell_live_rows(r, z, x0, x0 + TW - 1, liveLo, liveHi);
+    cell_walk<TW>(r.dW, x0, y0, y1, liveLo, liveHi, lane,
+        [&](int, int, bool) -> int { return 0; },
         [&](int cx, int cy, float (&sA)[4], float (&sVA)[4]) -> bool {
             int Zx, Zy;
             double dfx, dfy;
@@ -152,7 +176,7 @@ __global__ __launch_bounds__(kQuadBlock) void aai_cell_scan_kernel(RotLaunch r, 
             NoSrc s;
             return cell_eval<float, WIN, true, HP>(q, z, Zx, Zy, dfx, dfy, r.mW, r.mH, s, sA, sVA);
         },
-        [&](int px, int py, float A, float, int uncertain) {
+        [&](int px, int py, float A, float, int uncertain, int) {
             if (uncertain | ((A > 0.f && A < q.minArea) ? 1 : 0)) {
                 const unsigned long long bit = 1ull << flag_bit(px, py);
                 const unsigned long long old = atomicOr(laneMasks + flag_word(px, py, tilesX), bit);

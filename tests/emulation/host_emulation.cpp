@@ -249,7 +249,7 @@ template <int WIN>
 struct EmuQuadSrc {
     const RotLaunch *r; const float *img; int64_t stride;
     float v[WIN * WIN];
-    void issue(int xg0, int yg0, unsigned long long valid)
+    void issue(int xg0, int yg0, unsigned long long valid, bool = false)
     {
         for (int j = 0; j < WIN; ++j)
             for (int i = 0; i < WIN; ++i)
@@ -579,7 +579,7 @@ static void emu_cell_parts(const RotLaunch &r, const float *img, int dx, int dy,
 {
     struct Src {
         const RotLaunch *r; const float *img; int64_t stride; float v[WIN * WIN];
-        void issue(int xg0, int yg0, unsigned long long valid) { for (int j = 0; j < WIN; ++j) for (int i = 0; i < WIN; ++i) v[j * WIN + i] = ((valid >> (j * WIN + i)) & 1) ? img[virt_offset(*r, xg0 + i, yg0 + j, stride)] : 0.f; }
+        void issue(int xg0, int yg0, unsigned long long valid, bool = false) { for (int j = 0; j < WIN; ++j) for (int i = 0; i < WIN; ++i) v[j * WIN + i] = ((valid >> (j * WIN + i)) & 1) ? img[virt_offset(*r, xg0 + i, yg0 + j, stride)] : 0.f; }
         void commit() {}
         void at(int slot, F (&vals)[1]) const { vals[0] = (F)v[slot]; }
     };
@@ -726,6 +726,32 @@ long aai_emu_cell_band_cover(const aai_request *rq, int r0, int r1)
                 }
         }
     return outside;
+}
+
+// cell_live_rows must be a superset: counts the cells that contribute something (non-zero area sums) although their row lies
+// outside the interval reported for the 64-column strip they belong to.  -1: the cell formulation does not serve the request.
+long aai_emu_cell_live_rows_check(const aai_request *rq)
+{
+    Geometry g; std::string msg;
+    if (make_geometry(*rq, g, msg) != AAI_OK) return -2;
+    const RotLaunch r = make_rot_launch(g, rq->mode, rq->policy);
+    if (!r.cell) return -1;
+    EmuCells cells;
+    std::vector<float> img((size_t)r.W * r.H, 1.0f);
+    emu_cells(r, img.data(), r.W, cells);
+    const CellConsts<float> z = make_cell_consts<float>(r.side, r.c, r.s);
+    long bad = 0;
+    for (int x0 = 0; x0 <= r.dW; x0 += 63) {
+        int lo, hi;
+        cell_live_rows(r, z, x0, x0 + 63, lo, hi);
+        for (int y = 0; y <= r.dH; ++y)
+            for (int x = x0; x <= std::min(x0 + 63, r.dW); ++x) {
+                const size_t at = (size_t)y * cells.W1 + x;
+                const bool contributes = cells.a[0][at] != 0.f || cells.a[1][at] != 0.f || cells.a[2][at] != 0.f || cells.a[3][at] != 0.f || cells.unc[at];
+                if (contributes && (y < lo || y > hi)) ++bad;
+            }
+    }
+    return bad;
 }
 
 // The host-side class verification of an axis-aligned plan (aai_plan.cpp: axis_verify_by_class) against the per-pixel scan

@@ -649,6 +649,28 @@ def test_band_source_rows_hold_every_window_the_cell_kernel_fetches(aai, hostemu
     assert checked > 150, checked
 
 
+def test_cell_live_row_interval_is_a_superset(aai, hostemu):
+    """The cell kernel skips the cell rows outside cell_live_rows' interval for its 64 columns without computing anything
+    (the empty corners of a rotated canvas): no cell outside the interval may contribute.  Random geometries, all quadrants,
+    isocenters inside and outside the image, up- and down-sampling."""
+    import ctypes
+    rng = np.random.default_rng(9)
+    checked = 0
+    for k in range(120):
+        W, H = int(rng.integers(8, 150)), int(rng.integers(8, 150))
+        sr, dr = float(rng.uniform(0.5, 5.0)), float(rng.uniform(0.5, 2.5))
+        ang = float(rng.uniform(0.5, 89.5)) + 90.0 * (k % 4)
+        iso = (float(rng.uniform(-W, 2 * W)), float(rng.uniform(-H, 2 * H))) if k % 3 else ((W - 1) / 2, (H - 1) / 2)
+        rq = aai.make_request(W, H, sr, dr, iso, ang, mode=1)
+        rc, msg, lay = aai.query(rq)
+        if rc != 0:
+            continue
+        bad = hostemu.aai_emu_cell_live_rows_check(ctypes.byref(rq))
+        assert bad in (0, -1), (W, H, sr, dr, iso, ang, bad)
+        checked += bad == 0
+    assert checked > 90, checked
+
+
 def test_cell_fp32_replay_against_oracle_at_larger_sizes(aai, hostemu, po):
     """... and against the oracle at sizes where border pixels no longer dominate: BASELINE config 3's and 5's geometries,
     all quadrants, both policies, near-axis rotations (hiPrec); few pixels left to the double-precision pass."""
