@@ -156,13 +156,10 @@ RotLaunch make_rot_launch(const Geometry &g, int mode, int policy)
     // beyond the parity bar (quad_supported).
     r.quad = ((mode == AAI_MODE_AREA || mode == AAI_MODE_FAST) && !(policy & AAI_POLICY_DOUBLE_PRECISION) && c > 0.0 && s > 0.0 &&
               quad_supported(g.side, c, s)) ? 1 : 0;
-    // Fast mode with replication stays on the line-walking kernel: a dst square then holds one to four centres and that
-    // kernel fetches just those, where the window kernel fetches its whole 3 x 3 ... 5 x 5 window (x2 up-sampling at 30
-    // degrees 0.69 vs 0.96 ms, x4 at 45 degrees 2.75 vs 4.33 ms: profiles/r02_fast_envelope.txt).
-    {
-        static const bool fastScaled = [] { const char *e = getenv("AAI_FAST_SCALED"); return e && atoi(e) != 0; }();      // experiment
-        if (mode == AAI_MODE_FAST && g.scale > 1 && !fastScaled) r.quad = 0;
-    }
+    // (Fast mode with replication used to stay on the fp64 line-walking kernel: the 4 x 4 ... 5 x 5 area-mode window fetched
+    // too much.  With the centre-only window of round 3 -- 3 x 3 at x4 up-sampling -- the window kernel wins everywhere
+    // measured: x4 at 45 degrees 2.75 -> 2.67 ms, x2 at 30 0.68 -> 0.59, 1:1 at 61 0.212 -> 0.204, x3 at 17.5 0.37 -> 0.29:
+    // tools/fast_scaled_ab.sh.)
     // Area mode: the cell formulation (aai_rot_cell.hpp) evaluates every (dst, src) pair once instead of once per dst pixel
     r.cell = (r.quad && mode == AAI_MODE_AREA && cell_supported(g.side, c, s)) ? 1 : 0;
     {

@@ -41,13 +41,6 @@
 
 namespace aai {
 
-// a vote over the lanes of the wave on the GPU; the CPU replay evaluates one cell at a time
-#if defined(__HIP_DEVICE_COMPILE__)
-#define AAI_WAVE_ALL(x) (__all(x) != 0)
-#else
-#define AAI_WAVE_ALL(x) (x)
-#endif
-
 enum CellTarget { CELL_O = 0, CELL_W = 1, CELL_N = 2, CELL_NW = 3 };     // own dst pixel (x, y); (x-1, y); (x, y-1); (x-1, y-1)
 
 template <typename F>

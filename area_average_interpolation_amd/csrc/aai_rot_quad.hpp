@@ -37,6 +37,13 @@
 
 #include "aai_rot_math.hpp"
 
+// a vote over the lanes of the wave on the GPU; the CPU replay evaluates one pixel / cell at a time
+#if defined(__HIP_DEVICE_COMPILE__)
+#define AAI_WAVE_ALL(x) (__all(x) != 0)
+#else
+#define AAI_WAVE_ALL(x) (x)
+#endif
+
 namespace aai {
 
 constexpr int kQuadMaxWin = 8;        // window positions per axis that the 64-bit position masks can hold
@@ -440,17 +447,26 @@ AAI_HD bool quad_fast_pixel(const QuadConsts<F> &q, int Xc, int Yc, double dfx, 
     const F fi0 = ceil(fpx - q.hbf), fj0 = ceil(fpy - q.hbf);          // first lattice point a centre of the square can be
     const int i0 = (int)fi0, j0 = (int)fj0;
     const int xg0 = Xc + i0, yg0 = Yc + j0;
+    // Away from the image border every window of the wave lies inside the lattice: one vote replaces the per-column / per-row
+    // validity and the clamps in the loads
+    const bool interior = AAI_WAVE_ALL(xg0 >= 0 && xg0 + WIN <= mW && yg0 >= 0 && yg0 + WIN <= mH);
     // window columns ia..ib and rows ja..jb lie inside the lattice
-    const int ia = xg0 < 0 ? -xg0 : 0, ib = (mW - 1 - xg0 < WIN - 1) ? mW - 1 - xg0 : WIN - 1;
-    const int ja = yg0 < 0 ? -yg0 : 0, jb = (mH - 1 - yg0 < WIN - 1) ? mH - 1 - yg0 : WIN - 1;
-    if (ia > ib || ja > jb) return false;
+    int ia = 0, ib = WIN - 1, ja = 0, jb = WIN - 1;
+    if (!interior) {
+        ia = xg0 < 0 ? -xg0 : 0; ib = (mW - 1 - xg0 < WIN - 1) ? mW - 1 - xg0 : WIN - 1;
+        ja = yg0 < 0 ? -yg0 : 0; jb = (mH - 1 - yg0 < WIN - 1) ? mH - 1 - yg0 : WIN - 1;
+        if (ia > ib || ja > jb) return false;
+    }
     if (!SCAN) {
-        const unsigned cols = (2u << ib) - (1u << ia);
-        mask_t valid = 0;
+        mask_t valid = ~(mask_t)0;
+        if (!interior) {
+            const unsigned cols = (2u << ib) - (1u << ia);
+            valid = 0;
 #pragma unroll
-        for (int j = 0; j < WIN; ++j)
-            if (j >= ja && j <= jb) valid |= (mask_t)cols << (j * WIN);
-        src.issue(xg0, yg0, valid);
+            for (int j = 0; j < WIN; ++j)
+                if (j >= ja && j <= jb) valid |= (mask_t)cols << (j * WIN);
+        }
+        src.issue(xg0, yg0, valid, interior);
     }
     // Columns and rows off the lattice get a coordinate far away: a = far * c (or far * s, or far * (c - s) with
     // b = far * (c + s) when both are off) fails the membership test by itself, c and s being > 1e-4 -- one select per

@@ -937,8 +937,6 @@ def test_quad_kernel_equals_its_cpu_replay_bit_for_bit(gpu, hostemu, po):
             # (area mode on plain images has since moved to the cell kernel -- next test; the quad area kernels keep
             # interleaved channels and sources of 4 GiB and more, covered by their own parity tests)
             for mode, kernel in ((2, "aai_quad_fast_kernel"),):
-                if mode == 2 and dr / sr * 2 ** 0.5 + 1 >= 2:
-                    continue                    # replicated source pixels: fast mode keeps the double-precision line-walking kernel
                 rq = gpu.make_request(W, H, sr, dr, iso, ang, mode=mode, policy=policy)
                 ref, axis = hostemu.resample(rq, src)
                 quad, flagged = hostemu.quad_stats()
@@ -991,8 +989,7 @@ def test_double_precision_policy(gpu, po):
         for policy in (0, 1):
             gold = po.oracle_run(omode, src.astype(np.float64), sr, dr, iso, ang, policy=policy).dst
             rc, msg, dst, _, lay = gpu.resample_host(src, sr, dr, iso, ang, mode=mode, policy=policy)
-            # (this geometry replicates its source pixels: fast mode keeps the line-walking kernel)
-            assert rc == 0 and ("aai_cell_kernel" in gpu.last_kernel()) == (mode == 1) and rel_err(dst, gold).max() <= TOL
+            assert rc == 0 and ("aai_cell_kernel" if mode == 1 else "aai_quad_fast_kernel") in gpu.last_kernel() and rel_err(dst, gold).max() <= TOL
             rc, msg, dst, _, lay = gpu.resample_host(src, sr, dr, iso, ang, mode=mode, policy=policy | flag)
             assert rc == 0 and "quad" not in gpu.last_kernel() and "cell" not in gpu.last_kernel(), gpu.last_kernel()
             assert rel_err(dst, gold).max() <= 1.5e-7 and np.array_equal(gold == 0, dst == 0)

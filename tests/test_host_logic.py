@@ -569,7 +569,7 @@ def test_quad_fp32_replay_matches_small_golden(aai, hostemu, po, small_golden):
                 flagged += u
                 assert rel_err(out, gold).max() <= 0.3 * TOL, (i, c, tag, float(rel_err(out, gold).max()))
                 assert np.array_equal(gold == 0, out == 0), (i, tag)
-        assert quad > 50000 and flagged < 0.08 * quad, (quad, flagged)      # small images: many border pixels (fast mode: only without replication)
+        assert quad > 50000 and flagged < 0.08 * quad, (quad, flagged)      # small images: many border pixels
     finally:
         hostemu.aai_emu_use_quad(0)
 
@@ -716,8 +716,7 @@ def test_quad_fp32_replay_against_oracle_at_larger_sizes(aai, hostemu, po):
             out, axis = hostemu.resample(aai.make_request(W, W, sr, dr, iso, ang, mode=2, policy=policy), src)
             q, u = hostemu.quad_stats()
             gold = po.oracle_run(po.MODE_FAST, src.astype(np.float64), sr, dr, iso, ang, policy=policy).dst
-            replicated = int(dr / sr * 2 ** 0.5 + 1 + 2.3e-16) > 1       # with replication fast mode keeps the line-walking kernel
-            assert not axis and (q == 0 if replicated else (q > 0 and u < 0.01 * q)), (W, sr, dr, ang, q, u)
+            assert not axis and q > 0 and u < 0.01 * q, (W, sr, dr, ang, q, u)        # (with replication too, since round 3)
             assert rel_err(out, gold).max() <= 0.1 * TOL, (W, sr, dr, ang, float(rel_err(out, gold).max()))
             assert np.array_equal(gold == 0, out == 0)
     finally:
@@ -735,8 +734,7 @@ def test_double_precision_policy_keeps_requests_off_the_fp32_formulation(aai, ho
         for mode, omode in ((1, po.MODE_EXACT), (2, po.MODE_FAST)):
             gold = po.oracle_run(omode, src.astype(np.float64), sr, dr, iso, ang, policy=1).dst
             out, _ = hostemu.resample(aai.make_request(W, H, sr, dr, iso, ang, mode=mode, policy=1), src)
-            # (this geometry replicates its source pixels: fast mode keeps the line-walking kernel)
-            assert (hostemu.quad_stats()[0] > 0) == (mode == 1) and rel_err(out, gold).max() <= TOL
+            assert hostemu.quad_stats()[0] > 0 and rel_err(out, gold).max() <= TOL
             out, _ = hostemu.resample(aai.make_request(W, H, sr, dr, iso, ang, mode=mode, policy=1 | aai.POLICY_DOUBLE_PRECISION), src)
             assert hostemu.quad_stats()[0] == 0 and rel_err(out, gold).max() <= 1e-7
     finally:
