@@ -283,6 +283,14 @@ def plan_shape(request, channels=1):
     return buf.value.decode()
 
 
+def debug_cell_min_waves(waves):
+    """tests only: the smallest output (in cell waves of 63 x 8 dst pixels) the cell kernel takes; 0 = all, -1 = the default"""
+    lib = L.load()
+    lib.aai_debug_cell_min_waves.restype = None
+    lib.aai_debug_cell_min_waves.argtypes = [ctypes.c_int]
+    lib.aai_debug_cell_min_waves(int(waves))
+
+
 def shutdown():
     """aai_shutdown: drop every cached plan now (optional; a process may simply exit)."""
     L.load().aai_shutdown()

@@ -302,6 +302,8 @@ int aai_shutdown(void)
 
 /* experiments only (tools/tune_axis.py); not declared in include/aai.h */
 void aai_debug_axis_tune(const char *spec) { aai::set_axis_tune(spec); }
+/* tests only: the smallest output (in cell waves) the cell kernel takes; 0 = every output, < 0 = the default */
+void aai_debug_cell_min_waves(int waves) { aai::set_cell_min_waves(waves); }
 
 const char *aai_debug_plan_shape(const aai_request *req)
 {

@@ -81,6 +81,7 @@ hipError_t launch_quad(const RotLaunch &r, const QuadMap &m, const void *src, in
 // the cell formulation (aai_rotated_cell.hip): one lane per cell of the dst grid, every (dst, src) pair evaluated once
 bool cell_can_serve(const RotLaunch &r, int srcType, ImageView sv);      // r.chan set; plain images below 4 GiB, area mode
 int cell_rows_per_strip(int dW, int rows, int batch, int tileWidth);
+void set_cell_min_waves(int waves);      // tests / experiments: outputs of fewer cell waves than this stay on the quad kernel (default 1024; < 0 restores it)
 hipError_t launch_cell_scan(const RotLaunch &r, unsigned long long *laneMasks, unsigned *counter, hipStream_t stream);
 hipError_t launch_cell(const RotLaunch &r, const QuadMap &m, const void *src, int srcType, ImageView sv, float *dst, ImageView dv,
                        int batch, const unsigned long long *skipMasks, hipStream_t stream);

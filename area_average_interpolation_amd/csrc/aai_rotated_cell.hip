@@ -259,11 +259,19 @@ int cell_rows_per_strip(int dW, int rows, int batch, int tileWidth)
     return R;
 }
 
+// (tests: aai_debug_cell_min_waves(0) sends small images to the cell kernel too)
+static int g_cellMinWaves = 1024;
+void set_cell_min_waves(int waves) { g_cellMinWaves = waves < 0 ? 1024 : waves; }
+
 bool cell_can_serve(const RotLaunch &r, int srcType, ImageView sv)
 {
     // plain images below 4 GiB (lanes address their pixels with unsigned 32-bit byte offsets from the image's first element)
     static const bool enabled = [] { const char *e = getenv("AAI_CELL"); return !(e && atoi(e) == 0); }();      // experiments: AAI_CELL=0 keeps the quad kernel
     if (!enabled || !r.cell || r.chan > 1 || r.mode != AAI_MODE_AREA) return false;
+    // Small outputs stay on the quad kernel: a cell wave lives for rows + 1 cell rows, and an image of fewer than ~1000 such
+    // waves (about 720 x 720 dst pixels) cannot fill the chip with them -- the reference's own example call (158 x 158 dst
+    // pixels at 5.9 : 1) takes 71 us on 60 cell waves and 36 us on 390 one-shot quad waves.
+    if ((int64_t)((r.dW + 62) / 63) * ((r.dH + 7) / 8) < g_cellMinWaves) return false;
     const int64_t esz = srcType == SRC_U8 ? 1 : srcType == SRC_U16 ? 2 : 4;
     return (int64_t)r.H * sv.rowStride * esz < ((int64_t)1 << 32);
 }

@@ -40,12 +40,124 @@ hipError_t launch_axis_verify(const RotLaunch &r, unsigned long long *laneMasks,
     return hipSuccess;
 }
 
+// The fix-up pass over the plan's LIST of flagged dst pixels, 16 lanes per pixel.  aai_rotated_kernel<STRICT> gives every
+// listed pixel ONE lane, which then walks its whole window alone -- 100 pairs of double-precision replay at 5.9 : 1: a
+// latency-bound pass of 40-120 us however few pixels are listed, which set the time of every small rotated request (the
+// reference's own example call: 72 us, config 5 at 1/8 scale: 125 us) and shared the chip with the production kernel on larger
+// ones.  Here the 16 lanes of a group take the window's pairs in turn (the same per-pair code: classify_pair, the closed
+// forms, the strict replay of the reference's classifier at knife edges) and their partial sums are added in a four-step
+// butterfly; four groups per wave.  Sums are reassociated (double precision: ~1e-16 relative).
+constexpr int kFixGroup = 16;
+
+template <int MODE, typename T, bool MULTI>
+__global__ __launch_bounds__(kRotBlock) void aai_fixup_group_kernel(RotLaunch r, const T *__restrict__ src, ImageView sv, float *__restrict__ dst, ImageView dv,
+                                                                   const uint2 *__restrict__ pixelList, unsigned nList)
+{
+    constexpr int NC = MULTI ? kMaxChan : 1;
+    const int tid = threadIdx.x, sub = tid & (kFixGroup - 1);
+    const unsigned e = blockIdx.x * (kRotBlock / kFixGroup) + (unsigned)(tid / kFixGroup);
+    bool valid = e < nList;
+    const uint2 p = valid ? pixelList[e] : make_uint2(0u, 0u);
+    const int dx = (int)p.x, dy = (int)p.y;
+    valid = valid && dy >= r.dyBase && dy < r.dyEnd;                 // (uniform within a group)
+    const T *img = src + (int64_t)blockIdx.z * sv.imageStride;
+    const int chan = MULTI ? r.chan : 1;
+
+    double sumA = 0.0, acc[NC] = {};
+    int count = 0;
+    if (valid) {
+        double px, py;
+        pixel_centre(r, dx, dy, px, py);
+        const double hb = r.h * (r.c + r.s);
+        const int x0 = max(0, (int)floor(px - hb + 0.5 - AAI_KNIFE_GUARD)), x1 = min(r.mW - 1, (int)ceil(px + hb - 0.5 + AAI_KNIFE_GUARD));
+        const int y0 = max(0, (int)floor(py - hb + 0.5 - AAI_KNIFE_GUARD)), y1 = min(r.mH - 1, (int)ceil(py + hb - 0.5 + AAI_KNIFE_GUARD));
+        const int nW = x1 - x0 + 1;
+        SVec sv4[4];
+        bool haveVertices = false;
+        const double lim = r.h + DBL_EPSILON * r.side;
+        // pair k of the window (row-major) belongs to lane k mod 16
+        int X = x0 + sub, Y = y0;
+        while (X > x1 && Y <= y1) { X -= nW; ++Y; }
+        while (nW > 0 && Y <= y1) {
+            const double ex = X - px, ey = Y - py;
+            double w = 0.0;
+            if (MODE == AAI_MODE_FAST) {
+                const double a = fabs(ex * r.c - ey * r.s), b = fabs(ex * r.s + ey * r.c);
+                bool in = a <= lim && b <= lim;
+                const bool edgy = (fabs(a - r.h) < AAI_KNIFE_GUARD && b <= r.h + AAI_KNIFE_GUARD) || (fabs(b - r.h) < AAI_KNIFE_GUARD && a <= r.h + AAI_KNIFE_GUARD);
+                if (edgy) {                      // a centre on an edge: the reference's ray cast decides
+                    if (!haveVertices) { strict_vertices(r, dx, dy, sv4); haveVertices = true; }
+                    SVec pc; pc.x = X; pc.y = Y;
+                    in = strict_centre_inside(pc, sv4);
+                }
+                if (in) { w = 1.0; ++count; }
+            } else {
+                const double a = ex * r.c - ey * r.s, b = ex * r.s + ey * r.c;
+                double d = 0.0;
+                bool edgy = false, edgy2 = false;
+                const int cls = classify_pair<true>(r, a, b, d, edgy);
+                if (cls != PAIR_OUTSIDE) {
+                    if (cls == PAIR_INSIDE) w = 1.0;
+                    else if (cls == PAIR_GENERAL) w = wedge_pair_area<true>(r, px - (X - 0.5), py - (Y - 0.5), a < 0.0, b < 0.0, r.policy, edgy2);
+                    else w = single_cut_area<true>(r, d, cls == PAIR_CUT_LR, r.policy, edgy2);
+                    if (edgy || edgy2) {
+                        if (!haveVertices) { strict_vertices(r, dx, dy, sv4); haveVertices = true; }
+                        w = strict_pair_area(sv4, X, Y, r.policy);
+                    }
+                }
+            }
+            if (w != 0.0) {
+                sumA += w;
+                const T *q = img + virt_offset(r, X, Y, sv.rowStride, chan);
+                if (!MULTI) acc[0] += w * (double)q[0];
+                else {
+                    float v[kMaxChan];
+                    load_pixel(q, chan, v);
+#pragma unroll
+                    for (int c = 0; c < NC; ++c)
+                        if (c < chan) acc[c] += w * (double)v[c];
+                }
+            }
+            X += kFixGroup;
+            while (X > x1 && Y <= y1) { X -= nW; ++Y; }
+        }
+    }
+    // the group's sums (every lane of the wave takes part; groups of invalid entries add zeros)
+#pragma unroll
+    for (int off = kFixGroup / 2; off > 0; off >>= 1) {
+        sumA += __shfl_xor(sumA, off, kFixGroup);
+        count += __shfl_xor(count, off, kFixGroup);
+#pragma unroll
+        for (int c = 0; c < NC; ++c) acc[c] += __shfl_xor(acc[c], off, kFixGroup);
+    }
+    if (valid && sub == 0) {
+        float *out = dst + (int64_t)blockIdx.z * dv.imageStride + (int64_t)(dy - r.dyBase) * dv.rowStride + (int64_t)dx * chan;
+        const bool any = MODE == AAI_MODE_FAST ? count > 0 : DBL_EPSILON < fabs(sumA);           // Source.cpp:905 / 577
+        const double denom = MODE == AAI_MODE_FAST ? (double)count : sumA;
+#pragma unroll
+        for (int c = 0; c < NC; ++c)
+            if (c < chan) out[c] = any ? (float)(acc[c] / denom) : 0.f;
+    }
+}
+
 template <typename T>
 static void fixup_typed(const RotLaunch &r, int batch, const T *src, ImageView sv, float *dst, ImageView dv,
                         const uint2 *waveFlags, unsigned nList, hipStream_t stream)
 {
-    const dim3 grid = waveFlags ? dim3((nList + kRotBlock - 1) / kRotBlock, 1, batch)
-                                : dim3((r.dW + 15) / 16, (r.dyEnd - r.dyBase + 15) / 16, batch);
+    if (waveFlags) {
+        // the plan's list: 16 lanes per listed pixel
+        const dim3 groups((nList + kRotBlock / kFixGroup - 1) / (kRotBlock / kFixGroup), 1, batch);
+        if (r.chan > 1) {
+            if (r.mode == AAI_MODE_FAST) hipLaunchKernelGGL((aai_fixup_group_kernel<AAI_MODE_FAST, T, true>), groups, dim3(kRotBlock), 0, stream, r, src, sv, dst, dv, waveFlags, nList);
+            else hipLaunchKernelGGL((aai_fixup_group_kernel<AAI_MODE_AREA, T, true>), groups, dim3(kRotBlock), 0, stream, r, src, sv, dst, dv, waveFlags, nList);
+        } else {
+            if (r.mode == AAI_MODE_FAST) hipLaunchKernelGGL((aai_fixup_group_kernel<AAI_MODE_FAST, T, false>), groups, dim3(kRotBlock), 0, stream, r, src, sv, dst, dv, waveFlags, nList);
+            else hipLaunchKernelGGL((aai_fixup_group_kernel<AAI_MODE_AREA, T, false>), groups, dim3(kRotBlock), 0, stream, r, src, sv, dst, dv, waveFlags, nList);
+        }
+        return;
+    }
+    // no list: so many pixels are flagged that the whole image takes the strict pass, one lane per dst pixel
+    const dim3 grid((r.dW + 15) / 16, (r.dyEnd - r.dyBase + 15) / 16, batch);
     if (r.chan > 1) {      // interleaved channels
         if (r.mode == AAI_MODE_FAST)
             hipLaunchKernelGGL((aai_rotated_kernel<AAI_MODE_FAST, true, T, true>), grid, dim3(kRotBlock), 0, stream, r, src, sv, dst, dv, waveFlags, nList);

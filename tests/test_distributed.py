@@ -159,7 +159,7 @@ def test_bench_two_ranks_on_one_gpu_drive_the_hip_path():
         env.pop(k, None)
     for extra, kernel, scaling in ((["--workload", "cfg1"], "aai_axis_kernel", "weak"),
                                    (["--workload", "cfg1", "--shard", "rows"], "aai_axis_kernel", "strong"),
-                                   (["--custom", "1024,1024,3,1,17.5", "--shard", "rows", "--gather"], "aai_cell_kernel", "strong")):
+                                   (["--custom", "4096,4096,3,1,17.5", "--shard", "rows", "--gather"], "aai_cell_kernel", "strong")):
         p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--no-cpu-baseline",
                             "--steps", "3", "--warmup", "1", "--min-seconds", "0.05"] + extra, capture_output=True, text=True, env=env, timeout=600)
         lines = [l for l in p.stdout.splitlines() if l.startswith("{")]

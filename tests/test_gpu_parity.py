@@ -27,6 +27,15 @@ def gpu(aai):
     return aai
 
 
+@pytest.fixture(params=["default", "cell"])
+def formulation(request, gpu):
+    """Small rotated area requests stay on the quad kernel by default (too few cell waves to fill the chip); "cell" sends them
+    to the cell kernel as well, so that the golden vectors and the oracle check BOTH fp32 formulations on every case."""
+    gpu.debug_cell_min_waves(0 if request.param == "cell" else -1)
+    yield request.param
+    gpu.debug_cell_min_waves(-1)
+
+
 def _host(gpu, src, c, mode, policy=0):
     rc, msg, dst, iso, lay = gpu.resample_host(src, c["src_res"], c["dst_res"], c["iso"], c["angle"], mode=mode, policy=policy)
     assert rc == 0, msg
@@ -34,7 +43,7 @@ def _host(gpu, src, c, mode, policy=0):
 
 
 # ---- (a) golden vectors of the unmodified reference ---------------------------------------------------------
-def test_small_golden_cases_f32(gpu, po, small_golden):
+def test_small_golden_cases_f32(gpu, formulation, po, small_golden):
     z, manifest = small_golden
     for i, c in enumerate(manifest):
         src = po.synth_image(c["W"], c["H"], c["seed"])
@@ -98,7 +107,7 @@ def test_baseline_configs_against_reference_known_answers(gpu, name):
 
 
 # ---- (b) oracle on the same seeded inputs -------------------------------------------------------------------
-def test_reference_default_call_on_a_dose_like_image(gpu, po, refdefault_golden):
+def test_reference_default_call_on_a_dose_like_image(gpu, formulation, po, refdefault_golden):
     """The reference's own example call (Source.cpp:1528-1534: a 911 x 911 film at 150 dpi to 25.4 dpi about (455, 455), rotated
     by 1.5 degrees; mode 2 is its default) on a dose-like image -- flat field, penumbrae, tails at 1e-4 of the maximum, so
     neighbouring values differ by decades -- against the UNMODIFIED reference's output.  1e-5 relative with an absolute floor
@@ -116,7 +125,7 @@ def test_reference_default_call_on_a_dose_like_image(gpu, po, refdefault_golden)
             assert np.array_equal(dst == 0, gold == 0), (tag, policy)
 
 
-def test_random_geometries_against_oracle(gpu, po):
+def test_random_geometries_against_oracle(gpu, formulation, po):
     rng = np.random.default_rng(11)
     for k in range(60):
         W, H = int(rng.integers(1, 90)), int(rng.integers(1, 90))
@@ -174,7 +183,7 @@ def test_axis_kernel_code_paths_against_oracle(gpu, po):
     assert {"aai_axis_kernel", "aai_axis_wide_kernel", "aai_axis_tile_kernel"} <= seen, seen
 
 
-def test_rows_as_runs_kernel_against_oracle(gpu, po):
+def test_rows_as_runs_kernel_against_oracle(gpu, formulation, po):
     """Large footprints (heavy down-sampling at an angle) take aai_rotated_runs_kernel: boundary / interior / boundary
     runs per source row.  Same cases as the CPU replay test, plus 8- and 16-bit sources and a batch."""
     from area_average_interpolation_amd import _lib as L
@@ -188,7 +197,7 @@ def test_rows_as_runs_kernel_against_oracle(gpu, po):
             rc, msg, dst, giso, lay = gpu.resample_host(src, sr, dr, iso, ang, mode=1, policy=policy)
             assert rc == 0, msg
             # (footprints whose window still fits the fp32 formulations -- up to about 5.5 : 1 -- take the cell kernel)
-            assert "aai_rotated_runs_kernel" in gpu.last_kernel() or "aai_cell_kernel" in gpu.last_kernel(), (k, gpu.last_kernel())
+            assert any(n in gpu.last_kernel() for n in ("aai_rotated_runs_kernel", "aai_cell_kernel", "aai_quad_kernel")), (k, gpu.last_kernel())
             kernels.add(gpu.last_kernel())
             assert dst.shape == gold.dst.shape and tuple(giso) == gold.dst_iso
             assert rel_err(dst, gold.dst).max() <= TOL, (k, policy, W, H, sr, ang)
@@ -203,7 +212,7 @@ def test_rows_as_runs_kernel_against_oracle(gpu, po):
                 assert np.array_equal(gold.dst == 0, dst == 0), (k, dt)
 
 
-def test_near_axis_rotations_against_oracle(gpu, po):
+def test_near_axis_rotations_against_oracle(gpu, formulation, po):
     """Rotations a hair away from a multiple of 90 degrees: the rotated kernels run with sin or cos around 1e-9
     (1/sin ~ 1e9 inside the closed forms), or the request snaps to the axis-aligned kernel (|tan| < DBL_EPSILON)."""
     rng = np.random.default_rng(3)
@@ -219,7 +228,7 @@ def test_near_axis_rotations_against_oracle(gpu, po):
                 assert np.array_equal(gold == 0, dst == 0), (ang, sr, dr, mode)
 
 
-def test_typed_sources_u8_u16_against_oracle(gpu, po):
+def test_typed_sources_u8_u16_against_oracle(gpu, formulation, po):
     """8-bit and 16-bit unsigned sources through aai_resample_host /
     aai_resample_batch_device; pixel values are used as they are, output fp32."""
     import torch
@@ -252,7 +261,7 @@ def test_typed_sources_u8_u16_against_oracle(gpu, po):
             assert (np.abs(out[1].cpu().numpy() - gold2) / np.maximum(np.abs(gold2), 1e-3 * hi)).max() <= TOL
 
 
-def test_exact_policy_against_oracle(gpu, po):
+def test_exact_policy_against_oracle(gpu, formulation, po):
     rng = np.random.default_rng(12)
     from area_average_interpolation_amd import _lib as L
     for k in range(12):
@@ -294,7 +303,7 @@ def _polygon_area(poly):
     return 0.5 * abs(sum(p[0] * q[1] - q[0] * p[1] for p, q in zip(poly, poly[1:] + poly[:1])))
 
 
-def test_exact_policy_against_polygon_clipping(gpu):
+def test_exact_policy_against_polygon_clipping(gpu, formulation):
     """AAI_POLICY_EXACT pinned by code that shares nothing with the product or the oracle: every dst pixel is the square
     spanned by the steps between neighbouring dst centres (the reference's affine map restated in conftest.sample_points),
     clipped against every source pixel of the ORIGINAL image with a Sutherland-Hodgman clip written here, areas by the
@@ -391,7 +400,7 @@ def test_knife_edge_geometries_against_oracle(gpu, po):
     assert runs > 300
 
 
-def test_knife_edge_geometries_against_reference_goldens(gpu, po, knife_golden):
+def test_knife_edge_geometries_against_reference_goldens(gpu, formulation, po, knife_golden):
     """The structured knife-edge geometries against outputs of the UNMODIFIED reference (tests/golden/knife_cases.npz,
     generated by tests/golden/make_golden.py knife from oracle/_ref): 189 geometries x both modes, no pixel excepted,
     exact zeros exact.  This is the reference-held evidence for the fix-up pass (Source.cpp:330-342, 401-408, 500-564, 1430)."""
@@ -755,7 +764,7 @@ def test_interleaved_channels_equal_planar_calls(gpu, po):
         gpu.resample_interleaved_device(rq, 5, dsrc.data_ptr(), (W + 5) * C, ddst.data_ptr(), (lay.dst_width + 2) * C)
 
 
-def test_row_bands_equal_full_image(gpu):
+def test_row_bands_equal_full_image(gpu, formulation):
     """dst row bands computed from buffers holding only their source footprint are
     bit-identical to the same rows of the full-image call -- every kernel family, all quadrants."""
     import torch
@@ -934,9 +943,8 @@ def test_quad_kernel_equals_its_cpu_replay_bit_for_bit(gpu, hostemu, po):
                                             (150, 150, 2.0, 1.0, 117.3, 1), (120, 90, 1.0, 1.0, 200.0, 0), (128, 128, 3.0, 2.0, 300.0, 0)):
             iso = (float(rng.uniform(0, W)), float(rng.uniform(0, H)))
             src = rng.random((H, W)).astype(np.float32)
-            # (area mode on plain images has since moved to the cell kernel -- next test; the quad area kernels keep
-            # interleaved channels and sources of 4 GiB and more, covered by their own parity tests)
-            for mode, kernel in ((2, "aai_quad_fast_kernel"),):
+            # (small outputs -- these -- stay on the quad kernel in area mode; larger plain images take the cell kernel, next test)
+            for mode, kernel in ((1, "aai_quad_kernel"), (2, "aai_quad_fast_kernel")):
                 rq = gpu.make_request(W, H, sr, dr, iso, ang, mode=mode, policy=policy)
                 ref, axis = hostemu.resample(rq, src)
                 quad, flagged = hostemu.quad_stats()
@@ -958,6 +966,7 @@ def test_cell_kernel_equals_its_cpu_replay_bit_for_bit(gpu, hostemu, po):
     row bands of the kernel's strips (more than 32 dst rows)."""
     rng = np.random.default_rng(78)
     hostemu.aai_emu_use_cell(1)
+    gpu.debug_cell_min_waves(0)
     try:
         for (W, H, sr, dr, ang, policy) in ((200, 160, 8192.0, 2731.0, 17.5, 0), (96, 96, 1.0, 4.0, 45.0, 0), (180, 140, 4.0, 1.0, 0.5, 0),
                                             (150, 150, 2.0, 1.0, 117.3, 1), (120, 90, 1.0, 1.0, 200.0, 0), (128, 128, 3.0, 2.0, 300.0, 0),
@@ -974,6 +983,7 @@ def test_cell_kernel_equals_its_cpu_replay_bit_for_bit(gpu, hostemu, po):
             assert rel_err(dst, ref).max() <= 3e-7
     finally:
         hostemu.aai_emu_use_cell(0)
+        gpu.debug_cell_min_waves(-1)
 
 
 def test_double_precision_policy(gpu, po):
@@ -989,7 +999,7 @@ def test_double_precision_policy(gpu, po):
         for policy in (0, 1):
             gold = po.oracle_run(omode, src.astype(np.float64), sr, dr, iso, ang, policy=policy).dst
             rc, msg, dst, _, lay = gpu.resample_host(src, sr, dr, iso, ang, mode=mode, policy=policy)
-            assert rc == 0 and ("aai_cell_kernel" if mode == 1 else "aai_quad_fast_kernel") in gpu.last_kernel() and rel_err(dst, gold).max() <= TOL
+            assert rc == 0 and ("aai_quad_kernel" if mode == 1 else "aai_quad_fast_kernel") in gpu.last_kernel() and rel_err(dst, gold).max() <= TOL
             rc, msg, dst, _, lay = gpu.resample_host(src, sr, dr, iso, ang, mode=mode, policy=policy | flag)
             assert rc == 0 and "quad" not in gpu.last_kernel() and "cell" not in gpu.last_kernel(), gpu.last_kernel()
             assert rel_err(dst, gold).max() <= 1.5e-7 and np.array_equal(gold == 0, dst == 0)
