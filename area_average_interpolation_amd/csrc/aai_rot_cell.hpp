@@ -112,7 +112,9 @@ AAI_HD bool cell_eval(const QuadConsts<F> &q, const CellConsts<F> &z, int Zx, in
         src.at(slot, vals);
         return vals[0];
     };
-    auto add = [&](int target, F area, F v) { sA[target] += area; sVA[target] = qfma(area, v, sVA[target]); };
+    // (a pixel that does not reach a target contributes area 0 there -- and must then contribute nothing, whatever its value:
+    // 0 x NaN would put a source pixel's NaN into a dst pixel it does not overlap)
+    auto add = [&](int target, F area, F v) { sA[target] += area; sVA[target] = qfma(area, area != F(0) ? v : F(0), sVA[target]); };
 
     // window origin: the first lattice point the zone's bounding box can hold
     const F fi0 = ceil(fpx - z.hbz), fj0 = ceil(fpy - z.hbz);
