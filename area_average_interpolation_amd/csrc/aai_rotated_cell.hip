@@ -229,7 +229,7 @@ template <typename T>
 hipError_t launch_cell_typed(const RotLaunch &r, const QuadMap &m, const T *src, ImageView sv, float *dst, ImageView dv, int batch,
                              const unsigned long long *skipMasks, hipStream_t stream)
 {
-    const QuadConsts<float> q = make_quad_consts<float>(r.side, r.c, r.s, r.policy, r.scale);
+    const QuadConsts<float> q = make_cell_quad_consts<float>(r.side, r.c, r.s, r.policy);
     const CellConsts<float> z = make_cell_consts<float>(r.side, r.c, r.s);
     switch (z.win) {
     case 2: return launch_cell_win<T, 2>(r, q, z, m, src, sv, dst, dv, batch, skipMasks, stream);
@@ -292,7 +292,7 @@ hipError_t launch_cell(const RotLaunch &r, const QuadMap &map, const void *src, 
 hipError_t launch_cell_scan(const RotLaunch &r, unsigned long long *laneMasks, unsigned *counter, hipStream_t stream)
 {
     if (r.dW <= 0 || r.dH <= 0) return hipSuccess;
-    const QuadConsts<float> q = make_quad_consts<float>(r.side, r.c, r.s, r.policy, r.scale);
+    const QuadConsts<float> q = make_cell_quad_consts<float>(r.side, r.c, r.s, r.policy);
     const CellConsts<float> z = make_cell_consts<float>(r.side, r.c, r.s);
     const int rows = 16;
     const int strips = (r.dW + 62) / 63;                       // the scan walks 64 x 1 tiles

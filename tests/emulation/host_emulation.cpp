@@ -328,7 +328,7 @@ static void emu_cells_win(const RotLaunch &r, const QuadConsts<float> &qc, const
 }
 static void emu_cells(const RotLaunch &r, const float *img, int64_t stride, EmuCells &out)
 {
-    const QuadConsts<float> qc = make_quad_consts<float>(r.side, r.c, r.s, r.policy, r.scale);
+    const QuadConsts<float> qc = make_cell_quad_consts<float>(r.side, r.c, r.s, r.policy);
     const CellConsts<float> zc = make_cell_consts<float>(r.side, r.c, r.s);
     out.W1 = r.dW + 1; out.H1 = r.dH + 1;
     const size_t n = (size_t)out.W1 * out.H1;
@@ -583,7 +583,7 @@ static void emu_cell_parts(const RotLaunch &r, const float *img, int dx, int dy,
         void commit() {}
         void at(int slot, F (&vals)[1]) const { vals[0] = (F)v[slot]; }
     };
-    const QuadConsts<F> q = make_quad_consts<F>(r.side, r.c, r.s, r.policy, r.scale);
+    const QuadConsts<F> q = make_cell_quad_consts<F>(r.side, r.c, r.s, r.policy);
     const CellConsts<F> z = make_cell_consts<F>(r.side, r.c, r.s);
     const int cxs[4] = {dx, dx + 1, dx, dx + 1}, cys[4] = {dy, dy, dy + 1, dy + 1};
     for (int t = 0; t < 4; ++t) {
