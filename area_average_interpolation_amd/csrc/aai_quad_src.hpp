@@ -43,6 +43,31 @@ struct QuadSrc {
     {
         unsigned colOff[WIN], rowOff[WIN];            // source indices along virtual X / Y first, byte offsets below
         const unsigned sxb = (unsigned)m->strideX * (unsigned)sizeof(T), syb = (unsigned)m->strideY * (unsigned)sizeof(T);
+        arranged = 0;
+        if (SCALED && allInside && WIN - 1 <= m->scale && m->anchorRows == 0) {
+            // Replicated pixels, window no wider than a source pixel plus one: it spans at most two source columns and two
+            // source rows -- four loads, and every position selects its value by which side of the split it lies on
+            // (x >= 0 here, so (x + 0.5) / scale is at least 0.5 / scale away from an integer: the floor is exact)
+            const int scale = m->scale;
+            const int qx0 = (int)(((double)xg0 + 0.5) * m->invScaleD), qy0 = (int)(((double)yg0 + 0.5) * m->invScaleD);
+            const int splitX = scale - (xg0 - qx0 * scale), splitY = scale - (yg0 - qy0 * scale);      // in [1, scale]: first column / row of the second source pixel
+            const int qx1 = splitX < WIN ? qx0 + 1 : qx0, qy1 = splitY < WIN ? qy0 + 1 : qy0;          // (never fetched from outside the image)
+            const unsigned c0 = (unsigned)(m->flipX ? m->nX - 1 - qx0 : qx0) * sxb, c1 = (unsigned)(m->flipX ? m->nX - 1 - qx1 : qx1) * sxb;
+            const unsigned r0 = (unsigned)(m->flipY ? m->nY - 1 - qy0 : qy0) * syb, r1 = (unsigned)(m->flipY ? m->nY - 1 - qy1 : qy1) * syb;
+            const T v00 = *reinterpret_cast<const T *>(img + (c0 + r0)), v10 = *reinterpret_cast<const T *>(img + (c1 + r0));
+            const T v01 = *reinterpret_cast<const T *>(img + (c0 + r1)), v11 = *reinterpret_cast<const T *>(img + (c1 + r1));
+            T top[WIN], bottom[WIN];
+#pragma unroll
+            for (int i = 0; i < WIN; ++i) {
+                top[i] = i >= splitX ? v10 : v00;
+                bottom[i] = i >= splitX ? v11 : v01;
+            }
+#pragma unroll
+            for (int j = 0; j < WIN; ++j)
+#pragma unroll
+                for (int i = 0; i < WIN; ++i) v[j * WIN + i] = j >= splitY ? bottom[i] : top[i];
+            return;
+        }
         if (!SCALED && allInside) {
             const int bx = m->flipX ? m->nX - 1 - xg0 : xg0, by = m->flipY ? m->nY - 1 - yg0 : yg0;
             const int sx = m->flipX ? -1 : 1, sy = m->flipY ? -1 : 1;
@@ -93,7 +118,6 @@ struct QuadSrc {
         // virtual Y in 1 / 3): fetch each of its WIN lines with one or two vector loads instead of WIN scalar ones -- lanes
         // are L source pixels apart, so every load instruction touches a dozen cache lines and their NUMBER is what the
         // texture path charges for.  Only where no lane of the wave has a clamped (off-image) column or row.
-        arranged = 0;
         if (!SCALED && sizeof(T) == 4 && (allInside || __all(xg0 >= 0 && xg0 + WIN <= mW && yg0 >= 0 && yg0 + WIN <= mH))) {
             // (every condition below is wave-uniform: the map is a kernel argument)
             const bool alongX = sxb == (unsigned)sizeof(T);
