@@ -299,6 +299,7 @@ static int build_plan(Plan &p)
             if (e == hipSuccess) e = hipMemsetAsync(dCount, 0, sizeof(unsigned), bs);
             if (e == hipSuccess) e = verifyAxis ? aai::launch_axis_verify(r, dMasks, dCount, bs) : aai::launch_knife_scan(r, dMasks, dCount, bs);
             if (e == hipSuccess && r.quad) e = form == aai::ROT_FORM_CELL ? aai::launch_cell_scan(r, dMasks, dCount, bs) : aai::launch_quad_scan(r, dMasks, dCount, bs);
+            if (e == hipSuccess && r.wide && !verifyAxis) e = aai::launch_wide_scan(r, dMasks, dCount, bs);
             if (e == hipSuccess) e = hipMemcpyAsync(&count, dCount, sizeof(unsigned), hipMemcpyDeviceToHost, bs);
             if (e == hipSuccess) e = hipStreamSynchronize(bs);
             stage("scans");
@@ -311,7 +312,7 @@ static int build_plan(Plan &p)
             }
             if (dCount) (void)hipFree(dCount);
             stage("flag list");
-            if (e == hipSuccess && count && r.quad) {
+            if (e == hipSuccess && count && (r.quad || r.wide)) {
                 // keep the masks: the fp32 kernel skips the flagged pixels and the fix-up pass runs beside it
                 p.dMasks = dMasks;
                 dMasks = nullptr;

@@ -78,6 +78,14 @@ bool quad_can_address(const RotLaunch &r, int srcType, ImageView sv);
 hipError_t launch_quad(const RotLaunch &r, const QuadMap &m, const void *src, int srcType, ImageView sv, float *dst, ImageView dv,
                        int batch, const unsigned long long *skipMasks, hipStream_t stream);
 
+int quad_anchor_rows(const RotLaunch &r);      // images of 4 GiB and more: how many source rows apart two lanes of a wave can read
+
+// wide footprints (aai_rotated_wide.hip): the quad formulation over a window split into parts, one lane per part
+bool wide_can_serve(const RotLaunch &r, int srcType, ImageView sv);      // r.chan set; RotLaunch::wide, plain images, area mode
+hipError_t launch_wide_scan(const RotLaunch &r, unsigned long long *laneMasks, unsigned *counter, hipStream_t stream);
+hipError_t launch_wide(const RotLaunch &r, const QuadMap &m, const void *src, int srcType, ImageView sv, float *dst, ImageView dv,
+                       int batch, const unsigned long long *skipMasks, hipStream_t stream);
+
 // the cell formulation (aai_rotated_cell.hip): one lane per cell of the dst grid, every (dst, src) pair evaluated once
 bool cell_can_serve(const RotLaunch &r, int srcType, ImageView sv);      // r.chan set; plain images below 4 GiB, area mode
 int cell_rows_per_strip(int dW, int rows, int batch, int tileWidth);

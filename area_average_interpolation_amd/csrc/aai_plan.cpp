@@ -162,6 +162,10 @@ RotLaunch make_rot_launch(const Geometry &g, int mode, int policy)
     // tools/fast_scaled_ab.sh.)
     // Area mode: the cell formulation (aai_rot_cell.hpp) evaluates every (dst, src) pair once instead of once per dst pixel
     r.cell = (r.quad && mode == AAI_MODE_AREA && cell_supported(g.side, c, s)) ? 1 : 0;
+    // Area mode, footprints too wide for one 8 x 8 window (ratios above ~5.5 : 1): the same fp32 arithmetic over a window split
+    // into 2 x 2 or 4 x 4 parts, a lane per part (aai_rotated_wide.hip) -- the double-precision runs kernel was bound by its
+    // boundary pairs (8 : 1 at 17.5 degrees: 0.34 ms where the source is read in 0.05)
+    r.wide = (mode == AAI_MODE_AREA && !(policy & AAI_POLICY_DOUBLE_PRECISION) && c > 0.0 && s > 0.0 && g.scale == 1) ? quad_wide_parts(g.side, c, s) : 0;
     {
         // virtual centre: X = dx (side cs) + dy (side sn) + X0, Y = -dx (side sn) + dy (side cs) + Y0   (pixel_centre)
         const double u0 = g.fracX * g.side - g.isoX + g.offX, v0 = g.fracY * g.side - g.isoY + g.offY;
@@ -211,7 +215,8 @@ void rotated_band_source_rows(const Geometry &g, int row0, int row1, bool sample
     // The cell kernel (aai_rot_cell.hpp) also evaluates the cells of dst row `row1` and dst column dW (their N / W parts
     // belong to the band's last row / column) and fetches whole lattice windows around ZONE centres, which sit up to
     // (c + s) / 2 < 0.71 beside the pixel centre: the box therefore spans cells [0, dW] x [row0, row1] and reaches one more pixel.
-    const double hb = 0.5 * g.side * (std::fabs(g.cs) + std::fabs(g.sn)) + 2.0 + (sampler ? 3.0 * g.scale : 0.0);
+    // The wide-footprint kernel (aai_rotated_wide.hip) splits its window into parts that may overhang it by up to 3 positions.
+    const double hb = 0.5 * g.side * (std::fabs(g.cs) + std::fabs(g.sn)) + 2.0 + (sampler ? 3.0 * g.scale : 0.0) + (!sampler && g.side > 5.0 ? 3.0 : 0.0);
     double minX = 1e300, maxX = -1e300, minY = 1e300, maxY = -1e300;
     for (int c = 0; c < 4; ++c) {
         double px, py;

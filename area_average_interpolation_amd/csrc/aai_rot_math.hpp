@@ -47,6 +47,7 @@ struct RotLaunch {
     int runs;                       // area mode: walk each source row as boundary / interior / boundary runs (large footprints)
     int quad;                       // area / fast mode: the fp32 quad formulation serves this geometry (aai_rot_quad.hpp)
     int cell;                       // area mode: ... and so does the cell formulation (aai_rot_cell.hpp), which then takes plain images
+    int wide;                       // area mode, wide footprints: parts per axis of the fp32 window (quad_wide_parts: 2 or 4), 0 = none
     int chan;                       // interleaved channels per pixel (1 = a plain image): element = pixel offset * chan + channel
     int lt45;                       // reduced angle < 45 degrees
     double tsn, tcs, ttn;           // tmpSin, tmpCos, tmpTan (tan snapped to 0 below DBL_EPSILON)

@@ -61,7 +61,8 @@ struct QuadConsts {
     F margin;                         // SCAN: decisions closer than this to their threshold are reported
     F minArea;                        // SCAN: pixels whose total area is below this (and not zero) are reported
     int ref;                          // 1 = AAI_POLICY_REFERENCE
-    int win;                          // window positions per axis, <= kQuadMaxWin
+    int win;                          // window positions per axis, <= kQuadMaxWin (wide footprints: of ONE part of the window)
+    int parts, winFull;               // parts per axis the window is split into (1: a single window; 2 or 4: quad_wide_parts) and its whole extent
     // fast mode only looks at pixel CENTRES inside the closed square: they lie within h (c + s) of its centre along either
     // lattice axis, i.e. at most floor(2 h (c + s)) + 1 positions per axis -- one fewer than the area mode's window, which
     // also holds the pixels the square merely touches (config 3: 4 x 4 instead of 5 x 5)
@@ -106,6 +107,33 @@ AAI_HD bool quad_supported(double side, double c, double s)
     return (int)floor(2.0 * m) + 3 <= kQuadMaxWin && h - k > 1e-3;
 }
 
+// Wide footprints (dst pixels of more than ~5 source pixels a side): the window of up to 16 x 16 / 32 x 32 positions is split
+// into 2 x 2 / 4 x 4 PARTS of at most kQuadMaxWin positions a side, each evaluated like a window of its own (quad_pixel, PART)
+// by a lane of its own, the sums added afterwards (quad_parts_sum).  Returns the parts per axis, 0: not a wide footprint the
+// formulation serves.  The coordinate error grows with the window (quad_coord_eps) but the areas it perturbs are a thin ring
+// of the L^2 the weights sum to.
+AAI_HD int quad_wide_parts(double side, double c, double s)
+{
+    if (!(c > 1e-4 && s > 1e-4)) return 0;
+    const double h = 0.5 * side, k = 0.5 * (c + s);
+    if (!(h - k > 1e-3)) return 0;
+    const double m = h * (c + s) - 0.5 + 1e-5;
+    if (!(m < 64.0)) return 0;
+    const int win = (int)floor(2.0 * m) + 3;
+    if (win <= kQuadMaxWin) return 0;
+    return win <= 2 * kQuadMaxWin ? 2 : (win <= 4 * kQuadMaxWin ? 4 : 0);
+}
+
+// the sum of the parts' partial sums, in the order the lanes of a dst pixel exchange them (a butterfly over lane distance 1, 2,
+// 4, ...): v[0] afterwards
+template <typename F>
+AAI_HD F quad_parts_sum(F *v, int n)
+{
+    for (int o = 1; o < n; o <<= 1)
+        for (int i = 0; i + o < n; i += 2 * o) v[i] = v[i] + v[i + o];
+    return v[0];
+}
+
 template <typename F>
 AAI_HD QuadConsts<F> make_quad_consts(double side, double c, double s, int policy, int scale = 1)
 {
@@ -127,7 +155,9 @@ AAI_HD QuadConsts<F> make_quad_consts(double side, double c, double s, int polic
     q.margin = (F)(3.0 * eps);
     q.minArea = (F)(side * side < 4.0 ? 0.25 * side * side : 1.0);
     q.ref = policy == AAI_POLICY_REFERENCE ? 1 : 0;
-    q.win = (int)floor(2.0 * (hb - 0.5 + 1e-5)) + 3;
+    q.winFull = (int)floor(2.0 * (hb - 0.5 + 1e-5)) + 3;
+    q.parts = q.winFull <= kQuadMaxWin ? 1 : (q.winFull <= 2 * kQuadMaxWin ? 2 : 4);
+    q.win = (q.winFull + q.parts - 1) / q.parts;
     q.hbf = (F)(hb + 1e-5);
     q.winFast = (int)floor(2.0 * (hb + 1e-5)) + 1;
     // ... and with replicated source pixels (up-sampling): a dst pixel then covers one or two source pixels and a dst value is
@@ -264,8 +294,11 @@ template <int WIN> struct QuadMask<WIN, true> { typedef unsigned type; };
 // SCAN: src is never touched, every value counts as 1 and the return value says whether this pixel must be left to
 // the double-precision pass.
 // HP: QuadConsts::hiPrec as a compile-time switch (the double-precision code costs registers even where it never runs)
-template <typename F, int WIN, bool SCAN, bool HP, int NC, typename Src>
-AAI_HD bool quad_pixel(const QuadConsts<F> &q, int Xc, int Yc, double dfx, double dfy, int mW, int mH, Src &src, F &sumA, F (&sumVA)[NC])
+// PART: this call evaluates part (partI, partJ) of a wide window (quad_wide_parts) -- WIN x WIN positions from (partI, partJ) *
+// WIN on; a vertex pixel belongs to the part that holds it; the caller adds the parts and (SCAN) tests the total area
+template <typename F, int WIN, bool SCAN, bool HP, int NC, typename Src, bool PART = false>
+AAI_HD bool quad_pixel(const QuadConsts<F> &q, int Xc, int Yc, double dfx, double dfy, int mW, int mH, Src &src, F &sumA, F (&sumVA)[NC],
+                       int partI = 0, int partJ = 0)
 {
     typedef typename QuadMask<WIN>::type u64;
     const F fpx = (F)dfx, fpy = (F)dfy;          // (32 bits for windows up to 5 x 5)
@@ -284,7 +317,7 @@ AAI_HD bool quad_pixel(const QuadConsts<F> &q, int Xc, int Yc, double dfx, doubl
         for (int c = 0; c < NC; ++c) sumVA[c] = qfma(w, vals[c], sumVA[c]);
     };
     // window origin: first pixel centre the square's bounding box can reach
-    const F fi0 = floor(fpx - q.hbm), fj0 = floor(fpy - q.hbm);
+    const F fi0 = floor(fpx - q.hbm) + (PART ? (F)(partI * WIN) : F(0)), fj0 = floor(fpy - q.hbm) + (PART ? (F)(partJ * WIN) : F(0));
     const int i0 = (int)fi0, j0 = (int)fj0;
     const int xg0 = Xc + i0, yg0 = Yc + j0;
 
@@ -360,7 +393,7 @@ AAI_HD bool quad_pixel(const QuadConsts<F> &q, int Xc, int Yc, double dfx, doubl
         const F rx = floor(wx + F(0.5)), ry = floor(wy + F(0.5));
         const F fx = wx - rx, fy = wy - ry;
         const int i = (int)rx - i0, j = (int)ry - j0;
-        if (i < 0 || i >= WIN || j < 0 || j >= WIN) { if (SCAN) uncertain = true; continue; }   // cannot happen (the box holds the vertices)
+        if (i < 0 || i >= WIN || j < 0 || j >= WIN) { if (SCAN && !PART) uncertain = true; continue; }   // another part's; else cannot happen (the box holds the vertices)
         const int slot = j * WIN + i;
         const u64 bit = (u64)1 << slot;
         if (SCAN && (qabs(fx) > F(0.5) - q.margin || qabs(fy) > F(0.5) - q.margin)) uncertain = true;
@@ -427,7 +460,7 @@ AAI_HD bool quad_pixel(const QuadConsts<F> &q, int Xc, int Yc, double dfx, doubl
         sumA += area;
         accumulate(area, slot);
     }
-    if (SCAN && sumA > F(0) && sumA < q.minArea) uncertain = true;
+    if (SCAN && !PART && sumA > F(0) && sumA < q.minArea) uncertain = true;
     return uncertain;
 }
 

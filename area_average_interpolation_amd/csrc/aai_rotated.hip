@@ -410,6 +410,12 @@ static bool cell_serves(const RotLaunch &r, int srcType, ImageView sv, const Rot
     return flags.form == ROT_FORM_CELL && rot_tune().quad != 0 && cell_can_serve(r, srcType, sv);
 }
 
+// ... or, for footprints wider than one 8 x 8 window, the quad formulation split into parts (aai_rotated_wide.hip)
+static bool wide_serves(const RotLaunch &r, int srcType, ImageView sv)
+{
+    return rot_tune().quad != 0 && wide_can_serve(r, srcType, sv);
+}
+
 // one launch of at most 65535 tile rows (16-row tiles; the bicubic sampler: 8-row tiles)
 template <typename T>
 static hipError_t launch_rotated_band(const RotLaunch &r, const QuadMap &m, const T *src, int srcType, ImageView sv, float *dst, ImageView dv,
@@ -434,6 +440,10 @@ static hipError_t launch_rotated_band(const RotLaunch &r, const QuadMap &m, cons
         // the cell formulation: one lane per cell of the dst grid, every (dst, src) pair evaluated once
         if (kernelName) *kernelName = "aai_cell_kernel<area>";
         return launch_cell(r, m, src, srcType, sv, dst, dv, batch, flags.count ? flags.masks : nullptr, stream);
+    }
+    if (wide_serves(r, srcType, sv)) {
+        if (kernelName) *kernelName = "aai_wide_kernel<area>";
+        return launch_wide(r, m, src, srcType, sv, dst, dv, batch, flags.count ? flags.masks : nullptr, stream);
     }
     if (r.chan > 1 && quad) {
         // interleaved channels through the fp32 quad formulation: areas once per pair, applied to every channel
@@ -498,7 +508,7 @@ static hipError_t launch_rotated_typed(const RotLaunch &r, const QuadMap &m, con
     // pass on the same stream -- or, when the production kernel is the quad kernel and skips those pixels, beside it on
     // the plan's side stream: fork before, join after.
     const bool fixup = !sampler && flags.count != 0;
-    bool beside = fixup && flags.masks && flags.side && (quad_serves(r, srcType, sv) || cell_serves(r, srcType, sv, flags));
+    bool beside = fixup && flags.masks && flags.side && (quad_serves(r, srcType, sv) || cell_serves(r, srcType, sv, flags) || wide_serves(r, srcType, sv));
     if (beside) {
         // a caller's stream that is being captured into a graph must not pull the plan's shared side stream into the
         // capture (another thread may use it meanwhile): the fix-up pass then follows the production pass in-stream

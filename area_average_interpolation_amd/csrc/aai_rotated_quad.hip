@@ -396,7 +396,7 @@ hipError_t launch_quad_typed(const RotLaunch &r, const QuadMap &m, const T *src,
 
 // How many source rows apart two lanes of one wave (a 16 x 4 dst tile) can read: their centres differ by at most
 // 15.6 dst pixel sides, each reaches half a window further, plus slack for rounding and clamping.
-static int quad_anchor_rows(const RotLaunch &r)
+int quad_anchor_rows(const RotLaunch &r)
 {
     const int win = (int)floor(2.0 * (r.h * (r.c + r.s) - 0.5 + 1e-5)) + 3;
     return (int)ceil(15.6 * 2.0 * r.h / r.scale) + win + 4;

@@ -1,0 +1,211 @@
+// aai_rotated_wide.hip -- K2 for WIDE footprints (dst pixels of more than ~5.5 source pixels a side at a general rotation):
+// the fp32 quad formulation (aai_rot_quad.hpp) over a window of up to 32 x 32 source pixels, split into 2 x 2 or 4 x 4
+// parts of at most 8 x 8 positions, ONE LANE PER PART.
+//
+// Replaces Source.cpp:413-579 + 986-1431 of the reference for these geometries, which the double-precision runs kernel
+// (aai_rotated_runs_kernel) served before: it read the source at a tenth of the HBM rate because every one of the ~5 L
+// boundary pairs of a dst pixel cost ~200 double-precision instructions in ONE lane, while a dst image of (W / L)^2 pixels has
+// too few lanes to fill the chip (8 : 1 on 8192^2: 16 k waves).  Here a dst pixel is 4 or 16 lanes -- four / sixteen times the
+// waves, each part a window the existing passes classify and evaluate in fp32 (an interior part is 36 ... 64 pixels of
+// area 1) -- and the partial sums meet in a butterfly of lane exchanges (quad_parts_sum spells the order out for the CPU replay).
+//
+// Decisions: as for the other fp32 kernels the plan's scan (aai_wide_scan_kernel: the same code and lane layout, no pixel
+// loads) flags the dst pixels with a decision too close to its threshold, the production kernel skips them and the
+// double-precision fix-up pass computes them beside it.
+//
+// Plain single-channel images without replication (scale 1: wide footprints never have any); interleaved channels and
+// the double-precision policy keep the runs kernel.
+#include "aai_kernels.hpp"
+#include "aai_rot_quad.hpp"
+#include "aai_quad_src.hpp"
+
+namespace aai {
+
+namespace {
+
+constexpr int wide_waves_per_simd(int win, bool hp)
+{
+    const int w = 160 / (win * win) >= 8 ? 8 : 160 / (win * win);
+    return hp && w > 2 ? w - 1 : w;
+}
+
+// lane -> (dst pixel, part).  A block of 256 lanes is 256 / PARTS^2 dst pixels of ONE 16-pixel-wide mask word region:
+// PARTS = 2: the 16 x 4 pixels of lane-mask word `sub` (0..3) of tile (bx, blockIdx.y); PARTS = 4: row `sub` (0..15) of the tile
+template <int PARTS>
+struct WideLane {
+    int dx, dy, partI, partJ;
+    size_t word;
+    int bit;
+    __device__ __forceinline__ WideLane(const RotLaunch &r, int tileRow0)
+    {
+        constexpr int LANES = PARTS * PARTS;
+        const int tid = threadIdx.x;
+        const int tilesX = (r.dW + 15) / 16;
+        const int sub = blockIdx.x / tilesX, bx = blockIdx.x - sub * tilesX;
+        const int p = tid / LANES, part = tid & (LANES - 1);
+        partI = part % PARTS; partJ = part / PARTS;
+        const int tileRow = tileRow0 + blockIdx.y;
+        if (PARTS == 2) {
+            dx = bx * 16 + (p & 15);
+            dy = tileRow * 16 + sub * 4 + (p >> 4);
+            word = ((size_t)tileRow * tilesX + bx) * 4 + sub;
+            bit = p;
+        } else {
+            dx = bx * 16 + p;
+            dy = tileRow * 16 + sub;
+            word = ((size_t)tileRow * tilesX + bx) * 4 + (sub >> 2);
+            bit = (sub & 3) * 16 + p;
+        }
+    }
+};
+
+// the parts' sums of one dst pixel: every lane of the pixel ends with the total (quad_parts_sum's order)
+template <int PARTS>
+__device__ __forceinline__ float wide_total(float v)
+{
+#pragma unroll
+    for (int o = 1; o < PARTS * PARTS; o <<= 1) v = v + __shfl_xor(v, o);
+    return v;
+}
+
+template <typename T, int WIN, bool HP, int PARTS>
+__global__ __launch_bounds__(kQuadBlock, wide_waves_per_simd(WIN, HP)) void aai_wide_kernel(RotLaunch r, QuadConsts<float> q, QuadMap m, const T *__restrict__ src,
+                                                                                           ImageView sv, float *__restrict__ dst, ImageView dv,
+                                                                                           const unsigned long long *__restrict__ skipMasks)
+{
+    __shared__ float window[WIN * WIN][kQuadBlock];
+    const WideLane<PARTS> l(r, r.dyBase / 16);
+    if (!(l.dx < r.dW && l.dy < r.dyEnd)) return;                     // (whole pixels: all lanes of a dst pixel decide alike)
+    if (skipMasks && ((skipMasks[l.word] >> l.bit) & 1ull)) return;   // flagged: the double-precision pass's, beside this kernel
+    double px, py;
+    pixel_centre(r, l.dx, l.dy, px, py);
+    const double cx = floor(px + 0.5), cy = floor(py + 0.5);
+    float sumA = 0.f, sumVA[1] = {0.f};
+    // a centre further than the window's reach from the lattice touches nothing (and stays inside int range)
+    if (cx > -40.0 && cx < (double)r.mW + 40.0 && cy > -40.0 && cy < (double)r.mH + 40.0) {
+        QuadSrc<T, WIN, false, true> s;
+        s.img = reinterpret_cast<const char *>(src + (int64_t)blockIdx.z * sv.imageStride + m.base);
+        s.m = &m; s.mW = r.mW; s.mH = r.mH; s.lds = window; s.tid = threadIdx.x;
+        quad_pixel<float, WIN, false, HP, 1, QuadSrc<T, WIN, false, true>, true>(q, (int)cx, (int)cy, px - cx, py - cy, r.mW, r.mH, s, sumA, sumVA, l.partI, l.partJ);
+    }
+    const float A = wide_total<PARTS>(sumA), VA = wide_total<PARTS>(sumVA[0]);
+    if ((threadIdx.x & (PARTS * PARTS - 1)) == 0)
+        dst[(int64_t)blockIdx.z * dv.imageStride + (int64_t)(l.dy - r.dyBase) * dv.rowStride + l.dx] = A > 0.f ? VA / A : 0.f;      // Source.cpp:577
+}
+
+// Once per geometry: the same lanes and arithmetic without pixel loads; a pixel one of whose parts has a decision within
+// QuadConsts::margin of its threshold, or whose total area is too small for fp32 weights, gets its bit in the lane masks
+template <int WIN, bool HP, int PARTS>
+__global__ __launch_bounds__(kQuadBlock) void aai_wide_scan_kernel(RotLaunch r, QuadConsts<float> q, unsigned long long *__restrict__ laneMasks,
+                                                                  unsigned *__restrict__ counter, int tileRow0)
+{
+    const WideLane<PARTS> l(r, tileRow0);
+    if (!(l.dx < r.dW && l.dy < r.dH)) return;
+    double px, py;
+    pixel_centre(r, l.dx, l.dy, px, py);
+    const double cx = floor(px + 0.5), cy = floor(py + 0.5);
+    float sumA = 0.f, sumVA[1] = {0.f};
+    bool uncertain = false;
+    if (cx > -40.0 && cx < (double)r.mW + 40.0 && cy > -40.0 && cy < (double)r.mH + 40.0) {
+        NoSrc s;
+        uncertain = quad_pixel<float, WIN, true, HP, 1, NoSrc, true>(q, (int)cx, (int)cy, px - cx, py - cy, r.mW, r.mH, s, sumA, sumVA, l.partI, l.partJ);
+    }
+    const float A = wide_total<PARTS>(sumA);
+    if (A > 0.f && A < q.minArea) uncertain = true;
+    if (uncertain) {
+        const unsigned long long bit = 1ull << l.bit;
+        const unsigned long long old = atomicOr(laneMasks + l.word, bit);
+        if (!(old & bit)) atomicAdd(counter, 1u);
+    }
+}
+
+template <typename T, int WIN, int PARTS>
+hipError_t launch_wide_win(const RotLaunch &r, const QuadConsts<float> &q, const QuadMap &m, const T *src, ImageView sv, float *dst, ImageView dv,
+                           int batch, const unsigned long long *skipMasks, hipStream_t stream)
+{
+    const int tilesX = (r.dW + 15) / 16;
+    const dim3 grid(tilesX * (PARTS == 2 ? 4 : 16), (r.dyEnd - r.dyBase + 15) / 16, batch);      // at most 65535 tile rows: the caller bands taller outputs
+    if (q.hiPrec) hipLaunchKernelGGL((aai_wide_kernel<T, WIN, true, PARTS>), grid, dim3(kQuadBlock), 0, stream, r, q, m, src, sv, dst, dv, skipMasks);
+    else hipLaunchKernelGGL((aai_wide_kernel<T, WIN, false, PARTS>), grid, dim3(kQuadBlock), 0, stream, r, q, m, src, sv, dst, dv, skipMasks);
+    return hipGetLastError();
+}
+
+template <typename T, int PARTS>
+hipError_t launch_wide_parts(const RotLaunch &r, const QuadConsts<float> &q, const QuadMap &m, const T *src, ImageView sv, float *dst, ImageView dv,
+                             int batch, const unsigned long long *skipMasks, hipStream_t stream)
+{
+    switch (q.win) {
+    case 5: return launch_wide_win<T, 5, PARTS>(r, q, m, src, sv, dst, dv, batch, skipMasks, stream);
+    case 6: return launch_wide_win<T, 6, PARTS>(r, q, m, src, sv, dst, dv, batch, skipMasks, stream);
+    case 7: return launch_wide_win<T, 7, PARTS>(r, q, m, src, sv, dst, dv, batch, skipMasks, stream);
+    case 8: return launch_wide_win<T, 8, PARTS>(r, q, m, src, sv, dst, dv, batch, skipMasks, stream);
+    default: return hipErrorInvalidValue;
+    }
+}
+
+template <typename T>
+hipError_t launch_wide_typed(const RotLaunch &r, const QuadMap &m, const T *src, ImageView sv, float *dst, ImageView dv, int batch,
+                             const unsigned long long *skipMasks, hipStream_t stream)
+{
+    const QuadConsts<float> q = make_quad_consts<float>(r.side, r.c, r.s, r.policy, r.scale);
+    if (q.parts != r.wide) return hipErrorInvalidValue;
+    if (q.parts == 2) return launch_wide_parts<T, 2>(r, q, m, src, sv, dst, dv, batch, skipMasks, stream);
+    return launch_wide_parts<T, 4>(r, q, m, src, sv, dst, dv, batch, skipMasks, stream);
+}
+
+template <int PARTS>
+hipError_t launch_wide_scan_parts(const RotLaunch &r, const QuadConsts<float> &q, unsigned long long *laneMasks, unsigned *counter, hipStream_t stream)
+{
+    const int tilesX = (r.dW + 15) / 16, tileRows = (r.dH + 15) / 16;
+    for (int t0 = 0; t0 < tileRows; t0 += 65535) {         // grid.y carries at most 65535 tiles
+        const dim3 grid(tilesX * (PARTS == 2 ? 4 : 16), tileRows - t0 < 65535 ? tileRows - t0 : 65535, 1);
+#define AAI_WIDE_SCAN(W)                                                                                                                       \
+    case W:                                                                                                                                    \
+        if (q.hiPrec) hipLaunchKernelGGL((aai_wide_scan_kernel<W, true, PARTS>), grid, dim3(kQuadBlock), 0, stream, r, q, laneMasks, counter, t0); \
+        else hipLaunchKernelGGL((aai_wide_scan_kernel<W, false, PARTS>), grid, dim3(kQuadBlock), 0, stream, r, q, laneMasks, counter, t0);     \
+        break;
+        switch (q.win) {
+            AAI_WIDE_SCAN(5) AAI_WIDE_SCAN(6) AAI_WIDE_SCAN(7) AAI_WIDE_SCAN(8)
+        default: return hipErrorInvalidValue;
+        }
+#undef AAI_WIDE_SCAN
+        const hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
+}
+
+}  // namespace
+
+bool wide_can_serve(const RotLaunch &r, int srcType, ImageView sv)
+{
+    static const bool off = [] { const char *e = getenv("AAI_WIDE"); return e && atoi(e) == 0; }();      // experiments: AAI_WIDE=0 keeps the runs kernel
+    if (off || !r.wide || r.mode != AAI_MODE_AREA || r.chan != 1 || r.scale != 1 || (r.dyBase & 15) != 0) return false;
+    // (tilesX * 16 blocks along grid.x)
+    if ((int64_t)((r.dW + 15) / 16) * 16 > 2147483647ll) return false;
+    return quad_can_address(r, srcType, sv);
+}
+
+hipError_t launch_wide(const RotLaunch &r, const QuadMap &map, const void *src, int srcType, ImageView sv, float *dst, ImageView dv,
+                       int batch, const unsigned long long *skipMasks, hipStream_t stream)
+{
+    if (r.dW <= 0 || r.dyEnd <= r.dyBase || batch <= 0) return hipSuccess;
+    QuadMap m = map;
+    const int64_t esz = srcType == SRC_U8 ? 1 : srcType == SRC_U16 ? 2 : 4;
+    m.anchorRows = (int64_t)r.H * sv.rowStride * esz >= ((int64_t)1 << 32) ? quad_anchor_rows(r) : 0;
+    switch (srcType) {
+    case SRC_U8: return launch_wide_typed(r, m, static_cast<const unsigned char *>(src), sv, dst, dv, batch, skipMasks, stream);
+    case SRC_U16: return launch_wide_typed(r, m, static_cast<const unsigned short *>(src), sv, dst, dv, batch, skipMasks, stream);
+    default: return launch_wide_typed(r, m, static_cast<const float *>(src), sv, dst, dv, batch, skipMasks, stream);
+    }
+}
+
+hipError_t launch_wide_scan(const RotLaunch &r, unsigned long long *laneMasks, unsigned *counter, hipStream_t stream)
+{
+    if (r.dW <= 0 || r.dH <= 0 || !r.wide) return hipSuccess;
+    const QuadConsts<float> q = make_quad_consts<float>(r.side, r.c, r.s, r.policy, r.scale);
+    if (q.parts != r.wide) return hipErrorInvalidValue;
+    return q.parts == 2 ? launch_wide_scan_parts<2>(r, q, laneMasks, counter, stream) : launch_wide_scan_parts<4>(r, q, laneMasks, counter, stream);
+}
+
+}  // namespace aai

@@ -280,6 +280,42 @@ static bool emu_quad_pixel(const QuadConsts<float> &qc, const RotLaunch &r, cons
     return true;
 }
 
+// wide footprints (aai_wide_kernel): the window in PARTS x PARTS parts, each a quad_pixel of its own, summed in the lanes' order
+template <int WIN>
+static bool emu_wide_pixel(const QuadConsts<float> &qc, const RotLaunch &r, const float *img, int64_t stride, double px, double py, float &value)
+{
+    const double cxr = std::floor(px + 0.5), cyr = std::floor(py + 0.5);
+    if (!(cxr > -40.0 && cxr < (double)r.mW + 40.0 && cyr > -40.0 && cyr < (double)r.mH + 40.0)) { value = 0.f; return true; }
+    const int Xc = (int)cxr, Yc = (int)cyr;
+    const double fpx = px - cxr, fpy = py - cyr;
+    const int n = qc.parts * qc.parts;
+    float a[16], va[16];
+    bool uncertain = false;
+    for (int pass = 0; pass < 2; ++pass)          // the plan's scan first, then the production arithmetic
+        for (int part = 0; part < n; ++part) {
+            EmuQuadSrc<WIN> qs{&r, img, stride, {}};
+            float sA, sVA[1];
+            const int pi = part % qc.parts, pj = part / qc.parts;
+            if (pass == 0) {
+                if (qc.hiPrec) uncertain |= quad_pixel<float, WIN, true, true, 1, EmuQuadSrc<WIN>, true>(qc, Xc, Yc, fpx, fpy, r.mW, r.mH, qs, sA, sVA, pi, pj);
+                else uncertain |= quad_pixel<float, WIN, true, false, 1, EmuQuadSrc<WIN>, true>(qc, Xc, Yc, fpx, fpy, r.mW, r.mH, qs, sA, sVA, pi, pj);
+            } else {
+                if (qc.hiPrec) quad_pixel<float, WIN, false, true, 1, EmuQuadSrc<WIN>, true>(qc, Xc, Yc, fpx, fpy, r.mW, r.mH, qs, sA, sVA, pi, pj);
+                else quad_pixel<float, WIN, false, false, 1, EmuQuadSrc<WIN>, true>(qc, Xc, Yc, fpx, fpy, r.mW, r.mH, qs, sA, sVA, pi, pj);
+            }
+            a[part] = sA; va[part] = sVA[0];
+            if (pass == 0 && part == n - 1) {
+                float t[16];
+                for (int k = 0; k < n; ++k) t[k] = a[k];
+                const float A = quad_parts_sum(t, n);
+                if (uncertain || (A > 0.f && A < qc.minArea)) return false;
+            }
+        }
+    const float A = quad_parts_sum(a, n), VA = quad_parts_sum(va, n);
+    value = A > 0.f ? VA / A : 0.f;
+    return true;
+}
+
 // fast mode through the fp32 formulation (aai_quad_fast_kernel)
 template <int WIN>
 static bool emu_quad_fast_pixel(const QuadConsts<float> &qc, const RotLaunch &r, const float *img, int64_t stride, double px, double py, float &value)
@@ -369,7 +405,7 @@ static void emu_rotated(const Geometry &g, const aai_request &rq, const float *i
     const RotLaunch r = make_rot_launch(g, rq.mode, rq.policy);
     g_knifePairs = g_knifePixels = g_missedPairs = 0;
     g_quadPixels = g_quadUncertain = 0;
-    const bool quad = g_useQuad && r.quad;
+    const bool quad = g_useQuad && (r.quad || r.wide);
     const bool fastQuad = rq.mode == AAI_MODE_FAST;
     const QuadConsts<float> qc = make_quad_consts<float>(r.side, r.c, r.s, r.policy, r.scale);
     EmuCells cells;
@@ -408,6 +444,13 @@ static void emu_rotated(const Geometry &g, const aai_request &rq, const float *i
                     case 6: done = emu_quad_fast_pixel<6>(qc, r, img, srcStride, px, py, value); break;
                     case 7: done = emu_quad_fast_pixel<7>(qc, r, img, srcStride, px, py, value); break;
                     default: done = emu_quad_fast_pixel<8>(qc, r, img, srcStride, px, py, value); break;
+                    }
+                } else if (r.wide) {
+                    switch (qc.win) {
+                    case 5: done = emu_wide_pixel<5>(qc, r, img, srcStride, px, py, value); break;
+                    case 6: done = emu_wide_pixel<6>(qc, r, img, srcStride, px, py, value); break;
+                    case 7: done = emu_wide_pixel<7>(qc, r, img, srcStride, px, py, value); break;
+                    default: done = emu_wide_pixel<8>(qc, r, img, srcStride, px, py, value); break;
                     }
                 } else {
                     switch (qc.win) {
@@ -644,6 +687,15 @@ int aai_emu_uses_runs(const aai_request *rq)
     return make_rot_launch(g, rq->mode, rq->policy).runs;
 }
 
+// parts per axis of the fp32 window of a wide footprint (RotLaunch::wide; 0: not one)
+int aai_emu_wide_parts(const aai_request *rq)
+{
+    Geometry g;
+    std::string msg;
+    if (make_geometry(*rq, g, msg) != AAI_OK || g.axisAligned) return 0;
+    return make_rot_launch(g, rq->mode, rq->policy).wide;
+}
+
 // Property behind the rows-as-runs kernel: for every dst pixel and every line of its window, line_runs' interior
 // pixels are PAIR_INSIDE for classify_pair and the pixels outside its touched interval are PAIR_OUTSIDE -- along rows
 // and along columns.  Returns the number of violations (0 expected), -1 on a bad request.
@@ -724,6 +776,41 @@ long aai_emu_cell_band_cover(const aai_request *rq, int r0, int r1)
                     const int row = (int)(off >> 20);
                     if (row < a || row >= b) ++outside;
                 }
+        }
+    return outside;
+}
+
+// The same for the wide-footprint kernel (aai_wide_kernel): every part's window of every dst pixel of rows [r0, r1), clamped like
+// QuadSrc::issue clamps it.  -1: not a wide footprint.
+long aai_emu_wide_band_cover(const aai_request *rq, int r0, int r1)
+{
+    Geometry g; std::string msg;
+    if (make_geometry(*rq, g, msg) != AAI_OK) return -2;
+    const RotLaunch r = make_rot_launch(g, rq->mode, rq->policy);
+    if (!r.wide) return -1;
+    int a = 0, b = 0;
+    rotated_band_source_rows(g, r0, r1, false, a, b);
+    const QuadConsts<float> q = make_quad_consts<float>(r.side, r.c, r.s, r.policy, r.scale);
+    long outside = 0;
+    for (int dy = r0; dy < r1; ++dy)
+        for (int dx = 0; dx < r.dW; ++dx) {
+            double px, py;
+            pixel_centre(r, dx, dy, px, py);
+            const double cx = std::floor(px + 0.5), cy = std::floor(py + 0.5);
+            if (!(cx > -40.0 && cx < (double)r.mW + 40.0 && cy > -40.0 && cy < (double)r.mH + 40.0)) continue;
+            const float fpx = (float)(px - cx), fpy = (float)(py - cy);
+            for (int part = 0; part < q.parts * q.parts; ++part) {
+                const int xg0 = (int)cx + (int)(std::floor(fpx - q.hbm) + (float)((part % q.parts) * q.win));
+                const int yg0 = (int)cy + (int)(std::floor(fpy - q.hbm) + (float)((part / q.parts) * q.win));
+                if (xg0 > r.mW - 1 || xg0 + q.win - 1 < 0 || yg0 > r.mH - 1 || yg0 + q.win - 1 < 0) continue;      // the part misses the lattice: nothing is fetched
+                for (int j = 0; j < q.win; ++j)
+                    for (int i = 0; i < q.win; ++i) {
+                        const int X = std::min(std::max(xg0 + i, 0), r.mW - 1), Y = std::min(std::max(yg0 + j, 0), r.mH - 1);
+                        const int64_t off = virt_offset(r, X, Y, /*rowStride*/ 1 << 20);
+                        const int row = (int)(off >> 20);
+                        if (row < a || row >= b) ++outside;
+                    }
+            }
         }
     return outside;
 }

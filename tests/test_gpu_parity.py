@@ -183,9 +183,11 @@ def test_axis_kernel_code_paths_against_oracle(gpu, po):
     assert {"aai_axis_kernel", "aai_axis_wide_kernel", "aai_axis_tile_kernel"} <= seen, seen
 
 
-def test_rows_as_runs_kernel_against_oracle(gpu, formulation, po):
-    """Large footprints (heavy down-sampling at an angle) take aai_rotated_runs_kernel: boundary / interior / boundary
-    runs per source row.  Same cases as the CPU replay test, plus 8- and 16-bit sources and a batch."""
+def test_wide_footprints_against_oracle(gpu, formulation, po):
+    """Large footprints (heavy down-sampling at an angle): aai_wide_kernel -- the fp32 formulation over a window split into
+    2 x 2 or 4 x 4 parts, a lane per part -- up to windows of 32 x 32 source pixels, aai_rotated_runs_kernel (double precision:
+    boundary / interior / boundary runs per source row) beyond that, within 0.006 degrees of an axis and under
+    AAI_POLICY_DOUBLE_PRECISION.  Same cases as the CPU replay test, plus 8- and 16-bit sources."""
     from area_average_interpolation_amd import _lib as L
     rng = np.random.default_rng(78)
     kernels = set()
@@ -197,8 +199,8 @@ def test_rows_as_runs_kernel_against_oracle(gpu, formulation, po):
             rc, msg, dst, giso, lay = gpu.resample_host(src, sr, dr, iso, ang, mode=1, policy=policy)
             assert rc == 0, msg
             # (footprints whose window still fits the fp32 formulations -- up to about 5.5 : 1 -- take the cell kernel)
-            assert any(n in gpu.last_kernel() for n in ("aai_rotated_runs_kernel", "aai_cell_kernel", "aai_quad_kernel")), (k, gpu.last_kernel())
-            kernels.add(gpu.last_kernel())
+            assert any(n in gpu.last_kernel() for n in ("aai_rotated_runs_kernel", "aai_wide_kernel", "aai_cell_kernel", "aai_quad_kernel")), (k, gpu.last_kernel())
+            kernels.add(gpu.last_kernel().split("<")[0])
             assert dst.shape == gold.dst.shape and tuple(giso) == gold.dst_iso
             assert rel_err(dst, gold.dst).max() <= TOL, (k, policy, W, H, sr, ang)
             assert np.array_equal(gold.dst == 0, dst == 0), (k, policy)
@@ -210,6 +212,14 @@ def test_rows_as_runs_kernel_against_oracle(gpu, formulation, po):
                 assert rc == 0, msg
                 assert (np.abs(dst - gold.dst) / np.maximum(np.abs(gold.dst), 1e-3 * top)).max() <= TOL, (k, dt)
                 assert np.array_equal(gold.dst == 0, dst == 0), (k, dt)
+    assert {"aai_wide_kernel", "aai_rotated_runs_kernel"} <= kernels, kernels
+    # the same request under the double-precision policy stays on the runs kernel and agrees to fp32 rounding
+    W, H, sr, dr, ang, off = RUNS_CASES[2]
+    iso = ((W - 1) / 2, (H - 1) / 2)
+    src = rng.random((H, W)).astype(np.float32)
+    gold = po.oracle_run(po.MODE_EXACT, src.astype(np.float64), sr, dr, iso, ang).dst
+    rc, msg, dst, _, _ = gpu.resample_host(src, sr, dr, iso, ang, mode=1, policy=gpu.POLICY_DOUBLE_PRECISION)
+    assert rc == 0 and "aai_rotated_runs_kernel" in gpu.last_kernel() and rel_err(dst, gold).max() <= 2e-7, (msg, gpu.last_kernel())
 
 
 def test_near_axis_rotations_against_oracle(gpu, formulation, po):
@@ -728,9 +738,9 @@ def test_interleaved_channels_equal_planar_calls(gpu, po):
                 # the planar image is too narrow for the strip kernel (per-pixel fallback), the interleaved one is not:
                 # same weights, different summation order
                 assert rel_err(dst[:, :, c], planar, floor=1e-3 * float(src.max())).max() <= 1e-6, (k, c)
-            elif ("aai_quad" in gpu.last_kernel()) != ("aai_quad" in kern_interleaved):
+            elif any(t in gpu.last_kernel() for t in ("aai_quad", "aai_cell", "aai_wide")) != any(t in kern_interleaved for t in ("aai_quad", "aai_cell", "aai_wide")):
                 # one of the two calls takes the fp32 quad formulation, the other a double-precision kernel (an interleaved
-                # window too large to stage: areas shared between the channels in fp64): same areas to ~1e-7
+                # window too large to stage, or a wide footprint: areas shared between the channels in fp64): same areas to ~1e-7
                 assert rel_err(dst[:, :, c], planar, floor=1e-3 * float(src.max())).max() <= 2e-6, (k, c)
                 assert np.array_equal(dst[:, :, c] == 0, planar == 0), (k, c)
             else:
@@ -954,6 +964,39 @@ def test_quad_kernel_equals_its_cpu_replay_bit_for_bit(gpu, hostemu, po):
                 # flagged pixels go through the double-precision kernels, whose summation order differs from the replay's
                 assert differ <= flagged, (W, H, sr, dr, ang, mode, differ, flagged, quad)
                 assert rel_err(dst, ref).max() <= 3e-7
+    finally:
+        hostemu.aai_emu_use_quad(0)
+
+
+def test_wide_kernel_equals_its_cpu_replay_bit_for_bit(gpu, hostemu, po):
+    """aai_wide_kernel (a dst pixel = 4 or 16 lanes, one per part of its window, partial sums exchanged in a butterfly) against
+    the CPU replay, which evaluates the parts one after the other and adds them in the butterfly's order: bit for bit outside
+    the pixels the scan leaves to the double-precision pass.  2 x 2 and 4 x 4 parts, every part size (5 ... 8), every
+    quadrant, both policies, hiPrec (close to an axis), 8-bit sources, more than one tile row and column."""
+    rng = np.random.default_rng(79)
+    hostemu.aai_emu_use_quad(1)
+    try:
+        for (W, H, sr, dr, ang, policy, parts) in ((512, 400, 8.0, 1.0, 17.5, 0, 2), (400, 512, 6.0, 1.0, 45.0, 1, 2), (640, 512, 10.5, 1.0, 123.0, 0, 2),
+                                                   (512, 512, 7.0, 1.0, 211.0, 0, 2), (600, 600, 9.3, 1.1, 300.0, 0, 2), (700, 512, 16.0, 1.0, 45.0, 0, 4),
+                                                   (800, 640, 21.0, 1.0, 100.0, 1, 4), (640, 800, 13.0, 1.0, 250.0, 0, 4), (512, 512, 9.0, 1.0, 0.7, 0, 2),
+                                                   (900, 500, 26.0, 1.0, 88.5, 0, 4), (1400, 1100, 8.0, 1.0, 17.5, 0, 2)):
+            iso = (float(rng.uniform(0.3 * W, 0.7 * W)), float(rng.uniform(0.3 * H, 0.7 * H)))
+            src = rng.random((H, W)).astype(np.float32)
+            rq = gpu.make_request(W, H, sr, dr, iso, ang, mode=1, policy=policy)
+            assert hostemu.aai_emu_wide_parts(ctypes.byref(rq)) == parts, (sr, ang)
+            ref, axis = hostemu.resample(rq, src)
+            wide, flagged = hostemu.quad_stats()
+            rc, msg, dst, _, lay = gpu.resample_host(src, sr, dr, iso, ang, mode=1, policy=policy)
+            assert rc == 0 and "aai_wide_kernel" in gpu.last_kernel(), (msg, gpu.last_kernel())
+            differ = int((dst != ref).sum())
+            assert wide > 0 and differ <= flagged, (W, H, sr, dr, ang, differ, flagged, wide)
+            assert rel_err(dst, ref).max() <= 3e-7
+        isrc = rng.integers(0, 256, size=(480, 640)).astype(np.uint8)
+        rq = gpu.make_request(640, 480, 8.0, 1.0, (300.0, 250.0), 33.0, mode=1)
+        ref, _ = hostemu.resample(rq, isrc.astype(np.float32))
+        wide, flagged = hostemu.quad_stats()
+        rc, msg, dst, _, _ = gpu.resample_host(isrc, 8.0, 1.0, (300.0, 250.0), 33.0, mode=1)
+        assert rc == 0 and "aai_wide_kernel" in gpu.last_kernel() and int((dst != ref).sum()) <= flagged
     finally:
         hostemu.aai_emu_use_quad(0)
 

@@ -649,6 +649,30 @@ def test_band_source_rows_hold_every_window_the_cell_kernel_fetches(aai, hostemu
     assert checked > 150, checked
 
 
+def test_band_source_rows_hold_every_window_the_wide_kernel_fetches(aai, hostemu):
+    """The same for aai_wide_kernel: its parts overhang the footprint's window by up to parts - 1 positions, and every fetched
+    position (clamped to the lattice, not to the band) must lie inside the rows aai_band_source_rows reports."""
+    import ctypes
+    rng = np.random.default_rng(9)
+    checked = 0
+    for k in range(120):
+        W, H = int(rng.integers(300, 700)), int(rng.integers(300, 700))
+        sr = float(rng.uniform(5.6, 22.0))
+        ang = float(rng.uniform(0.5, 89.5)) + 90.0 * (k % 4)
+        iso = (float(rng.uniform(-3, W + 3)), float(rng.uniform(-3, H + 3)))
+        rq = aai.make_request(W, H, sr, float(rng.uniform(0.9, 1.1)), iso, ang, mode=1)
+        rc, msg, lay = aai.query(rq)
+        if rc != 0 or lay.dst_height < 32:
+            continue
+        for _ in range(3):
+            r0 = 16 * int(rng.integers(0, lay.dst_height // 16))
+            r1 = int(rng.integers(r0 + 1, lay.dst_height + 1))
+            out = hostemu.aai_emu_wide_band_cover(ctypes.byref(rq), r0, r1)
+            assert out in (0, -1), (W, H, sr, ang, iso, r0, r1, out)
+            checked += out == 0
+    assert checked > 150, checked
+
+
 def test_cell_live_row_interval_is_a_superset(aai, hostemu):
     """The cell kernel skips the cell rows outside cell_live_rows' interval for its 64 columns without computing anything
     (the empty corners of a rotated canvas): no cell outside the interval may contribute.  Random geometries, all quadrants,
@@ -721,6 +745,44 @@ def test_quad_fp32_replay_against_oracle_at_larger_sizes(aai, hostemu, po):
             assert np.array_equal(gold == 0, out == 0)
     finally:
         hostemu.aai_emu_use_quad(0)
+
+
+def test_wide_fp32_replay_against_oracle(aai, hostemu, po):
+    """Footprints wider than one 8 x 8 window (ratios above ~5.5 : 1 at an angle): the fp32 formulation over a window split
+    into 2 x 2 or 4 x 4 parts (csrc/aai_rotated_wide.hip), replayed on the CPU in the kernel's arithmetic and summation order."""
+    hostemu.aai_emu_use_quad(1)
+    try:
+        for (W, H, sr, dr, ang, policy, iso) in ((512, 512, 8.0, 1.0, 17.5, 0, None), (600, 480, 6.0, 1.0, 45.0, 0, None), (640, 512, 11.0, 1.0, 33.0, 1, None),
+                                                (800, 700, 16.0, 1.0, 61.0, 0, None), (768, 768, 21.0, 1.0, 45.0, 0, None), (700, 900, 14.3, 1.7, 200.5, 0, (311.2, 420.9)),
+                                                # close to an axis: hiPrec
+                                                (640, 640, 9.0, 1.0, 0.7, 0, None), (640, 640, 12.0, 1.0, 89.2, 1, None), (900, 500, 28.0, 1.0, 2.0, 0, None)):
+            src = po.synth_image(W, H, 3)
+            iso = iso or ((W - 1) / 2, (H - 1) / 2)
+            out, axis = hostemu.resample(aai.make_request(W, H, sr, dr, iso, ang, mode=1, policy=policy), src)
+            q, u = hostemu.quad_stats()
+            gold = po.oracle_run(po.MODE_EXACT, src.astype(np.float64), sr, dr, iso, ang, policy=policy).dst
+            assert not axis and q > 0 and u < 0.02 * q + 2, (W, sr, dr, ang, q, u)
+            assert rel_err(out, gold).max() <= 0.3 * TOL, (W, sr, dr, ang, float(rel_err(out, gold).max()))
+            assert np.array_equal(gold == 0, out == 0)
+        # 8-bit noise, where a dst value can lie far below its neighbours
+        for (W, H, sr, dr, ang, policy) in ((400, 400, 8.0, 1.0, 17.5, 0), (500, 400, 13.0, 1.0, 45.0, 0), (400, 400, 7.0, 1.0, 1.0, 0)):
+            iso = ((W - 1) / 2, (H - 1) / 2)
+            for seed in range(2):
+                src = np.random.default_rng(seed).integers(0, 256, size=(H, W)).astype(np.float32)
+                gold = po.oracle_run(po.MODE_EXACT, src.astype(np.float64), sr, dr, iso, ang, policy=policy).dst
+                out, _ = hostemu.resample(aai.make_request(W, H, sr, dr, iso, ang, mode=1, policy=policy), src)
+                assert hostemu.quad_stats()[0] > 0
+                assert rel_err(out, gold, floor=0.256).max() <= 2e-6, (W, sr, ang, float(rel_err(out, gold, floor=0.256).max()))
+    finally:
+        hostemu.aai_emu_use_quad(0)
+    # the geometry rule: one window up to 8 x 8, 2 x 2 parts up to 16 x 16, 4 x 4 up to 32 x 32, beyond that the double-precision kernels
+    def plan_of(sr, ang):
+        return aai.make_request(2048, 2048, sr, 1.0, (1023.5, 1023.5), ang, mode=1)
+    assert hostemu.aai_emu_wide_parts(ctypes.byref(plan_of(5.0, 17.5))) == 0
+    assert hostemu.aai_emu_wide_parts(ctypes.byref(plan_of(8.0, 17.5))) == 2
+    assert hostemu.aai_emu_wide_parts(ctypes.byref(plan_of(16.0, 45.0))) == 4
+    assert hostemu.aai_emu_wide_parts(ctypes.byref(plan_of(40.0, 45.0))) == 0
+    assert hostemu.aai_emu_wide_parts(ctypes.byref(plan_of(8.0, 0.0))) == 0          # axis-aligned: K1
 
 
 def test_double_precision_policy_keeps_requests_off_the_fp32_formulation(aai, hostemu, po):
