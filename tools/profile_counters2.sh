@@ -19,7 +19,7 @@ for f in sorted(glob.glob(out + "/*/**/*kernel_trace.csv", recursive=True))[:1]:
 for f in sorted(glob.glob(out + "/*/**/*counter_collection.csv", recursive=True)):
     acc = collections.defaultdict(list)
     for row in csv.DictReader(open(f)):
-        if "aai_cell_kernel" in row["Kernel_Name"] or "aai_quad_kernel" in row["Kernel_Name"] or "aai_quad_fast" in row["Kernel_Name"]:
+        if any(t in row["Kernel_Name"] for t in ("aai_cell_kernel", "aai_quad_kernel", "aai_quad_fast", "aai_wide_kernel", "aai_rotated_runs")):
             acc[(row["Kernel_Name"][:60], row["Counter_Name"])].append(float(row["Counter_Value"]))
     for (k, c), v in sorted(acc.items()):
         print("%-60s %-24s n=%d mean=%.6g" % (k, c, len(v), sum(v) / len(v)))
