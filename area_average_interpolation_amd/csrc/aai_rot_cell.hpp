@@ -167,19 +167,21 @@ AAI_HD bool cell_eval(const QuadConsts<F> &q, const CellConsts<F> &z, int Zx, in
     bool uncertain = false;
 
     // ---- pass 1: which zone does every lattice point of the window belong to ------------------------------------------
-    u64 pZ = 0, pV = 0, pH = 0;           // in this cell's zone; within k of the vertical / horizontal grid line through G
+    QuadPlane<WIN> plZ, plV, plH;         // in this cell's zone; within k of the vertical / horizontal grid line through G
 #pragma unroll
-    for (int j = 0; j < WIN; ++j) {
+    for (int jj = 0; jj < WIN; ++jj) {
+        const int j = WIN - 1 - jj;                                  // (last slot first: QuadPlane)
         const F fj = fj0 + (F)j;
         const F rowA = qfma(-fj, q.s, ac), rowB = qfma(fj, q.c, bc);
 #pragma unroll
-        for (int i = 0; i < WIN; ++i) {
+        for (int ii = 0; ii < WIN; ++ii) {
+            const int i = WIN - 1 - ii;
             const F fi = fi0 + (F)i;
             const F az = qfma(fi, q.c, rowA), bz = qfma(fi, q.s, rowB);
             const u64 bit = (u64)1 << (j * WIN + i);
-            if (qabs(az) < q.h && qabs(bz) < q.h) pZ |= bit;
-            if (az < z.thr) pV |= bit;
-            if (bz < z.thr) pH |= bit;
+            plZ.push(j * WIN + i, qabs(az) < q.h && qabs(bz) < q.h);
+            plV.push(j * WIN + i, az < z.thr);
+            plH.push(j * WIN + i, bz < z.thr);
             if (SCAN) {
                 const bool live = (valid & bit) != 0;
                 const F na = qabs(qabs(az) - q.h), nb = qabs(qabs(bz) - q.h);
@@ -188,6 +190,8 @@ AAI_HD bool cell_eval(const QuadConsts<F> &q, const CellConsts<F> &z, int Zx, in
             }
         }
     }
+    u64 pZ = plZ.mask();
+    const u64 pV = plV.mask(), pH = plH.mask();
     pZ &= valid;
     u64 mVtx = pZ & pV & pH, mLeft = pZ & pV & ~pH, mTop = pZ & ~pV & pH, mIn = pZ & ~pV & ~pH;
     if (!SCAN) src.commit();

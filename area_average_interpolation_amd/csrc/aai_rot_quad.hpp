@@ -280,6 +280,28 @@ AAI_HD int quad_ctz(unsigned m)
 template <int WIN, bool SMALL = (WIN * WIN <= 32)> struct QuadMask { typedef unsigned long long type; };
 template <int WIN> struct QuadMask<WIN, true> { typedef unsigned type; };
 
+// A plane of window-slot bits, filled from the LAST slot down to slot 0: p = 2 p + bit is ONE instruction per plane and position
+// on the GPU (v_addc_co_u32 with the compare's lane mask as carry-in) where "if (c) p |= bit" is a select and an or.
+AAI_HD void quad_push_bit(unsigned &p, bool bit)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    const unsigned long long lanes = __builtin_amdgcn_ballot_w64(bit);      // the lane mask the compare produced (an SGPR pair)
+    asm("v_addc_co_u32 %0, vcc, %0, %0, %1" : "+v"(p) : "s"(lanes) : "vcc");
+#else
+    p = p + p + (bit ? 1u : 0u);
+#endif
+}
+template <int WIN>
+struct QuadPlane {
+    unsigned lo = 0, hi = 0;
+    AAI_HD void push(int slot, bool bit) { if (slot >= 32) quad_push_bit(hi, bit); else quad_push_bit(lo, bit); }      // slots in DESCENDING order
+    AAI_HD typename QuadMask<WIN>::type mask() const
+    {
+        typedef typename QuadMask<WIN>::type mask_t;
+        return WIN * WIN <= 32 ? (mask_t)lo : (mask_t)(((unsigned long long)hi << 32) | lo);
+    }
+};
+
 // One dst pixel.  WIN = window positions per axis (QuadConsts::win, a compile-time constant so that the window pass
 // unrolls and the staged window has a fixed size); window position (i, j) is bit / slot j * WIN + i.
 // (Xc, Yc) = the virtual pixel nearest the centre, (fpx, fpy) = centre - (Xc, Yc), both in [-1/2, 1/2].
@@ -356,19 +378,21 @@ AAI_HD bool quad_pixel(const QuadConsts<F> &q, int Xc, int Yc, double dfx, doubl
 
     // ---- pass 1: classify every window position --------------------------------------------------------------
     // bit planes: |a| <= h - k, |b| <= h - k, touched; the class masks follow from them with three 64-bit operations
-    u64 pA = 0, pB = 0, pT = 0;
+    QuadPlane<WIN> plA, plB, plT;
 #pragma unroll
-    for (int j = 0; j < WIN; ++j) {
+    for (int jj = 0; jj < WIN; ++jj) {
+        const int j = WIN - 1 - jj;                                  // (last slot first: QuadPlane)
         const F fj = fj0 + (F)j;
         const F rowA = qfma(-fj, q.s, ac), rowB = qfma(fj, q.c, bc);
 #pragma unroll
-        for (int i = 0; i < WIN; ++i) {
+        for (int ii = 0; ii < WIN; ++ii) {
+            const int i = WIN - 1 - ii;
             const F fi = fi0 + (F)i;
             const F a = qabs(qfma(fi, q.c, rowA)), b = qabs(qfma(fi, q.s, rowB));
             const u64 bit = (u64)1 << (j * WIN + i);
-            if (a <= q.hmk) pA |= bit;
-            if (b <= q.hmk) pB |= bit;
-            if (a < q.hpk && b < q.hpk) pT |= bit;
+            plA.push(j * WIN + i, a <= q.hmk);
+            plB.push(j * WIN + i, b <= q.hmk);
+            plT.push(j * WIN + i, a < q.hpk && b < q.hpk);
             if (SCAN) {
                 // thresholds of |a| (the left/right line also switches formula at t = lo, hi under policy REFERENCE)
                 // and of |b|; one axis' thresholds only matter while the other axis does not already say "outside"
@@ -380,6 +404,8 @@ AAI_HD bool quad_pixel(const QuadConsts<F> &q, int Xc, int Yc, double dfx, doubl
             }
         }
     }
+    const u64 pA = plA.mask(), pB = plB.mask();
+    u64 pT = plT.mask();
     pT &= valid;
     u64 mIn = pA & pB & valid;                 // wholly inside (inside implies touched: h - k < h + k)
     u64 mSingle = pT & (pA ^ pB);              // one near line clear of the pixel, the other cuts it
