@@ -53,11 +53,14 @@ WORKLOADS = {
     "cfg4": (4096, 4096, 4.0, 1.0, 0.0, MODE_AREA, "4096x4096 fp32 -> 1024x1024, rotation 0"),
     "cfg5s": (512, 512, 1.0, 4.0, 45.0, MODE_AREA, "512x512 fp32 -> 2896x2896 (x4 up), rotation 45 (1/8 linear scale of cfg5)"),
     "cfg5": (4096, 4096, 1.0, 4.0, 45.0, MODE_AREA, "4096x4096 fp32 -> 23170x23170 (x4 up), rotation 45"),
+    "cfg5fast": (4096, 4096, 1.0, 4.0, 45.0, MODE_FAST, "4096x4096 fp32 -> 23170x23170 (x4 up), rotation 45, fast mode"),
     "cfg5bilinear": (4096, 4096, 1.0, 4.0, 45.0, MODE_BILINEAR, "4096x4096 fp32 -> 23170x23170, rotation 45, bilinear"),
     "cfg5bicubic": (4096, 4096, 1.0, 4.0, 45.0, MODE_BICUBIC, "4096x4096 fp32 -> 23170x23170, rotation 45, bicubic"),
     # the reference's own example call, Source.cpp:1528-1534 (isocenter (455, 455), mode 2 = fast is its default)
     "refdefault": (911, 911, 150.0, 25.4, 1.5, MODE_AREA, "911x911 fp32 at 150 dpi -> 25.4 dpi (158x158), rotation 1.5, isocenter (455,455)"),
     "refdefaultfast": (911, 911, 150.0, 25.4, 1.5, MODE_FAST, "911x911 fp32 at 150 dpi -> 25.4 dpi (158x158), rotation 1.5, isocenter (455,455), fast mode"),
+    # not a BASELINE configuration: a wide footprint (the reference's default ratio is 5.9:1; film at 200 dpi -> 25.4 dpi is 8:1) at config 3's angle
+    "wide8": (8192, 8192, 8.0, 1.0, 17.5, MODE_AREA, "8192x8192 fp32 -> 1284x1284 (8:1), rotation 17.5"),
 }
 ISOCENTER = {"refdefault": (455.0, 455.0), "refdefaultfast": (455.0, 455.0)}      # default: the image centre
 
@@ -67,8 +70,8 @@ def isocenter(name, W, H):
 
 
 # the `configs` block of the default invocation: (workload, images per launch)
-CONFIG_SET = [("cfg1", 4), ("cfg2", 1), ("cfg3", 1), ("cfg3fast", 1), ("cfg4", 64), ("cfg5", 1), ("cfg5bilinear", 1), ("cfg5bicubic", 1),
-              ("refdefault", 1), ("refdefaultfast", 1)]
+CONFIG_SET = [("cfg1", 4), ("cfg2", 1), ("cfg3", 1), ("cfg3fast", 1), ("cfg4", 64), ("cfg5", 1), ("cfg5fast", 1), ("cfg5bilinear", 1), ("cfg5bicubic", 1),
+              ("refdefault", 1), ("refdefaultfast", 1), ("wide8", 1)]
 
 
 # ---- CPU baseline -----------------------------------------------------------------------------------------------

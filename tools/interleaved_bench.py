@@ -21,10 +21,13 @@ def timed(fn, n=7):
     return sorted(t)[n // 2]
 
 
-for (W, sr, dr, ang, C, dt) in ((8192, 8192.0, 2731.0, 17.5, 3, "f32"), (8192, 8192.0, 2731.0, 17.5, 3, "u8"), (8192, 8192.0, 2731.0, 17.5, 4, "u8"),
-                                (8192, 4.0, 1.0, 0.5, 3, "u8"), (8192, 1.0, 1.0, 1.0, 3, "u8"), (4096, 1.0, 2.0, 30.0, 3, "f32")):
+for (W, sr, dr, ang, C, dt, mode) in ((8192, 8192.0, 2731.0, 17.5, 3, "f32", 1), (8192, 8192.0, 2731.0, 17.5, 3, "u8", 1), (8192, 8192.0, 2731.0, 17.5, 4, "u8", 1),
+                                      (8192, 4.0, 1.0, 0.5, 3, "u8", 1), (8192, 1.0, 1.0, 1.0, 3, "u8", 1), (4096, 1.0, 2.0, 30.0, 3, "f32", 1),
+                                      # fast mode (the reference's default mode)
+                                      (8192, 8192.0, 2731.0, 17.5, 1, "f32", 2), (8192, 8192.0, 2731.0, 17.5, 3, "f32", 2), (8192, 8192.0, 2731.0, 17.5, 3, "u8", 2),
+                                      (8192, 8192.0, 2731.0, 17.5, 4, "u8", 2), (4096, 1.0, 2.0, 30.0, 3, "u8", 2)):
     H = W
-    rq = aai.make_request(W, H, sr, dr, ((W - 1) / 2, (H - 1) / 2), ang)
+    rq = aai.make_request(W, H, sr, dr, ((W - 1) / 2, (H - 1) / 2), ang, mode=mode)
     rc, msg, lay = aai.query(rq)
     dW, dH = lay.dst_width, lay.dst_height
     planar = torch.rand((C, H, W), dtype=torch.float32, device="cuda")
@@ -38,5 +41,5 @@ for (W, sr, dr, ang, C, dt) in ((8192, 8192.0, 2731.0, 17.5, 3, "f32"), (8192, 8
     ki = aai.last_kernel()
     tp = timed(lambda: aai.resample_device(rq, planar.data_ptr(), W, outp.data_ptr(), dW, st, batch=C, src_image_stride=W * H, dst_image_stride=dW * dH, src_dtype=code))
     same = bool(torch.equal(outi.permute(2, 0, 1), outp))
-    print("%5d^2 %g:%g angle %-5g C=%d %-3s  interleaved %.3f ms (%s)   %d planar %.3f ms (%s)   identical %s" % (
-        W, sr, dr, ang, C, dt, ti, ki, C, tp, aai.last_kernel(), same))
+    print("%5d^2 %g:%g angle %-5g mode %d C=%d %-3s  interleaved %.3f ms (%s)   %d planar %.3f ms (%s)   identical %s" % (
+        W, sr, dr, ang, mode, C, dt, ti, ki, C, tp, aai.last_kernel(), same))
