@@ -260,6 +260,18 @@ static int build_plan(Plan &p)
         if (p.kernel == AAI_KERNEL_AXIS) tune_axis_plan(p, channels, band0, bs);
         stage("launch-shape measurement");
     }
+    if (p.kernel == AAI_KERNEL_ROTATED || p.kernel == AAI_KERNEL_FAST || p.kernel == AAI_KERNEL_SAMPLE) {
+        // the corners of a rotated canvas hold nothing: which tiles of each tile row can (the whole image's table; bands index it by row)
+        std::vector<int> spans;
+        aai::rotated_live_spans(aai::make_rot_launch(g, rq.mode, rq.policy), p.kernel == AAI_KERNEL_SAMPLE, spans);
+        if (!spans.empty()) {
+            hipError_t e = hipMalloc((void **)&p.dLive, spans.size() * sizeof(int));
+            if (e == hipSuccess) e = hipMemcpyAsync(p.dLive, spans.data(), spans.size() * sizeof(int), hipMemcpyHostToDevice, bs);
+            if (e == hipSuccess) e = hipStreamSynchronize(bs);
+            if (e != hipSuccess) return hip_fail(e, "uploading the live tile spans");
+        }
+        stage("live tile spans");
+    }
     const bool axisKernel = p.kernel == AAI_KERNEL_AXIS || p.kernel == AAI_KERNEL_AXIS_WIDE;
     // K1's separable model against the reference's classifier (aai_axis_verify.hpp).  Both policies: they differ in the
     // corner-triangle rule of a slanted left/right edge only, which does not exist at multiples of 90 degrees.
@@ -478,7 +490,7 @@ int enqueue(const aai_request &rq, int batch, const void *dSrc, int srcType, int
         const aai::QuadMap qm = aai::make_quad_map(g, srcStride, r.srcRow0, channels, srcType == aai::SRC_U8 ? 1 : srcType == aai::SRC_U16 ? 2 : 4);
         aai::RotFlags flags;
         flags.list = p->dList; flags.count = p->flaggedPixels; flags.dense = p->dense;
-        flags.masks = p->dMasks; flags.side = p->side; flags.fork = p->fork; flags.join = p->join; flags.form = p->form;
+        flags.masks = p->dMasks; flags.live = p->dLive; flags.side = p->side; flags.fork = p->fork; flags.join = p->join; flags.form = p->form;
         e = hipSuccess;
         for (int b0 = 0; b0 < batch && e == hipSuccess; b0 += kMaxGridZ)
             e = aai::launch_rotated(r, qm, src_at(dSrc, srcType, (int64_t)b0 * srcImageStride), srcType, sv, dDst + (int64_t)b0 * dstImageStride, dv,

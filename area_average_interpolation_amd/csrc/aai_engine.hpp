@@ -49,6 +49,7 @@ struct Plan {
     bool dense = false;
     // fp32 rotated kernels: the lane masks of the flagged pixels (they skip them) and the side stream the fix-up pass runs on
     unsigned long long *dMasks = nullptr;
+    int *dLive = nullptr;            // per-pixel kernels on a rotated canvas: live tile span per tile row (aai::rotated_live_spans), or none
     hipStream_t side = nullptr;
     hipEvent_t fork = nullptr, join = nullptr;
     double buildMs = 0.0;            // wall clock of build_plan (tables, scans, launch-shape measurement)
@@ -65,6 +66,7 @@ struct Plan {
         if (fork) (void)hipEventDestroy(fork);
         if (join) (void)hipEventDestroy(join);
         if (dMasks) (void)hipFree(dMasks);
+        if (dLive) (void)hipFree(dLive);
         if (dList) (void)hipFree(dList);
         if (dLane) (void)hipFree(dLane);
         if (dRow) (void)hipFree(dRow);

@@ -56,6 +56,7 @@ struct RotFlags {
     // FOLLOW it: it runs beside it on the plan's side stream (fork / join through two events), where its few,
     // latency-bound waves cost nothing instead of ~40 us behind the production pass.
     const unsigned long long *masks = nullptr;
+    const int *live = nullptr;         // per 16-row tile row of the canvas: first and last 16-column tile that can hold a non-zero pixel (rotated_live_spans)
     int form = 0;                      // which fp32 formulation's scan produced the flags: ROT_FORM_QUAD or ROT_FORM_CELL (it serves the launch)
     hipStream_t side = nullptr;
     hipEvent_t fork = nullptr, join = nullptr;
@@ -76,7 +77,7 @@ hipError_t launch_rotated(const RotLaunch &r, const QuadMap &m, const void *src,
                           int batch, const RotFlags &flags, hipStream_t stream, const char **kernelName);
 bool quad_can_address(const RotLaunch &r, int srcType, ImageView sv);
 hipError_t launch_quad(const RotLaunch &r, const QuadMap &m, const void *src, int srcType, ImageView sv, float *dst, ImageView dv,
-                       int batch, const unsigned long long *skipMasks, hipStream_t stream);
+                       int batch, const unsigned long long *skipMasks, hipStream_t stream, const int *live = nullptr);
 
 int quad_anchor_rows(const RotLaunch &r);      // images of 4 GiB and more: how many source rows apart two lanes of a wave can read
 

@@ -237,6 +237,26 @@ void rotated_band_source_rows(const Geometry &g, int row0, int row1, bool sample
     srcRow0 = std::max(0, std::min(a, b)); srcRow1 = std::min(g.H, std::max(a, b) + 1);
 }
 
+void rotated_live_spans(const RotLaunch &r, bool sampler, std::vector<int> &spans)
+{
+    spans.clear();
+    if (!(r.side * r.cs > 1e-9 && r.side * r.sn > 1e-9) || r.dW <= 0 || r.dH <= 0) return;
+    // area / fast: the footprint's bounding box reaches h (c + s) from the centre, windows are anchored at the nearest lattice
+    // point; samplers: a sample point outside the image's extent is 0 (the taps' reach does not matter)
+    const double rho = sampler ? 2.0 : r.h * (r.c + r.s) + 2.5;
+    const int tileRows = (r.dH + 15) / 16, tilesX = (r.dW + 15) / 16;
+    spans.resize((size_t)tileRows * 2);
+    long dead = 0;
+    for (int t = 0; t < tileRows; ++t) {
+        int lo, hi;
+        rot_live_cols(r, t * 16, std::min(t * 16 + 15, r.dH - 1), rho, lo, hi);
+        if (lo > hi) { spans[2 * t] = 1; spans[2 * t + 1] = 0; dead += tilesX; continue; }
+        spans[2 * t] = lo >> 4; spans[2 * t + 1] = hi >> 4;
+        dead += (lo >> 4) + (tilesX - 1 - (hi >> 4));
+    }
+    if (dead * 16 < (long)tileRows * tilesX) spans.clear();      // fewer than 1/16 of the tiles: not worth a table
+}
+
 // ------------------------------------------------------------------------------------------------
 // K1 tables.  With the reduced angle at zero every dst pixel is an axis-parallel box on the virtual
 // lattice, so overlap areas factor into (x overlap) * (y overlap) and the reference's

@@ -120,5 +120,8 @@ bool axis_verify_by_class(const RotLaunch &r, std::vector<std::pair<int, int>> &
 
 // Source rows [srcRow0, srcRow1) that dst rows [row0,row1) of a rotated-lattice request can touch (conservative).
 void rotated_band_source_rows(const Geometry &g, int row0, int row1, bool sampler, int &srcRow0, int &srcRow1);
+// Live span of every 16-row tile row of the dst canvas, in 16-column tiles: spans[2 t] ... spans[2 t + 1] (first > last: none).
+// Tiles outside it hold only pixels that are 0 in every mode (rot_live_cols); empty when the geometry has no dead tiles to speak of.
+void rotated_live_spans(const RotLaunch &r, bool sampler, std::vector<int> &spans);
 
 }  // namespace aai

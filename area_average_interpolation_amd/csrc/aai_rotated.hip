@@ -255,7 +255,7 @@ template <int MODE> struct SampleRows { static constexpr int value = MODE == AAI
 
 template <int MODE, typename T>
 __global__ __launch_bounds__(kBlock) void aai_sample_kernel(RotLaunch r, const T *__restrict__ src, ImageView sv,
-                                                             float *__restrict__ dst, ImageView dv)
+                                                             float *__restrict__ dst, ImageView dv, const int *__restrict__ live)
 {
     constexpr int R = SampleRows<MODE>::value;
     constexpr int N = MODE == AAI_MODE_BILINEAR ? 2 : 4, FIRST = MODE == AAI_MODE_BILINEAR ? 0 : -1;
@@ -267,6 +267,14 @@ __global__ __launch_bounds__(kBlock) void aai_sample_kernel(RotLaunch r, const T
     const T *img = src + (int64_t)blockIdx.z * sv.imageStride;
     const int chan = r.chan > 1 ? r.chan : 1;          // interleaved channels share the taps' positions and weights
     float *outRow0 = dst + (int64_t)blockIdx.z * dv.imageStride + (int64_t)(dy0 - r.dyBase) * dv.rowStride;
+    if (live && chan == 1) {
+        // the 64 columns of this wave are four 16-column tiles of one tile row: all in a corner of the rotated canvas -> zeros
+        const int first = live[2 * (dy0 >> 4)], last = live[2 * (dy0 >> 4) + 1];
+        if ((int)blockIdx.x * 4 + 3 < first || (int)blockIdx.x * 4 > last) {
+            for (int j = 0; j < nRows; ++j) outRow0[(int64_t)j * dv.rowStride + dx] = 0.f;
+            return;
+        }
+    }
 
     SamplePoint pt[R];
     bool whole = true;          // no tap column of this lane is clamped (or the point is outside: no taps at all)
@@ -426,10 +434,10 @@ static hipError_t launch_rotated_band(const RotLaunch &r, const QuadMap &m, cons
         dim3 grid((r.dW + 63) / 64, (r.dyEnd - r.dyBase + tileRows - 1) / tileRows, batch);
         if (r.mode == AAI_MODE_BILINEAR) {
             if (kernelName) *kernelName = "aai_sample_kernel<bilinear>";
-            hipLaunchKernelGGL((aai_sample_kernel<AAI_MODE_BILINEAR, T>), grid, dim3(kBlock), 0, stream, r, src, sv, dst, dv);
+            hipLaunchKernelGGL((aai_sample_kernel<AAI_MODE_BILINEAR, T>), grid, dim3(kBlock), 0, stream, r, src, sv, dst, dv, flags.live);
         } else {
             if (kernelName) *kernelName = "aai_sample_kernel<bicubic>";
-            hipLaunchKernelGGL((aai_sample_kernel<AAI_MODE_BICUBIC, T>), grid, dim3(kBlock), 0, stream, r, src, sv, dst, dv);
+            hipLaunchKernelGGL((aai_sample_kernel<AAI_MODE_BICUBIC, T>), grid, dim3(kBlock), 0, stream, r, src, sv, dst, dv, flags.live);
         }
         return hipGetLastError();
     }
@@ -464,14 +472,14 @@ static hipError_t launch_rotated_band(const RotLaunch &r, const QuadMap &m, cons
     } else if (r.mode == AAI_MODE_FAST && quad) {
         // centres in the dst square, fp32 in the dst frame; flagged pixels belong to the fix-up pass as in area mode
         if (kernelName) *kernelName = "aai_quad_fast_kernel";
-        return launch_quad(r, m, src, srcType, sv, dst, dv, batch, flags.count ? flags.masks : nullptr, stream);
+        return launch_quad(r, m, src, srcType, sv, dst, dv, batch, flags.count ? flags.masks : nullptr, stream, flags.live);
     } else if (r.mode == AAI_MODE_FAST) {
         if (kernelName) *kernelName = "aai_rotated_kernel<fast>";
         hipLaunchKernelGGL((aai_rotated_kernel<AAI_MODE_FAST, false, T>), grid, dim3(kRotBlock), 0, stream, r, src, sv, dst, dv, nullptr, 0u);
     } else if (quad) {
         // the fp32 quad formulation; the pixels flagged by the plan's scans are recomputed by the fix-up pass
         if (kernelName) *kernelName = "aai_quad_kernel<area>";
-        return launch_quad(r, m, src, srcType, sv, dst, dv, batch, flags.count ? flags.masks : nullptr, stream);
+        return launch_quad(r, m, src, srcType, sv, dst, dv, batch, flags.count ? flags.masks : nullptr, stream, flags.live);
     } else {
         const int runs = tune.runs >= 0 ? (tune.runs && r.scale == 1) : r.runs;
         if (runs) {

@@ -149,7 +149,7 @@ constexpr int quad_waves_per_simd(int win) { return 160 / (win * win) >= 8 ? 8 :
 template <typename T, int WIN, bool SCALED, bool HP>
 __global__ __launch_bounds__(kQuadBlock, quad_waves_per_simd(WIN) - (HP && quad_waves_per_simd(WIN) > 2 ? 1 : 0)) void aai_quad_kernel(RotLaunch r, QuadConsts<float> q, QuadMap m, const T *__restrict__ src,
                                                              ImageView sv, float *__restrict__ dst, ImageView dv,
-                                                             const unsigned long long *__restrict__ skipMasks)
+                                                             const unsigned long long *__restrict__ skipMasks, const int *__restrict__ live)
 {
     __shared__ float window[WIN * WIN][kQuadBlock];
     const int tid = threadIdx.x;
@@ -164,6 +164,11 @@ __global__ __launch_bounds__(kQuadBlock, quad_waves_per_simd(WIN) - (HP && quad_
         if ((mask >> (tid & 63)) & 1ull) return;
     }
     float *out = dst + (int64_t)blockIdx.z * dv.imageStride + (int64_t)(dy - r.dyBase) * dv.rowStride + dx;
+    if (live) {
+        // a tile in a corner of the rotated canvas: every pixel is 0 (rot_live_cols), no centre is computed
+        const int first = live[2 * (ty + r.dyBase / 16)], last = live[2 * (ty + r.dyBase / 16) + 1];      // (scalar loads: wave-uniform)
+        if (tx < first || tx > last) { *out = 0.f; return; }
+    }
 
     double px, py;
     pixel_centre(r, dx, dy, px, py);
@@ -185,7 +190,8 @@ __global__ __launch_bounds__(kQuadBlock, quad_waves_per_simd(WIN) - (HP && quad_
 // square.  The window stays in the registers it was fetched into; no LDS.
 template <typename T, int WIN, bool SCALED>
 __global__ __launch_bounds__(kQuadBlock) void aai_quad_fast_kernel(RotLaunch r, QuadConsts<float> q, QuadMap m, const T *__restrict__ src, ImageView sv,
-                                                                  float *__restrict__ dst, ImageView dv, const unsigned long long *__restrict__ skipMasks)
+                                                                  float *__restrict__ dst, ImageView dv, const unsigned long long *__restrict__ skipMasks,
+                                                                  const int *__restrict__ live)
 {
     const int tid = threadIdx.x;
     const int tx = blockIdx.x, ty = blockIdx.y;
@@ -198,6 +204,11 @@ __global__ __launch_bounds__(kQuadBlock) void aai_quad_fast_kernel(RotLaunch r, 
         if ((mask >> (tid & 63)) & 1ull) return;
     }
     float *out = dst + (int64_t)blockIdx.z * dv.imageStride + (int64_t)(dy - r.dyBase) * dv.rowStride + dx;
+    if (live) {
+        // a tile in a corner of the rotated canvas: every pixel is 0 (rot_live_cols), no centre is computed
+        const int first = live[2 * (ty + r.dyBase / 16)], last = live[2 * (ty + r.dyBase / 16) + 1];      // (scalar loads: wave-uniform)
+        if (tx < first || tx > last) { *out = 0.f; return; }
+    }
 
     double px, py;
     pixel_centre(r, dx, dy, px, py);
@@ -310,20 +321,20 @@ __global__ __launch_bounds__(256) void aai_flag_list_kernel(const unsigned long 
 
 template <typename T, int WIN>
 hipError_t launch_quad_win(const RotLaunch &r, const QuadConsts<float> &q, const QuadMap &m, const T *src, ImageView sv, float *dst, ImageView dv,
-                           int batch, const unsigned long long *skipMasks, hipStream_t stream)
+                           int batch, const unsigned long long *skipMasks, hipStream_t stream, const int *live)
 {
     const dim3 grid((r.dW + 15) / 16, (r.dyEnd - r.dyBase + 15) / 16, batch);      // at most 65535 tile rows: the caller bands taller outputs
     if (r.mode == AAI_MODE_FAST) {
-        if (m.scale > 1) hipLaunchKernelGGL((aai_quad_fast_kernel<T, WIN, true>), grid, dim3(kQuadBlock), 0, stream, r, q, m, src, sv, dst, dv, skipMasks);
-        else hipLaunchKernelGGL((aai_quad_fast_kernel<T, WIN, false>), grid, dim3(kQuadBlock), 0, stream, r, q, m, src, sv, dst, dv, skipMasks);
+        if (m.scale > 1) hipLaunchKernelGGL((aai_quad_fast_kernel<T, WIN, true>), grid, dim3(kQuadBlock), 0, stream, r, q, m, src, sv, dst, dv, skipMasks, live);
+        else hipLaunchKernelGGL((aai_quad_fast_kernel<T, WIN, false>), grid, dim3(kQuadBlock), 0, stream, r, q, m, src, sv, dst, dv, skipMasks, live);
         return hipGetLastError();
     }
     if (m.scale > 1) {
-        if (q.hiPrec) hipLaunchKernelGGL((aai_quad_kernel<T, WIN, true, true>), grid, dim3(kQuadBlock), 0, stream, r, q, m, src, sv, dst, dv, skipMasks);
-        else hipLaunchKernelGGL((aai_quad_kernel<T, WIN, true, false>), grid, dim3(kQuadBlock), 0, stream, r, q, m, src, sv, dst, dv, skipMasks);
+        if (q.hiPrec) hipLaunchKernelGGL((aai_quad_kernel<T, WIN, true, true>), grid, dim3(kQuadBlock), 0, stream, r, q, m, src, sv, dst, dv, skipMasks, live);
+        else hipLaunchKernelGGL((aai_quad_kernel<T, WIN, true, false>), grid, dim3(kQuadBlock), 0, stream, r, q, m, src, sv, dst, dv, skipMasks, live);
     } else {
-        if (q.hiPrec) hipLaunchKernelGGL((aai_quad_kernel<T, WIN, false, true>), grid, dim3(kQuadBlock), 0, stream, r, q, m, src, sv, dst, dv, skipMasks);
-        else hipLaunchKernelGGL((aai_quad_kernel<T, WIN, false, false>), grid, dim3(kQuadBlock), 0, stream, r, q, m, src, sv, dst, dv, skipMasks);
+        if (q.hiPrec) hipLaunchKernelGGL((aai_quad_kernel<T, WIN, false, true>), grid, dim3(kQuadBlock), 0, stream, r, q, m, src, sv, dst, dv, skipMasks, live);
+        else hipLaunchKernelGGL((aai_quad_kernel<T, WIN, false, false>), grid, dim3(kQuadBlock), 0, stream, r, q, m, src, sv, dst, dv, skipMasks, live);
     }
     return hipGetLastError();
 }
@@ -368,7 +379,7 @@ hipError_t launch_quad_multi_win(const RotLaunch &r, const QuadConsts<float> &q,
 
 template <typename T>
 hipError_t launch_quad_typed(const RotLaunch &r, const QuadMap &m, const T *src, ImageView sv, float *dst, ImageView dv, int batch,
-                             const unsigned long long *skipMasks, hipStream_t stream)
+                             const unsigned long long *skipMasks, hipStream_t stream, const int *live)
 {
     const QuadConsts<float> q = make_quad_consts<float>(r.side, r.c, r.s, r.policy, r.scale);
     if (r.chan > 1) {
@@ -382,13 +393,13 @@ hipError_t launch_quad_typed(const RotLaunch &r, const QuadMap &m, const T *src,
         }
     }
     switch (r.mode == AAI_MODE_FAST ? q.winFast : q.win) {
-    case 2: return launch_quad_win<T, 2>(r, q, m, src, sv, dst, dv, batch, skipMasks, stream);
-    case 3: return launch_quad_win<T, 3>(r, q, m, src, sv, dst, dv, batch, skipMasks, stream);
-    case 4: return launch_quad_win<T, 4>(r, q, m, src, sv, dst, dv, batch, skipMasks, stream);
-    case 5: return launch_quad_win<T, 5>(r, q, m, src, sv, dst, dv, batch, skipMasks, stream);
-    case 6: return launch_quad_win<T, 6>(r, q, m, src, sv, dst, dv, batch, skipMasks, stream);
-    case 7: return launch_quad_win<T, 7>(r, q, m, src, sv, dst, dv, batch, skipMasks, stream);
-    default: return launch_quad_win<T, 8>(r, q, m, src, sv, dst, dv, batch, skipMasks, stream);
+    case 2: return launch_quad_win<T, 2>(r, q, m, src, sv, dst, dv, batch, skipMasks, stream, live);
+    case 3: return launch_quad_win<T, 3>(r, q, m, src, sv, dst, dv, batch, skipMasks, stream, live);
+    case 4: return launch_quad_win<T, 4>(r, q, m, src, sv, dst, dv, batch, skipMasks, stream, live);
+    case 5: return launch_quad_win<T, 5>(r, q, m, src, sv, dst, dv, batch, skipMasks, stream, live);
+    case 6: return launch_quad_win<T, 6>(r, q, m, src, sv, dst, dv, batch, skipMasks, stream, live);
+    case 7: return launch_quad_win<T, 7>(r, q, m, src, sv, dst, dv, batch, skipMasks, stream, live);
+    default: return launch_quad_win<T, 8>(r, q, m, src, sv, dst, dv, batch, skipMasks, stream, live);
     }
 }
 
@@ -423,16 +434,16 @@ bool quad_can_address(const RotLaunch &r, int srcType, ImageView sv)
 }
 
 hipError_t launch_quad(const RotLaunch &r, const QuadMap &map, const void *src, int srcType, ImageView sv, float *dst, ImageView dv,
-                       int batch, const unsigned long long *skipMasks, hipStream_t stream)
+                       int batch, const unsigned long long *skipMasks, hipStream_t stream, const int *live)
 {
     if (r.dW <= 0 || r.dyEnd <= r.dyBase || batch <= 0) return hipSuccess;
     QuadMap m = map;
     const int64_t esz = srcType == SRC_U8 ? 1 : srcType == SRC_U16 ? 2 : 4;
     m.anchorRows = (int64_t)r.H * sv.rowStride * esz >= ((int64_t)1 << 32) ? quad_anchor_rows(r) : 0;
     switch (srcType) {
-    case SRC_U8: return launch_quad_typed(r, m, static_cast<const unsigned char *>(src), sv, dst, dv, batch, skipMasks, stream);
-    case SRC_U16: return launch_quad_typed(r, m, static_cast<const unsigned short *>(src), sv, dst, dv, batch, skipMasks, stream);
-    default: return launch_quad_typed(r, m, static_cast<const float *>(src), sv, dst, dv, batch, skipMasks, stream);
+    case SRC_U8: return launch_quad_typed(r, m, static_cast<const unsigned char *>(src), sv, dst, dv, batch, skipMasks, stream, live);
+    case SRC_U16: return launch_quad_typed(r, m, static_cast<const unsigned short *>(src), sv, dst, dv, batch, skipMasks, stream, live);
+    default: return launch_quad_typed(r, m, static_cast<const float *>(src), sv, dst, dv, batch, skipMasks, stream, live);
     }
 }
 

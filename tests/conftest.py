@@ -100,6 +100,8 @@ def hostemu(aai):
     lib.aai_emu_check_line_runs.argtypes = [ctypes.POINTER(L.Request)]
     lib.aai_emu_wide_band_cover.restype = ctypes.c_long
     lib.aai_emu_wide_band_cover.argtypes = [ctypes.POINTER(L.Request), ctypes.c_int, ctypes.c_int]
+    lib.aai_emu_live_spans.restype = ctypes.c_int
+    lib.aai_emu_live_spans.argtypes = [ctypes.POINTER(L.Request), ctypes.POINTER(ctypes.c_int), ctypes.c_int]
     lib.aai_emu_wide_parts.restype = ctypes.c_int
     lib.aai_emu_wide_parts.argtypes = [ctypes.POINTER(L.Request)]
     lib.aai_emu_uses_runs.restype = ctypes.c_int

@@ -687,6 +687,20 @@ int aai_emu_uses_runs(const aai_request *rq)
     return make_rot_launch(g, rq->mode, rq->policy).runs;
 }
 
+// the live tile span table the plan uploads for a rotated canvas (rotated_live_spans): 2 ints per 16-row tile row; returns the
+// number of ints (0: no table), -1 on a bad request / too small a buffer
+int aai_emu_live_spans(const aai_request *rq, int *out, int capacity)
+{
+    Geometry g;
+    std::string msg;
+    if (make_geometry(*rq, g, msg) != AAI_OK) return -1;
+    std::vector<int> spans;
+    rotated_live_spans(make_rot_launch(g, rq->mode, rq->policy), rq->mode == AAI_MODE_BILINEAR || rq->mode == AAI_MODE_BICUBIC, spans);
+    if ((int)spans.size() > capacity) return -1;
+    for (size_t i = 0; i < spans.size(); ++i) out[i] = spans[i];
+    return (int)spans.size();
+}
+
 // parts per axis of the fp32 window of a wide footprint (RotLaunch::wide; 0: not one)
 int aai_emu_wide_parts(const aai_request *rq)
 {

@@ -673,6 +673,53 @@ def test_band_source_rows_hold_every_window_the_wide_kernel_fetches(aai, hostemu
     assert checked > 150, checked
 
 
+def test_live_tile_spans_hold_every_nonzero_pixel(aai, hostemu, po):
+    """The per-pixel kernels on a rotated canvas skip the tiles outside each tile row's live span (csrc/aai_plan.cpp:
+    rotated_live_spans) and store zeros there: every pixel the oracle gives a non-zero value must lie inside the span of its tile
+    row -- all four modes, all quadrants, up- and down-sampling, isocenters that push the image off the canvas's centre."""
+    import ctypes
+    rng = np.random.default_rng(10)
+    tables = dead_tiles = 0
+    for k in range(140):
+        W, H = int(rng.integers(40, 260)), int(rng.integers(40, 260))
+        sr, dr = float(rng.uniform(0.5, 6.0)), float(rng.uniform(0.5, 2.0))
+        if dr / sr > 2.2:
+            dr = sr * 2.2
+        ang = float(rng.uniform(0.5, 89.5)) + 90.0 * (k % 4)
+        iso = ((W - 1) / 2, (H - 1) / 2) if k % 3 else (float(rng.uniform(-3, W + 3)), float(rng.uniform(-3, H + 3)))
+        mode = 1 + k % 4
+        rq = aai.make_request(W, H, sr, dr, iso, ang, mode=mode)
+        rc, msg, lay = aai.query(rq)
+        if rc != 0 or lay.dst_height < 16:
+            continue
+        buf = (ctypes.c_int * (2 * ((lay.dst_height + 15) // 16)))()
+        n = hostemu.aai_emu_live_spans(ctypes.byref(rq), buf, len(buf))
+        assert n in (0, len(buf)), n
+        if n == 0:
+            continue
+        tables += 1
+        src = rng.random((H, W)) + 0.5              # strictly positive: a pixel that gets anything is non-zero
+        gold = po.oracle_run({1: po.MODE_EXACT, 2: po.MODE_FAST, 3: 3, 4: 4}[mode], src, sr, dr, iso, ang).dst
+        tilesX = (lay.dst_width + 15) // 16
+        for t in range(n // 2):
+            first, last = buf[2 * t], buf[2 * t + 1]
+            rows = gold[16 * t:16 * t + 16]
+            cols = np.nonzero(rows.any(axis=0))[0]
+            if cols.size:
+                assert first <= cols[0] // 16 and cols[-1] // 16 <= last, (W, H, sr, dr, ang, iso, mode, t, first, last, int(cols[0]), int(cols[-1]))
+            dead_tiles += tilesX if first > last else first + (tilesX - 1 - last)
+    assert tables > 60 and dead_tiles > 1000, (tables, dead_tiles)
+    # config 3 and config 5: about a third and a half of the canvas
+    for (W, sr, dr, ang, want) in ((8192, 8192.0, 2731.0, 17.5, 0.25), (4096, 1.0, 4.0, 45.0, 0.45)):
+        rq = aai.make_request(W, W, sr, dr, ((W - 1) / 2, (W - 1) / 2), ang, mode=2)
+        rc, msg, lay = aai.query(rq)
+        buf = (ctypes.c_int * (2 * ((lay.dst_height + 15) // 16)))()
+        n = hostemu.aai_emu_live_spans(ctypes.byref(rq), buf, len(buf))
+        tilesX = (lay.dst_width + 15) // 16
+        dead = sum(tilesX if buf[2 * t] > buf[2 * t + 1] else buf[2 * t] + (tilesX - 1 - buf[2 * t + 1]) for t in range(n // 2))
+        assert n == len(buf) and dead > want * tilesX * (n // 2), (W, ang, dead, tilesX * (n // 2))
+
+
 def test_cell_live_row_interval_is_a_superset(aai, hostemu):
     """The cell kernel skips the cell rows outside cell_live_rows' interval for its 64 columns without computing anything
     (the empty corners of a rotated canvas): no cell outside the interval may contribute.  Random geometries, all quadrants,
