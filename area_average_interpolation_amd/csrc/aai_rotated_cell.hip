@@ -27,6 +27,7 @@
 #include "aai_rot_cell.hpp"
 
 #include <cstdlib>
+#include <cstring>
 
 namespace aai {
 
@@ -111,7 +112,7 @@ __device__ __forceinline__ void cell_walk(int dW, int x0, int y0, int y1, int li
 template <typename T, int WIN, bool SCALED, bool HP, int TW>
 __global__ __launch_bounds__(kQuadBlock, cell_min_waves(WIN)) void aai_cell_kernel(
     RotLaunch r, QuadConsts<float> q, CellConsts<float> z, QuadMap m, const T *__restrict__ src, ImageView sv, float *__restrict__ dst, ImageView dv,
-    const unsigned long long *__restrict__ skipMasks, int tilesX, int rowsPerStrip)
+    const unsigned long long *__restrict__ skipMasks, int tilesX, int rowsPerStrip, int bigStrips, int tailRows)
 {
     __shared__ float window[WIN * WIN][kQuadBlock];
     const int tid = threadIdx.x;
@@ -121,8 +122,11 @@ __global__ __launch_bounds__(kQuadBlock, cell_min_waves(WIN)) void aai_cell_kern
     if (x0 >= r.dW) return;                                   // wave-uniform; no barrier below
     // (row bands in launch order: dealing them from the middle outwards, so that the launch's tail is made of the cheap
     // corner bands, measured 5 % SLOWER at config 3 -- profiles/r03_cell_kernel.txt)
-    const int y0 = r.dyBase + blockIdx.y * rowsPerStrip;
-    const int y1 = min(y0 + rowsPerStrip, r.dyEnd);           // dst rows [y0, y1); cells rows y0 .. y1
+    // the last strips of a launch are shorter (tailRows rows instead of rowsPerStrip): the waves that finish it live a fraction
+    // as long, and the chip drains in a fraction of the time
+    const int by = blockIdx.y;
+    const int y0 = r.dyBase + (by < bigStrips ? by * rowsPerStrip : bigStrips * rowsPerStrip + (by - bigStrips) * tailRows);
+    const int y1 = min(y0 + (by < bigStrips ? rowsPerStrip : tailRows), r.dyEnd);           // dst rows [y0, y1); cells rows y0 .. y1
     float *image = dst + (int64_t)blockIdx.z * dv.imageStride;
     const char *img = reinterpret_cast<const char *>(src + (int64_t)blockIdx.z * sv.imageStride + m.base);
     const CellColumn col = cell_column(r, z, x0 + (lane & (TW - 1)));
@@ -201,10 +205,25 @@ hipError_t launch_cell_tile(const RotLaunch &r, const QuadConsts<float> &q, cons
 {
     const int rowsPerStrip = cell_rows_per_strip(r.dW, r.dyEnd - r.dyBase, batch, TW);
     const int strips = (r.dW + TW - 2) / (TW - 1);
-    const dim3 grid((strips + 3) / 4, (r.dyEnd - r.dyBase + rowsPerStrip - 1) / rowsPerStrip, batch);
+    const int rows = r.dyEnd - r.dyBase;
+    // A launch with few waves (rowsPerStrip already at its minimum of 8: fewer than four rounds of the chip's wave slots) spends a
+    // fifth of its time draining: its last tenth of the rows goes in strips of 4, whose waves live half as long (config 3, one
+    // image: 211 -> 201 us; config 5, 32-row strips and 190 k waves, loses 0.4 ... 7 % to any tail: tools/cell_tail_ab.sh).
+    // Experiments: AAI_CELL_TAIL="<percent of the rows>,<rows per tail strip>".
+    static const int forcedPct = [] { const char *e = getenv("AAI_CELL_TAIL"); return e ? atoi(e) : -1; }();
+    static const int forcedR = [] { const char *e = getenv("AAI_CELL_TAIL"); const char *c = e ? strchr(e, ',') : nullptr; return c ? atoi(c + 1) : 2; }();
+    const int tailPct = forcedPct >= 0 ? forcedPct : (rowsPerStrip == 8 ? 10 : 0), tailR = forcedPct >= 0 ? forcedR : 4;
+    int bigStrips = (rows + rowsPerStrip - 1) / rowsPerStrip, tailRows = rowsPerStrip, tailStrips = 0;
+    if (tailPct > 0 && TW == 64 && tailR > 0 && tailR < rowsPerStrip) {
+        bigStrips = (int)((int64_t)rows * (100 - tailPct) / 100 / rowsPerStrip);
+        tailRows = tailR;
+        tailStrips = (rows - bigStrips * rowsPerStrip + tailRows - 1) / tailRows;
+        if (bigStrips + tailStrips > 65535) { bigStrips = (rows + rowsPerStrip - 1) / rowsPerStrip; tailRows = rowsPerStrip; tailStrips = 0; }      // grid.y
+    }
+    const dim3 grid((strips + 3) / 4, bigStrips + tailStrips, batch);
     const int tilesX = (r.dW + 15) / 16;
 #define AAI_CELL_LAUNCH(SCALED, HP) \
-    hipLaunchKernelGGL((aai_cell_kernel<T, WIN, SCALED, HP, TW>), grid, dim3(kQuadBlock), 0, stream, r, q, z, m, src, sv, dst, dv, skipMasks, tilesX, rowsPerStrip)
+    hipLaunchKernelGGL((aai_cell_kernel<T, WIN, SCALED, HP, TW>), grid, dim3(kQuadBlock), 0, stream, r, q, z, m, src, sv, dst, dv, skipMasks, tilesX, rowsPerStrip, bigStrips, tailRows)
     if (m.scale > 1) {
         if (q.hiPrec) AAI_CELL_LAUNCH(true, true); else AAI_CELL_LAUNCH(true, false);
     } else {
