@@ -156,6 +156,8 @@ RotLaunch make_rot_launch(const Geometry &g, int mode, int policy)
     // beyond the parity bar (quad_supported).
     r.quad = ((mode == AAI_MODE_AREA || mode == AAI_MODE_FAST) && !(policy & AAI_POLICY_DOUBLE_PRECISION) && c > 0.0 && s > 0.0 &&
               quad_supported(g.side, c, s)) ? 1 : 0;
+    // (fast mode's window holds pixel centres only and is two positions narrower: one 8 x 8 window reaches a little further)
+    if (mode == AAI_MODE_FAST && !(policy & AAI_POLICY_DOUBLE_PRECISION) && c > 0.0 && s > 0.0 && quad_fast_parts(g.side, c, s) == 1) r.quad = 1;
     // (Fast mode with replication used to stay on the fp64 line-walking kernel: the 4 x 4 ... 5 x 5 area-mode window fetched
     // too much.  With the centre-only window of round 3 -- 3 x 3 at x4 up-sampling -- the window kernel wins everywhere
     // measured: x4 at 45 degrees 2.75 -> 2.67 ms, x2 at 30 0.68 -> 0.59, 1:1 at 61 0.212 -> 0.204, x3 at 17.5 0.37 -> 0.29:
@@ -166,6 +168,10 @@ RotLaunch make_rot_launch(const Geometry &g, int mode, int policy)
     // into 2 x 2 or 4 x 4 parts, a lane per part (aai_rotated_wide.hip) -- the double-precision runs kernel was bound by its
     // boundary pairs (8 : 1 at 17.5 degrees: 0.34 ms where the source is read in 0.05)
     r.wide = (mode == AAI_MODE_AREA && !(policy & AAI_POLICY_DOUBLE_PRECISION) && c > 0.0 && s > 0.0 && g.scale == 1) ? quad_wide_parts(g.side, c, s) : 0;
+    // ... and fast mode likewise (aai_wide_fast_kernel: memberships instead of areas, the window in registers): the double-precision
+    // line-walking kernel took 0.26 ms for 8:1 at 17.5 degrees, more than the area mode's wide kernel
+    if (mode == AAI_MODE_FAST && !(policy & AAI_POLICY_DOUBLE_PRECISION) && c > 0.0 && s > 0.0 && g.scale == 1 && quad_fast_parts(g.side, c, s) > 1)
+        r.wide = quad_fast_parts(g.side, c, s);
     {
         // virtual centre: X = dx (side cs) + dy (side sn) + X0, Y = -dx (side sn) + dy (side cs) + Y0   (pixel_centre)
         const double u0 = g.fracX * g.side - g.isoX + g.offX, v0 = g.fracY * g.side - g.isoY + g.offY;

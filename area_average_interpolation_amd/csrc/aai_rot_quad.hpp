@@ -67,7 +67,8 @@ struct QuadConsts {
     // lattice axis, i.e. at most floor(2 h (c + s)) + 1 positions per axis -- one fewer than the area mode's window, which
     // also holds the pixels the square merely touches (config 3: 4 x 4 instead of 5 x 5)
     F hbf;                            // h (c + s) + guard
-    int winFast;
+    int winFast;                      // (wide footprints: of ONE part of the window, like `win`)
+    int partsFast, winFastFull;       // parts per axis of fast mode's window (1, 2 or 4) and its whole extent
     // Close to an axis (min(c,s) small) the reference's corner-triangle rule has slope ~1/(2 min(c,s)) in t, far too
     // steep for fp32 coordinates, and under either policy the thin corner triangles (area t^2 / (2 c s), t tiny) need t to
     // a RELATIVE accuracy fp32 differences of numbers near 1 do not have: hiPrec evaluates both edges' t = h + k - |a|,
@@ -124,6 +125,19 @@ AAI_HD int quad_wide_parts(double side, double c, double s)
     return win <= 2 * kQuadMaxWin ? 2 : (win <= 4 * kQuadMaxWin ? 4 : 0);
 }
 
+// Fast mode looks at pixel centres only, so its window is two positions narrower: 1 = one window of at most 8 x 8 (aai_quad_fast_kernel),
+// 2 / 4 = parts per axis (aai_wide_fast_kernel), 0 = the double-precision line-walking kernel.
+AAI_HD int quad_fast_parts(double side, double c, double s)
+{
+    if (!(c > 1e-4 && s > 1e-4)) return 0;
+    const double h = 0.5 * side, k = 0.5 * (c + s);
+    if (!(h - k > 1e-3)) return 0;
+    const double hb = h * (c + s) + 1e-5;
+    if (!(hb < 64.0)) return 0;
+    const int win = (int)floor(2.0 * hb) + 1;
+    return win <= kQuadMaxWin ? 1 : (win <= 2 * kQuadMaxWin ? 2 : (win <= 4 * kQuadMaxWin ? 4 : 0));
+}
+
 // the sum of the parts' partial sums, in the order the lanes of a dst pixel exchange them (a butterfly over lane distance 1, 2,
 // 4, ...): v[0] afterwards
 template <typename F>
@@ -159,7 +173,9 @@ AAI_HD QuadConsts<F> make_quad_consts(double side, double c, double s, int polic
     q.parts = q.winFull <= kQuadMaxWin ? 1 : (q.winFull <= 2 * kQuadMaxWin ? 2 : 4);
     q.win = (q.winFull + q.parts - 1) / q.parts;
     q.hbf = (F)(hb + 1e-5);
-    q.winFast = (int)floor(2.0 * (hb + 1e-5)) + 1;
+    q.winFastFull = (int)floor(2.0 * (hb + 1e-5)) + 1;
+    q.partsFast = q.winFastFull <= kQuadMaxWin ? 1 : (q.winFastFull <= 2 * kQuadMaxWin ? 2 : 4);
+    q.winFast = (q.winFastFull + q.partsFast - 1) / q.partsFast;
     // ... and with replicated source pixels (up-sampling): a dst pixel then covers one or two source pixels and a dst value is
     // nearly a copy of a source value, so on noisy data it can be a hundred times smaller than its neighbours -- where the
     // 1e-7 absolute error of an fp32 area shows as several 1e-6 relative (7e-6 on 8-bit noise; 4e-7 with hiPrec)
@@ -497,13 +513,15 @@ AAI_HD bool quad_pixel(const QuadConsts<F> &q, int Xc, int Yc, double dfx, doubl
 // Returns sum and count; the dst value is sum / count, or 0 when count is 0 (Source.cpp:905).
 // SCAN: nothing is fetched; the return value says whether a centre lies within QuadConsts::margin of an edge, in which
 // case the double-precision pass (with the reference's ray cast at knife edges) owns this pixel.
+// (partI, partJ): part of a wide window (quad_fast_parts), WIN x WIN positions from (partI, partJ) * WIN on; the caller adds the parts
 template <typename F, int WIN, bool SCAN, typename Src>
-AAI_HD bool quad_fast_pixel(const QuadConsts<F> &q, int Xc, int Yc, double dfx, double dfy, int mW, int mH, Src &src, F &sum, int &count)
+AAI_HD bool quad_fast_pixel(const QuadConsts<F> &q, int Xc, int Yc, double dfx, double dfy, int mW, int mH, Src &src, F &sum, int &count,
+                            int partI = 0, int partJ = 0)
 {
     typedef typename QuadMask<WIN>::type mask_t;
     const F fpx = (F)dfx, fpy = (F)dfy;
     sum = F(0); count = 0;
-    const F fi0 = ceil(fpx - q.hbf), fj0 = ceil(fpy - q.hbf);          // first lattice point a centre of the square can be
+    const F fi0 = ceil(fpx - q.hbf) + (F)(partI * WIN), fj0 = ceil(fpy - q.hbf) + (F)(partJ * WIN);      // first lattice point a centre of the square can be
     const int i0 = (int)fi0, j0 = (int)fj0;
     const int xg0 = Xc + i0, yg0 = Yc + j0;
     // Away from the image border every window of the wave lies inside the lattice: one vote replaces the per-column / per-row

@@ -450,7 +450,7 @@ static hipError_t launch_rotated_band(const RotLaunch &r, const QuadMap &m, cons
         return launch_cell(r, m, src, srcType, sv, dst, dv, batch, flags.count ? flags.masks : nullptr, stream);
     }
     if (wide_serves(r, srcType, sv)) {
-        if (kernelName) *kernelName = "aai_wide_kernel<area>";
+        if (kernelName) *kernelName = r.mode == AAI_MODE_FAST ? "aai_wide_fast_kernel" : "aai_wide_kernel<area>";
         return launch_wide(r, m, src, srcType, sv, dst, dv, batch, flags.count ? flags.masks : nullptr, stream);
     }
     if (r.chan > 1 && quad) {

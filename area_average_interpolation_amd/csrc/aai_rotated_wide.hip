@@ -13,8 +13,10 @@
 // loads) flags the dst pixels with a decision too close to its threshold, the production kernel skips them and the
 // double-precision fix-up pass computes them beside it.
 //
+// Fast mode (the reference's default mode) takes the same decomposition with memberships instead of areas: aai_wide_fast_kernel.
+//
 // Plain single-channel images without replication (scale 1: wide footprints never have any); interleaved channels and
-// the double-precision policy keep the runs kernel.
+// the double-precision policy keep the double-precision kernels.
 #include "aai_kernels.hpp"
 #include "aai_rot_quad.hpp"
 #include "aai_quad_src.hpp"
@@ -119,12 +121,74 @@ __global__ __launch_bounds__(kQuadBlock) void aai_wide_scan_kernel(RotLaunch r, 
     }
 }
 
+// Fast mode over a wide footprint (Source.cpp:868-907 + 837-864): the mean of the pixels whose centres lie in the dst square, the window
+// of centres (QuadConsts::winFastFull positions a side) in PARTS x PARTS parts, a lane per part as above; memberships are two
+// compares per position on values held in registers (no LDS), sums and counts meet in the same butterfly.
+template <int PARTS>
+__device__ __forceinline__ int wide_total_int(int v)
+{
+#pragma unroll
+    for (int o = 1; o < PARTS * PARTS; o <<= 1) v = v + __shfl_xor(v, o);
+    return v;
+}
+
+template <typename T, int WIN, int PARTS>
+__global__ __launch_bounds__(kQuadBlock) void aai_wide_fast_kernel(RotLaunch r, QuadConsts<float> q, QuadMap m, const T *__restrict__ src, ImageView sv,
+                                                                  float *__restrict__ dst, ImageView dv, const unsigned long long *__restrict__ skipMasks)
+{
+    const WideLane<PARTS> l(r, r.dyBase / 16);
+    if (!(l.dx < r.dW && l.dy < r.dyEnd)) return;
+    if (skipMasks && ((skipMasks[l.word] >> l.bit) & 1ull)) return;
+    double px, py;
+    pixel_centre(r, l.dx, l.dy, px, py);
+    const double cx = floor(px + 0.5), cy = floor(py + 0.5);
+    float sum = 0.f;
+    int count = 0;
+    if (cx > -40.0 && cx < (double)r.mW + 40.0 && cy > -40.0 && cy < (double)r.mH + 40.0) {
+        QuadSrc<T, WIN, false> s;
+        s.img = reinterpret_cast<const char *>(src + (int64_t)blockIdx.z * sv.imageStride + m.base);
+        s.m = &m; s.mW = r.mW; s.mH = r.mH; s.lds = nullptr; s.tid = threadIdx.x;
+        quad_fast_pixel<float, WIN, false>(q, (int)cx, (int)cy, px - cx, py - cy, r.mW, r.mH, s, sum, count, l.partI, l.partJ);
+    }
+    const float S = wide_total<PARTS>(sum);
+    const int N = wide_total_int<PARTS>(count);
+    if ((threadIdx.x & (PARTS * PARTS - 1)) == 0)
+        dst[(int64_t)blockIdx.z * dv.imageStride + (int64_t)(l.dy - r.dyBase) * dv.rowStride + l.dx] = N > 0 ? S / (float)N : 0.f;      // Source.cpp:905
+}
+
+template <int WIN, int PARTS>
+__global__ __launch_bounds__(kQuadBlock) void aai_wide_fast_scan_kernel(RotLaunch r, QuadConsts<float> q, unsigned long long *__restrict__ laneMasks,
+                                                                       unsigned *__restrict__ counter, int tileRow0)
+{
+    const WideLane<PARTS> l(r, tileRow0);
+    if (!(l.dx < r.dW && l.dy < r.dH)) return;
+    double px, py;
+    pixel_centre(r, l.dx, l.dy, px, py);
+    const double cx = floor(px + 0.5), cy = floor(py + 0.5);
+    bool uncertain = false;
+    if (cx > -40.0 && cx < (double)r.mW + 40.0 && cy > -40.0 && cy < (double)r.mH + 40.0) {
+        NoSrc s;
+        float sum;
+        int count;
+        uncertain = quad_fast_pixel<float, WIN, true>(q, (int)cx, (int)cy, px - cx, py - cy, r.mW, r.mH, s, sum, count, l.partI, l.partJ);
+    }
+    if (uncertain) {
+        const unsigned long long bit = 1ull << l.bit;
+        const unsigned long long old = atomicOr(laneMasks + l.word, bit);
+        if (!(old & bit)) atomicAdd(counter, 1u);
+    }
+}
+
 template <typename T, int WIN, int PARTS>
 hipError_t launch_wide_win(const RotLaunch &r, const QuadConsts<float> &q, const QuadMap &m, const T *src, ImageView sv, float *dst, ImageView dv,
                            int batch, const unsigned long long *skipMasks, hipStream_t stream)
 {
     const int tilesX = (r.dW + 15) / 16;
     const dim3 grid(tilesX * (PARTS == 2 ? 4 : 16), (r.dyEnd - r.dyBase + 15) / 16, batch);      // at most 65535 tile rows: the caller bands taller outputs
+    if (r.mode == AAI_MODE_FAST) {
+        hipLaunchKernelGGL((aai_wide_fast_kernel<T, WIN, PARTS>), grid, dim3(kQuadBlock), 0, stream, r, q, m, src, sv, dst, dv, skipMasks);
+        return hipGetLastError();
+    }
     if (q.hiPrec) hipLaunchKernelGGL((aai_wide_kernel<T, WIN, true, PARTS>), grid, dim3(kQuadBlock), 0, stream, r, q, m, src, sv, dst, dv, skipMasks);
     else hipLaunchKernelGGL((aai_wide_kernel<T, WIN, false, PARTS>), grid, dim3(kQuadBlock), 0, stream, r, q, m, src, sv, dst, dv, skipMasks);
     return hipGetLastError();
@@ -134,7 +198,7 @@ template <typename T, int PARTS>
 hipError_t launch_wide_parts(const RotLaunch &r, const QuadConsts<float> &q, const QuadMap &m, const T *src, ImageView sv, float *dst, ImageView dv,
                              int batch, const unsigned long long *skipMasks, hipStream_t stream)
 {
-    switch (q.win) {
+    switch (r.mode == AAI_MODE_FAST ? q.winFast : q.win) {
     case 5: return launch_wide_win<T, 5, PARTS>(r, q, m, src, sv, dst, dv, batch, skipMasks, stream);
     case 6: return launch_wide_win<T, 6, PARTS>(r, q, m, src, sv, dst, dv, batch, skipMasks, stream);
     case 7: return launch_wide_win<T, 7, PARTS>(r, q, m, src, sv, dst, dv, batch, skipMasks, stream);
@@ -148,8 +212,9 @@ hipError_t launch_wide_typed(const RotLaunch &r, const QuadMap &m, const T *src,
                              const unsigned long long *skipMasks, hipStream_t stream)
 {
     const QuadConsts<float> q = make_quad_consts<float>(r.side, r.c, r.s, r.policy, r.scale);
-    if (q.parts != r.wide) return hipErrorInvalidValue;
-    if (q.parts == 2) return launch_wide_parts<T, 2>(r, q, m, src, sv, dst, dv, batch, skipMasks, stream);
+    const int parts = r.mode == AAI_MODE_FAST ? q.partsFast : q.parts;
+    if (parts != r.wide) return hipErrorInvalidValue;
+    if (parts == 2) return launch_wide_parts<T, 2>(r, q, m, src, sv, dst, dv, batch, skipMasks, stream);
     return launch_wide_parts<T, 4>(r, q, m, src, sv, dst, dv, batch, skipMasks, stream);
 }
 
@@ -161,10 +226,11 @@ hipError_t launch_wide_scan_parts(const RotLaunch &r, const QuadConsts<float> &q
         const dim3 grid(tilesX * (PARTS == 2 ? 4 : 16), tileRows - t0 < 65535 ? tileRows - t0 : 65535, 1);
 #define AAI_WIDE_SCAN(W)                                                                                                                       \
     case W:                                                                                                                                    \
-        if (q.hiPrec) hipLaunchKernelGGL((aai_wide_scan_kernel<W, true, PARTS>), grid, dim3(kQuadBlock), 0, stream, r, q, laneMasks, counter, t0); \
+        if (r.mode == AAI_MODE_FAST) hipLaunchKernelGGL((aai_wide_fast_scan_kernel<W, PARTS>), grid, dim3(kQuadBlock), 0, stream, r, q, laneMasks, counter, t0); \
+        else if (q.hiPrec) hipLaunchKernelGGL((aai_wide_scan_kernel<W, true, PARTS>), grid, dim3(kQuadBlock), 0, stream, r, q, laneMasks, counter, t0); \
         else hipLaunchKernelGGL((aai_wide_scan_kernel<W, false, PARTS>), grid, dim3(kQuadBlock), 0, stream, r, q, laneMasks, counter, t0);     \
         break;
-        switch (q.win) {
+        switch (r.mode == AAI_MODE_FAST ? q.winFast : q.win) {
             AAI_WIDE_SCAN(5) AAI_WIDE_SCAN(6) AAI_WIDE_SCAN(7) AAI_WIDE_SCAN(8)
         default: return hipErrorInvalidValue;
         }
@@ -180,7 +246,7 @@ hipError_t launch_wide_scan_parts(const RotLaunch &r, const QuadConsts<float> &q
 bool wide_can_serve(const RotLaunch &r, int srcType, ImageView sv)
 {
     static const bool off = [] { const char *e = getenv("AAI_WIDE"); return e && atoi(e) == 0; }();      // experiments: AAI_WIDE=0 keeps the runs kernel
-    if (off || !r.wide || r.mode != AAI_MODE_AREA || r.chan != 1 || r.scale != 1 || (r.dyBase & 15) != 0) return false;
+    if (off || !r.wide || (r.mode != AAI_MODE_AREA && r.mode != AAI_MODE_FAST) || r.chan != 1 || r.scale != 1 || (r.dyBase & 15) != 0) return false;
     // (tilesX * 16 blocks along grid.x)
     if ((int64_t)((r.dW + 15) / 16) * 16 > 2147483647ll) return false;
     return quad_can_address(r, srcType, sv);
@@ -204,8 +270,9 @@ hipError_t launch_wide_scan(const RotLaunch &r, unsigned long long *laneMasks, u
 {
     if (r.dW <= 0 || r.dH <= 0 || !r.wide) return hipSuccess;
     const QuadConsts<float> q = make_quad_consts<float>(r.side, r.c, r.s, r.policy, r.scale);
-    if (q.parts != r.wide) return hipErrorInvalidValue;
-    return q.parts == 2 ? launch_wide_scan_parts<2>(r, q, laneMasks, counter, stream) : launch_wide_scan_parts<4>(r, q, laneMasks, counter, stream);
+    const int parts = r.mode == AAI_MODE_FAST ? q.partsFast : q.parts;
+    if (parts != r.wide) return hipErrorInvalidValue;
+    return parts == 2 ? launch_wide_scan_parts<2>(r, q, laneMasks, counter, stream) : launch_wide_scan_parts<4>(r, q, laneMasks, counter, stream);
 }
 
 }  // namespace aai

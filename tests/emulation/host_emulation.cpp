@@ -331,6 +331,33 @@ static bool emu_quad_fast_pixel(const QuadConsts<float> &qc, const RotLaunch &r,
     return true;
 }
 
+// fast mode over a wide footprint (aai_wide_fast_kernel): the window of centres in parts, sums and counts added in the lanes' order
+template <int WIN>
+static bool emu_wide_fast_pixel(const QuadConsts<float> &qc, const RotLaunch &r, const float *img, int64_t stride, double px, double py, float &value)
+{
+    const double cxr = std::floor(px + 0.5), cyr = std::floor(py + 0.5);
+    if (!(cxr > -40.0 && cxr < (double)r.mW + 40.0 && cyr > -40.0 && cyr < (double)r.mH + 40.0)) { value = 0.f; return true; }
+    const int n = qc.partsFast * qc.partsFast;
+    float sums[16];
+    int total = 0;
+    for (int pass = 0; pass < 2; ++pass)
+        for (int part = 0; part < n; ++part) {
+            EmuQuadSrc<WIN> qs{&r, img, stride, {}};
+            float sum;
+            int count;
+            const int pi = part % qc.partsFast, pj = part / qc.partsFast;
+            if (pass == 0) {
+                if (quad_fast_pixel<float, WIN, true>(qc, (int)cxr, (int)cyr, px - cxr, py - cyr, r.mW, r.mH, qs, sum, count, pi, pj)) return false;
+            } else {
+                quad_fast_pixel<float, WIN, false>(qc, (int)cxr, (int)cyr, px - cxr, py - cyr, r.mW, r.mH, qs, sum, count, pi, pj);
+                sums[part] = sum; total += count;
+            }
+        }
+    const float S = quad_parts_sum(sums, n);
+    value = total > 0 ? S / (float)total : 0.f;
+    return true;
+}
+
 // The cell formulation (aai_rot_cell.hpp) over a whole image, as aai_cell_kernel runs it: every cell (x, y), x in [0, dW],
 // y in [0, dH], evaluated once (scan first: a cell with a decision too close to its threshold marks itself), its four parts
 // kept; emu_rotated combines them per dst pixel in the kernel's order.
@@ -435,7 +462,14 @@ static void emu_rotated(const Geometry &g, const aai_request &rq, const float *i
                 // the GPU's production pass for generic pixels: fp32, relative to the nearest virtual pixel
                 float value = 0.f;
                 bool done;
-                if (fastQuad) {
+                if (fastQuad && r.wide) {
+                    switch (qc.winFast) {
+                    case 5: done = emu_wide_fast_pixel<5>(qc, r, img, srcStride, px, py, value); break;
+                    case 6: done = emu_wide_fast_pixel<6>(qc, r, img, srcStride, px, py, value); break;
+                    case 7: done = emu_wide_fast_pixel<7>(qc, r, img, srcStride, px, py, value); break;
+                    default: done = emu_wide_fast_pixel<8>(qc, r, img, srcStride, px, py, value); break;
+                    }
+                } else if (fastQuad) {
                     switch (qc.winFast) {
                     case 2: done = emu_quad_fast_pixel<2>(qc, r, img, srcStride, px, py, value); break;
                     case 3: done = emu_quad_fast_pixel<3>(qc, r, img, srcStride, px, py, value); break;

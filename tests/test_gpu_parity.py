@@ -975,11 +975,12 @@ def test_wide_kernel_equals_its_cpu_replay_bit_for_bit(gpu, hostemu, po):
     quadrant, both policies, hiPrec (close to an axis), 8-bit sources, more than one tile row and column."""
     rng = np.random.default_rng(79)
     hostemu.aai_emu_use_quad(1)
+    fast_kernels = set()
     try:
         for (W, H, sr, dr, ang, policy, parts) in ((512, 400, 8.0, 1.0, 17.5, 0, 2), (400, 512, 6.0, 1.0, 45.0, 1, 2), (640, 512, 10.5, 1.0, 123.0, 0, 2),
                                                    (512, 512, 7.0, 1.0, 211.0, 0, 2), (600, 600, 9.3, 1.1, 300.0, 0, 2), (700, 512, 16.0, 1.0, 45.0, 0, 4),
                                                    (800, 640, 21.0, 1.0, 100.0, 1, 4), (640, 800, 13.0, 1.0, 250.0, 0, 4), (512, 512, 9.0, 1.0, 0.7, 0, 2),
-                                                   (900, 500, 26.0, 1.0, 88.5, 0, 4), (1400, 1100, 8.0, 1.0, 17.5, 0, 2)):
+                                                   (900, 500, 26.0, 1.0, 88.5, 0, 4), (1400, 1100, 8.0, 1.0, 17.5, 0, 2), (480, 400, 6.0, 1.0, 17.5, 0, 2)):
             iso = (float(rng.uniform(0.3 * W, 0.7 * W)), float(rng.uniform(0.3 * H, 0.7 * H)))
             src = rng.random((H, W)).astype(np.float32)
             rq = gpu.make_request(W, H, sr, dr, iso, ang, mode=1, policy=policy)
@@ -991,6 +992,18 @@ def test_wide_kernel_equals_its_cpu_replay_bit_for_bit(gpu, hostemu, po):
             differ = int((dst != ref).sum())
             assert wide > 0 and differ <= flagged, (W, H, sr, dr, ang, differ, flagged, wide)
             assert rel_err(dst, ref).max() <= 3e-7
+            # fast mode over the same footprint: aai_wide_fast_kernel (its window of centres is two positions narrower: the
+            # smallest of these geometries fit one window and take aai_quad_fast_kernel)
+            rq = gpu.make_request(W, H, sr, dr, iso, ang, mode=2, policy=policy)
+            ref, axis = hostemu.resample(rq, src)
+            wide, flagged = hostemu.quad_stats()
+            rc, msg, dst, _, lay = gpu.resample_host(src, sr, dr, iso, ang, mode=2, policy=policy)
+            want = "aai_wide_fast_kernel" if hostemu.aai_emu_wide_parts(ctypes.byref(rq)) else "aai_quad_fast_kernel"
+            assert rc == 0 and want in gpu.last_kernel(), (msg, gpu.last_kernel(), sr, ang)
+            fast_kernels.add(want)
+            assert wide > 0 and int((dst != ref).sum()) <= flagged, (W, H, sr, dr, ang, int((dst != ref).sum()), flagged, wide)
+            assert rel_err(dst, ref).max() <= 3e-7
+        assert fast_kernels == {"aai_wide_fast_kernel", "aai_quad_fast_kernel"}, fast_kernels
         isrc = rng.integers(0, 256, size=(480, 640)).astype(np.uint8)
         rq = gpu.make_request(640, 480, 8.0, 1.0, (300.0, 250.0), 33.0, mode=1)
         ref, _ = hostemu.resample(rq, isrc.astype(np.float32))

@@ -811,6 +811,13 @@ def test_wide_fp32_replay_against_oracle(aai, hostemu, po):
             assert not axis and q > 0 and u < 0.02 * q + 2, (W, sr, dr, ang, q, u)
             assert rel_err(out, gold).max() <= 0.3 * TOL, (W, sr, dr, ang, float(rel_err(out, gold).max()))
             assert np.array_equal(gold == 0, out == 0)
+            # fast mode over the same footprints (aai_wide_fast_kernel): a mean of pixel values, fp32 rounding only
+            out, axis = hostemu.resample(aai.make_request(W, H, sr, dr, iso, ang, mode=2, policy=policy), src)
+            q, u = hostemu.quad_stats()
+            gold = po.oracle_run(po.MODE_FAST, src.astype(np.float64), sr, dr, iso, ang, policy=policy).dst
+            assert not axis and q > 0 and u < 0.02 * q + 2, (W, sr, dr, ang, q, u)
+            assert rel_err(out, gold).max() <= 0.1 * TOL, (W, sr, dr, ang, float(rel_err(out, gold).max()))
+            assert np.array_equal(gold == 0, out == 0)
         # 8-bit noise, where a dst value can lie far below its neighbours
         for (W, H, sr, dr, ang, policy) in ((400, 400, 8.0, 1.0, 17.5, 0), (500, 400, 13.0, 1.0, 45.0, 0), (400, 400, 7.0, 1.0, 1.0, 0)):
             iso = ((W - 1) / 2, (H - 1) / 2)
@@ -830,6 +837,12 @@ def test_wide_fp32_replay_against_oracle(aai, hostemu, po):
     assert hostemu.aai_emu_wide_parts(ctypes.byref(plan_of(16.0, 45.0))) == 4
     assert hostemu.aai_emu_wide_parts(ctypes.byref(plan_of(40.0, 45.0))) == 0
     assert hostemu.aai_emu_wide_parts(ctypes.byref(plan_of(8.0, 0.0))) == 0          # axis-aligned: K1
+    # fast mode: the window of centres is two positions narrower
+    def fast_plan_of(sr, ang):
+        return aai.make_request(2048, 2048, sr, 1.0, (1023.5, 1023.5), ang, mode=2)
+    assert hostemu.aai_emu_wide_parts(ctypes.byref(fast_plan_of(5.9, 1.5))) == 0      # the reference's default call: one window (aai_quad_fast_kernel)
+    assert hostemu.aai_emu_wide_parts(ctypes.byref(fast_plan_of(8.0, 17.5))) == 2
+    assert hostemu.aai_emu_wide_parts(ctypes.byref(fast_plan_of(20.0, 30.0))) == 4
 
 
 def test_double_precision_policy_keeps_requests_off_the_fp32_formulation(aai, hostemu, po):
