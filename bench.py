@@ -61,6 +61,7 @@ WORKLOADS = {
     "refdefaultfast": (911, 911, 150.0, 25.4, 1.5, MODE_FAST, "911x911 fp32 at 150 dpi -> 25.4 dpi (158x158), rotation 1.5, isocenter (455,455), fast mode"),
     # not a BASELINE configuration: a wide footprint (the reference's default ratio is 5.9:1; film at 200 dpi -> 25.4 dpi is 8:1) at config 3's angle
     "wide8": (8192, 8192, 8.0, 1.0, 17.5, MODE_AREA, "8192x8192 fp32 -> 1284x1284 (8:1), rotation 17.5"),
+    "wide8fast": (8192, 8192, 8.0, 1.0, 17.5, MODE_FAST, "8192x8192 fp32 -> 1284x1284 (8:1), rotation 17.5, fast mode"),
 }
 ISOCENTER = {"refdefault": (455.0, 455.0), "refdefaultfast": (455.0, 455.0)}      # default: the image centre
 
@@ -71,7 +72,7 @@ def isocenter(name, W, H):
 
 # the `configs` block of the default invocation: (workload, images per launch)
 CONFIG_SET = [("cfg1", 4), ("cfg2", 1), ("cfg3", 1), ("cfg3fast", 1), ("cfg4", 64), ("cfg5", 1), ("cfg5fast", 1), ("cfg5bilinear", 1), ("cfg5bicubic", 1),
-              ("refdefault", 1), ("refdefaultfast", 1), ("wide8", 1)]
+              ("refdefault", 1), ("refdefaultfast", 1), ("wide8", 1), ("wide8fast", 1)]
 
 
 # ---- CPU baseline -----------------------------------------------------------------------------------------------
