@@ -212,7 +212,14 @@ def test_wide_footprints_against_oracle(gpu, formulation, po):
                 assert rc == 0, msg
                 assert (np.abs(dst - gold.dst) / np.maximum(np.abs(gold.dst), 1e-3 * top)).max() <= TOL, (k, dt)
                 assert np.array_equal(gold.dst == 0, dst == 0), (k, dt)
-    assert {"aai_wide_kernel", "aai_rotated_runs_kernel"} <= kernels, kernels
+                # fast mode over the same footprint and source type (aai_wide_fast_kernel / aai_quad_fast_kernel / the line-walking kernel)
+                gold = po.oracle_run(po.MODE_FAST, isrc.astype(np.float64), sr, dr, iso, ang)
+                rc, msg, dst, giso, lay = gpu.resample_host(isrc, sr, dr, iso, ang, mode=2)
+                assert rc == 0, msg
+                kernels.add(gpu.last_kernel().split("<")[0])
+                assert (np.abs(dst - gold.dst) / np.maximum(np.abs(gold.dst), 1e-3 * top)).max() <= TOL, (k, dt, "fast", gpu.last_kernel())
+                assert np.array_equal(gold.dst == 0, dst == 0), (k, dt, "fast")
+    assert {"aai_wide_kernel", "aai_rotated_runs_kernel", "aai_wide_fast_kernel"} <= kernels, kernels
     # the same request under the double-precision policy stays on the runs kernel and agrees to fp32 rounding
     W, H, sr, dr, ang, off = RUNS_CASES[2]
     iso = ((W - 1) / 2, (H - 1) / 2)
