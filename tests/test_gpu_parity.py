@@ -858,7 +858,9 @@ def test_multi_device_entry_and_prepare(gpu):
     aai_prepare builds the plan up front, so that a captured stream only sees launches."""
     import torch
     # (the third geometry: K1 with a fix-up list behind it; the fourth: fast mode, fix-up beside the kernel on the side stream)
-    for (W, H, sr, dr, ang, mode) in ((768, 768, 4, 1, 0.0, 1), (768, 768, 3, 1, 17.5, 1), (40, 9, 3, 1, 0.0, 1), (768, 768, 2, 1, 45.0, 2)):
+    # (the last two: a wide footprint through aai_wide_kernel / aai_wide_fast_kernel)
+    for (W, H, sr, dr, ang, mode) in ((768, 768, 4, 1, 0.0, 1), (768, 768, 3, 1, 17.5, 1), (40, 9, 3, 1, 0.0, 1), (768, 768, 2, 1, 45.0, 2),
+                                      (768, 768, 8, 1, 17.5, 1), (768, 768, 8, 1, 17.5, 2)):
         rq = gpu.make_request(W, H, sr, dr, ((W - 1) / 2, (H - 1) / 2), ang, mode=mode)
         gpu.prepare(rq)
         rc, msg, lay = gpu.query(rq)
