@@ -126,6 +126,9 @@ AAI_HD bool cell_eval(const QuadConsts<F> &q, const CellConsts<F> &z, int Zx, in
     // (a pixel that does not reach a target contributes area 0 there -- and must then contribute nothing, whatever its value:
     // 0 x NaN would put a source pixel's NaN into a dst pixel it does not overlap)
     auto add = [&](int target, F area, F v) { sA[target] += area; sVA[target] = qfma(area, area != F(0) ? v : F(0), sVA[target]); };
+    // ... which only matters for values that are not finite: where every lane's value is (one vote per pixel), 0 x v is 0
+    auto addf = [&](int target, F area, F v) { sA[target] += area; sVA[target] = qfma(area, v, sVA[target]); };
+    auto finite = [&](F v) -> bool { return AAI_WAVE_ALL(qabs(v) <= F(3.0e38)); };
 
     // window origin: the first lattice point the zone's bounding box can hold
     const F fi0 = ceil(fpx - z.hbz), fj0 = ceil(fpy - z.hbz);
@@ -301,10 +304,11 @@ AAI_HD bool cell_eval(const QuadConsts<F> &q, const CellConsts<F> &z, int Zx, in
         const F aN = right ? (down ? gN : both) : (down ? F(0) : gEr);
         const F aNW = right ? (down ? F(0) : gWr) : (down ? gN : both);
         const F v = value(slot);
-        add(CELL_O, aO, v);
-        add(CELL_W, aW, v);
-        add(CELL_N, aN, v);
-        add(CELL_NW, aNW, v);
+        if (finite(v)) {
+            addf(CELL_O, aO, v); addf(CELL_W, aW, v); addf(CELL_N, aN, v); addf(CELL_NW, aNW, v);
+        } else {
+            add(CELL_O, aO, v); add(CELL_W, aW, v); add(CELL_N, aN, v); add(CELL_NW, aNW, v);
+        }
     }
     return uncertain;
 }

@@ -1051,6 +1051,35 @@ def test_cell_kernel_equals_its_cpu_replay_bit_for_bit(gpu, hostemu, po):
         gpu.debug_cell_min_waves(-1)
 
 
+def test_a_nan_source_pixel_stays_local(gpu):
+    """A NaN (or Inf) in the source reaches exactly the dst pixels whose footprint overlaps that pixel: a pair with area 0 must not
+    carry 0 x NaN into a dst pixel it does not touch (the cell kernel feeds four dst pixels from every pair, and its fast path for
+    finite values is taken by a vote over the wave).  Every fp32 formulation, fast mode, up- and down-sampling."""
+    rng = np.random.default_rng(12)
+    gpu.debug_cell_min_waves(0)
+    try:
+        for (W, H, sr, dr, ang, mode) in ((160, 120, 3.0, 1.0, 17.5, 1), (64, 64, 1.0, 4.0, 45.0, 1), (200, 160, 8192.0, 2731.0, 200.0, 1), (400, 400, 8.0, 1.0, 33.0, 1),
+                                          (160, 120, 3.0, 1.0, 17.5, 2), (400, 400, 8.0, 1.0, 33.0, 2), (64, 64, 1.0, 2.0, 30.0, 2)):
+            iso = ((W - 1) / 2, (H - 1) / 2)
+            src = rng.random((H, W)).astype(np.float32) + 0.5
+            y, x = H // 2 + 3, W // 2 - 5
+            for bad in (np.nan, np.inf):
+                poisoned = src.copy(); poisoned[y, x] = bad
+                zeroed = src.copy(); zeroed[y, x] = 0.0
+                delta = np.zeros_like(src); delta[y, x] = 1.0
+                rc, msg, out_bad, _, _ = gpu.resample_host(poisoned, sr, dr, iso, ang, mode=mode)
+                kernel = gpu.last_kernel()
+                rc2, _, out_zero, _, _ = gpu.resample_host(zeroed, sr, dr, iso, ang, mode=mode)
+                rc3, _, out_delta, _, _ = gpu.resample_host(delta, sr, dr, iso, ang, mode=mode)
+                assert rc == 0 and rc2 == 0 and rc3 == 0, msg
+                touched = out_delta > 0
+                broken = ~np.isfinite(out_bad)
+                assert touched.any() and np.array_equal(broken, touched), (W, sr, ang, mode, kernel, int(touched.sum()), int(broken.sum()))
+                assert np.array_equal(out_bad[~broken], out_zero[~broken]), (W, sr, ang, mode, kernel)
+    finally:
+        gpu.debug_cell_min_waves(-1)
+
+
 def test_double_precision_policy(gpu, po):
     """AAI_POLICY_DOUBLE_PRECISION routes general rotations to the double-precision kernels: exact to fp32 rounding on
     the geometry class where the fp32 formulation has its tail (dst values far below their neighbours: slight
