@@ -175,12 +175,14 @@ AAI_HD bool cell_eval(const QuadConsts<F> &q, const CellConsts<F> &z, int Zx, in
     for (int jj = 0; jj < WIN; ++jj) {
         const int j = WIN - 1 - jj;                                  // (last slot first: QuadPlane)
         const F fj = fj0 + (F)j;
-        const F rowA = qfma(-fj, q.s, ac), rowB = qfma(fj, q.c, bc);
+        F rowA, rowB;
+        qfma2(-fj, fj, q.s, q.c, ac, bc, rowA, rowB);
 #pragma unroll
         for (int ii = 0; ii < WIN; ++ii) {
             const int i = WIN - 1 - ii;
             const F fi = fi0 + (F)i;
-            const F az = qfma(fi, q.c, rowA), bz = qfma(fi, q.s, rowB);
+            F az, bz;
+            qfma2(fi, fi, q.c, q.s, rowA, rowB, az, bz);
             const u64 bit = (u64)1 << (j * WIN + i);
             plZ.push(j * WIN + i, qabs(az) < q.h && qabs(bz) < q.h);
             plV.push(j * WIN + i, az < z.thr);

@@ -199,6 +199,23 @@ AAI_HD double qabs(double a) { return __builtin_fabs(a); }
 // compiler chose to fuse differently.
 AAI_HD float qfma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
 AAI_HD double qfma(double a, double b, double c) { return __builtin_fma(a, b, c); }
+// two independent fused multiply-adds: r0 = a0 b0 + c0, r1 = a1 b1 + c1 -- ONE packed instruction on the GPU (v_pk_fma_f32), the
+// same two IEEE operations on the CPU
+AAI_HD void qfma2(float a0, float a1, float b0, float b1, float c0, float c1, float &r0, float &r1)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    const f2 a = {a0, a1}, b = {b0, b1}, c = {c0, c1};
+    const f2 r = __builtin_elementwise_fma(a, b, c);
+    r0 = r.x; r1 = r.y;
+#else
+    r0 = __builtin_fmaf(a0, b0, c0); r1 = __builtin_fmaf(a1, b1, c1);
+#endif
+}
+AAI_HD void qfma2(double a0, double a1, double b0, double b1, double c0, double c1, double &r0, double &r1)
+{
+    r0 = __builtin_fma(a0, b0, c0); r1 = __builtin_fma(a1, b1, c1);
+}
 
 // Area of the part of a unit pixel on the inner side of ONE edge line that has entered it by t (0 <= t <= c+s,
 // measured from the pixel's extreme corner along the line's normal).  substitute: the line is a left/right edge
@@ -399,12 +416,15 @@ AAI_HD bool quad_pixel(const QuadConsts<F> &q, int Xc, int Yc, double dfx, doubl
     for (int jj = 0; jj < WIN; ++jj) {
         const int j = WIN - 1 - jj;                                  // (last slot first: QuadPlane)
         const F fj = fj0 + (F)j;
-        const F rowA = qfma(-fj, q.s, ac), rowB = qfma(fj, q.c, bc);
+        F rowA, rowB;
+        qfma2(-fj, fj, q.s, q.c, ac, bc, rowA, rowB);
 #pragma unroll
         for (int ii = 0; ii < WIN; ++ii) {
             const int i = WIN - 1 - ii;
             const F fi = fi0 + (F)i;
-            const F a = qabs(qfma(fi, q.c, rowA)), b = qabs(qfma(fi, q.s, rowB));
+            F sa, sb;
+            qfma2(fi, fi, q.c, q.s, rowA, rowB, sa, sb);
+            const F a = qabs(sa), b = qabs(sb);
             const u64 bit = (u64)1 << (j * WIN + i);
             plA.push(j * WIN + i, a <= q.hmk);
             plB.push(j * WIN + i, b <= q.hmk);
@@ -559,10 +579,13 @@ AAI_HD bool quad_fast_pixel(const QuadConsts<F> &q, int Xc, int Yc, double dfx, 
     bool uncertain = false;
 #pragma unroll
     for (int j = 0; j < WIN; ++j) {
-        const F rowA = qfma(-fjs[j], q.s, ac), rowB = qfma(fjs[j], q.c, bc);
+        F rowA, rowB;
+        qfma2(-fjs[j], fjs[j], q.s, q.c, ac, bc, rowA, rowB);
 #pragma unroll
         for (int i = 0; i < WIN; ++i) {
-            const F a = qabs(qfma(fis[i], q.c, rowA)), b = qabs(qfma(fis[i], q.s, rowB));
+            F sa, sb;
+            qfma2(fis[i], fis[i], q.c, q.s, rowA, rowB, sa, sb);
+            const F a = qabs(sa), b = qabs(sb);
             const bool in = a <= q.h && b <= q.h;
             if (SCAN) {
                 if ((qabs(a - q.h) < q.margin && b < q.h + q.margin) || (qabs(b - q.h) < q.margin && a < q.h + q.margin)) uncertain = true;
