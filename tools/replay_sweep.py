@@ -4,7 +4,8 @@ model scan + fix-up, fp32 quad formulation + scans + strict fix-up) against the 
 reference's DBL_EPSILON rules decide: integer / rational ratios, isocenters on pixel centres, corners, half and quarter
 pixels, rotations at multiples of 90 degrees ("axis") or at atan(p/q), 15-degree steps and hair-breadth angles ("rotated").
 Needs no GPU; with --gpu the same cases go through the device library instead (on a GPU box).
-usage: python tools/replay_sweep.py axis|rotated [cases] [seed] [--gpu]"""
+"wide": the rotated angles at ratios 6:1 ... 20:1 on images up to 220 x 220 (the wide-footprint kernels).
+usage: python tools/replay_sweep.py axis|rotated|wide [cases] [seed] [--gpu]"""
 import math
 import os
 import sys
@@ -22,6 +23,7 @@ AXIS_RATIOS = [(5, 1), (3, 1), (2, 1), (4, 1), (7, 1), (1, 1), (5, 2), (3, 2), (
                (1.5, 1), (3, 4), (10, 3), (8, 1)]
 ROT_RATIOS = [(5, 1), (3, 1), (2, 1), (4, 1), (1, 1), (5, 2), (3, 2), (1, 2), (2, 3), (2.5, 1), (6, 1), (7, 3), (4, 3), (1.5, 1), (2 ** 0.5, 1),
               (2 * 2 ** 0.5, 1), (5 ** 0.5, 1), (1, 2 ** 0.5), (2.236067977, 2), (1.25, 1)]
+WIDE_RATIOS = [(6, 1), (8, 1), (10, 1), (12, 1), (16, 1), (7, 1), (9, 1), (15, 2), (20, 1), (6 * 2 ** 0.5, 1), (13, 2), (25, 3)]      # "wide": footprints beyond one 8 x 8 window
 ROT_ANGLES = [45.0, 30.0, 60.0, math.degrees(math.atan(0.5)), math.degrees(math.atan(2)), math.degrees(math.atan(0.75)), math.degrees(math.atan(1 / 3)),
               22.5, 15.0, 75.0, math.degrees(math.atan(0.25)), 1e-7, 89.9999999, 0.001, 1.0]
 
@@ -35,9 +37,9 @@ def sweep(kind, cases, seed, hostemu, report=print, gpu=False):
         hostemu.aai_emu_use_quad(1)
     try:
         for _ in range(cases):
-            big = 48 if kind == "axis" else 40
-            W, H = int(rng.integers(1, big)), int(rng.integers(1, big))
-            ratios = AXIS_RATIOS if kind == "axis" else ROT_RATIOS
+            big = 48 if kind == "axis" else (220 if kind == "wide" else 40)
+            W, H = int(rng.integers(1 if kind != "wide" else 40, big)), int(rng.integers(1 if kind != "wide" else 40, big))
+            ratios = AXIS_RATIOS if kind == "axis" else (WIDE_RATIOS if kind == "wide" else ROT_RATIOS)
             sr, dr = ratios[int(rng.integers(0, len(ratios)))]
             if dr / sr > 2.2:
                 continue
