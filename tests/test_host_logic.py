@@ -422,6 +422,9 @@ def test_structured_sweeps_of_the_replay_against_the_oracle(aai, hostemu):
     assert n > 2000 and bad == 0 and fixups >= 20, (n, bad, fixups, problems[:3])
     n, bad, worst, fixups = mod.sweep("rotated", 2500, 102, hostemu, report=lambda *a: problems.append(a))
     assert n > 2000 and bad == 0 and worst <= 0.7 * TOL, (n, bad, worst, problems[:3])
+    # the same angles at ratios 6:1 ... 20:1: the wide-footprint formulation (a window in parts) and its scan
+    n, bad, worst, fixups = mod.sweep("wide", 600, 103, hostemu, report=lambda *a: problems.append(a))
+    assert n > 500 and bad == 0 and worst <= 0.5 * TOL, (n, bad, worst, problems[:3])
 
 
 def test_baseline_geometries_raise_no_knife_flags(aai, hostemu, po):
