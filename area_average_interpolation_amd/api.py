@@ -118,6 +118,28 @@ def resample_host(src, src_resolution, dst_resolution, src_isocenter, rotation_a
     return rc, "", dst, (out_lay.dst_iso_x, out_lay.dst_iso_y), out_lay
 
 
+def precision_check(src, src_resolution, dst_resolution, src_isocenter, rotation_angle, mode=L.MODE_AREA, policy=L.POLICY_REFERENCE,
+                    floor=None):
+    """Does THIS image need AAI_POLICY_DOUBLE_PRECISION?  The default kernels take general rotations in fp32 (include/aai.h): a dst
+    value is then off by ~5e-8 x the spread of the source values under its footprint, which only shows where a dst value is hundreds
+    of times smaller than its neighbours.  That is a property of the data, not of the geometry, so no plan-time scan can flag it:
+    this runs the request under both policies and returns (worst relative deviation, dst of the default policy, dst of the
+    double-precision policy).  `floor`: absolute floor of the denominator (default 1e-6 x the largest |value|).  A deviation
+    above ~1e-5 says: use `policy | POLICY_DOUBLE_PRECISION` for images like this one (about 3 x the time)."""
+    rc, msg, fast, _, _ = resample_host(src, src_resolution, dst_resolution, src_isocenter, rotation_angle, mode=mode, policy=policy)
+    if rc != L.OK:
+        raise AaiError(rc, msg)
+    rc, msg, exact, _, _ = resample_host(src, src_resolution, dst_resolution, src_isocenter, rotation_angle, mode=mode,
+                                        policy=policy | L.POLICY_DOUBLE_PRECISION)
+    if rc != L.OK:
+        raise AaiError(rc, msg)
+    if exact.size == 0:
+        return 0.0, fast, exact
+    a, b = fast.astype(np.float64), exact.astype(np.float64)
+    fl = floor if floor is not None else 1e-6 * max(float(np.abs(b).max()), 1e-300)
+    return float((np.abs(a - b) / np.maximum(np.abs(b), fl)).max()), fast, exact
+
+
 _NP_DTYPES = {np.dtype(np.float32): L.DTYPE_F32, np.dtype(np.uint8): L.DTYPE_U8, np.dtype(np.uint16): L.DTYPE_U16}
 
 

@@ -1080,6 +1080,23 @@ def test_a_nan_source_pixel_stays_local(gpu):
         gpu.debug_cell_min_waves(-1)
 
 
+def test_precision_check_tells_benign_from_risky_data(gpu):
+    """precision_check: uniform noise and the dose-like image are far inside 1e-5 under the fp32 kernels; a value a
+    million times below its neighbours is not, and the helper says so."""
+    from oracle import pyoracle as po                  # (only for the synthetic dose image)
+    rng = np.random.default_rng(14)
+    benign = rng.random((300, 280)).astype(np.float32)
+    dev, _, _ = gpu.precision_check(benign, 3.0, 1.0, (139.5, 149.5), 17.5)
+    assert dev <= 2e-6, dev
+    dose = po.dose_image(400, 400, 2).astype(np.float32)
+    dev, _, _ = gpu.precision_check(dose, 5.9, 1.0, (199.5, 199.5), 1.5)
+    assert dev <= 1e-5, dev
+    spiky = np.full((200, 200), 1e-6, dtype=np.float32)
+    spiky[::7, ::5] = 1.0e3                               # isolated spikes nine decades above the background
+    dev, a, b = gpu.precision_check(spiky, 1.0, 2.0, (99.5, 99.5), 30.0, floor=1e-12)
+    assert dev > 1e-5 and np.isfinite(a).all() and np.isfinite(b).all(), dev
+
+
 def test_double_precision_policy(gpu, po):
     """AAI_POLICY_DOUBLE_PRECISION routes general rotations to the double-precision kernels: exact to fp32 rounding on
     the geometry class where the fp32 formulation has its tail (dst values far below their neighbours: slight
