@@ -328,9 +328,11 @@ static int build_plan(Plan &p)
                 // keep the masks: the fp32 kernel skips the flagged pixels and the fix-up pass runs beside it
                 p.dMasks = dMasks;
                 dMasks = nullptr;
-                e = hipStreamCreateWithFlags(&p.side, hipStreamNonBlocking);
-                if (e == hipSuccess) e = hipEventCreateWithFlags(&p.fork, hipEventDisableTiming);
-                if (e == hipSuccess) e = hipEventCreateWithFlags(&p.join, hipEventDisableTiming);
+                for (int k = 0; k < Plan::kSideSlots && e == hipSuccess; ++k) {
+                    e = hipStreamCreateWithFlags(&p.side[k], hipStreamNonBlocking);
+                    if (e == hipSuccess) e = hipEventCreateWithFlags(&p.fork[k], hipEventDisableTiming);
+                    if (e == hipSuccess) e = hipEventCreateWithFlags(&p.join[k], hipEventDisableTiming);
+                }
             }
             if (dMasks) (void)hipFree(dMasks);
             stage("side stream + events");
@@ -490,7 +492,8 @@ int enqueue(const aai_request &rq, int batch, const void *dSrc, int srcType, int
         const aai::QuadMap qm = aai::make_quad_map(g, srcStride, r.srcRow0, channels, srcType == aai::SRC_U8 ? 1 : srcType == aai::SRC_U16 ? 2 : 4);
         aai::RotFlags flags;
         flags.list = p->dList; flags.count = p->flaggedPixels; flags.dense = p->dense;
-        flags.masks = p->dMasks; flags.live = p->dLive; flags.side = p->side; flags.fork = p->fork; flags.join = p->join; flags.form = p->form;
+        const unsigned slot = p->nextSide++ % Plan::kSideSlots;      // (under p->launch)
+        flags.masks = p->dMasks; flags.live = p->dLive; flags.side = p->side[slot]; flags.fork = p->fork[slot]; flags.join = p->join[slot]; flags.form = p->form;
         e = hipSuccess;
         for (int b0 = 0; b0 < batch && e == hipSuccess; b0 += kMaxGridZ)
             e = aai::launch_rotated(r, qm, src_at(dSrc, srcType, (int64_t)b0 * srcImageStride), srcType, sv, dDst + (int64_t)b0 * dstImageStride, dv,

@@ -50,8 +50,12 @@ struct Plan {
     // fp32 rotated kernels: the lane masks of the flagged pixels (they skip them) and the side stream the fix-up pass runs on
     unsigned long long *dMasks = nullptr;
     int *dLive = nullptr;            // per-pixel kernels on a rotated canvas: live tile span per tile row (aai::rotated_live_spans), or none
-    hipStream_t side = nullptr;
-    hipEvent_t fork = nullptr, join = nullptr;
+    // (kSideSlots of them, dealt round-robin per call under `launch`: the fix-up passes of callers on different streams run beside
+    // each other instead of queueing on one stream)
+    static constexpr int kSideSlots = 4;
+    hipStream_t side[kSideSlots] = {};
+    hipEvent_t fork[kSideSlots] = {}, join[kSideSlots] = {};
+    unsigned nextSide = 0;
     double buildMs = 0.0;            // wall clock of build_plan (tables, scans, launch-shape measurement)
     // Built once, by whoever gets here first, under `build` -- NOT under the cache's lock: other requests, other devices
     // and other threads are not held up by this plan's scans or launch-shape measurement.  `launch` serialises the use of
@@ -62,9 +66,11 @@ struct Plan {
     std::string buildError;
     ~Plan()
     {
-        if (side) { (void)hipStreamSynchronize(side); (void)hipStreamDestroy(side); }
-        if (fork) (void)hipEventDestroy(fork);
-        if (join) (void)hipEventDestroy(join);
+        for (int k = 0; k < kSideSlots; ++k) {
+            if (side[k]) { (void)hipStreamSynchronize(side[k]); (void)hipStreamDestroy(side[k]); }
+            if (fork[k]) (void)hipEventDestroy(fork[k]);
+            if (join[k]) (void)hipEventDestroy(join[k]);
+        }
         if (dMasks) (void)hipFree(dMasks);
         if (dLive) (void)hipFree(dLive);
         if (dList) (void)hipFree(dList);
