@@ -381,33 +381,38 @@ constexpr int kTileCols = 16;
 constexpr int kTilePitch = kTileCols + 1;              // odd pitch: the transposed reads hit 64 different banks
 constexpr int kTileWaveFloats = 64 * VEC + 8 + 256 * kTilePitch;
 
-template <bool NT, typename T>
+// COOP: the four waves of a workgroup take ONE strip and four consecutive groups of 16 output rows, meet at a barrier and store
+// together -- lane = one of 64 consecutive dst x, read from the four waves' tiles: 256 contiguous bytes per dst row and store
+// instruction instead of four 64-byte segments.
+constexpr int kTileWaveFloatsCoop = (kTileWaveFloats + 31) / 32 * 32 + 16;      // tiles 16 banks apart: the joint reads are conflict free
+template <bool NT, typename T, bool COOP>
 __global__ __launch_bounds__(kWaves * 64) void aai_axis_tile_kernel(AxisLaunch a, const AxisEntry *__restrict__ laneTab,
                                                                      const AxisEntry *__restrict__ rowTab, const AxisStrip *__restrict__ strips,
                                                                      const T *__restrict__ src, ImageView sv,
                                                                      float *__restrict__ dst, ImageView dv)
 {
-    __shared__ __attribute__((aligned(16))) float smem[kWaves * kTileWaveFloats];     // 72 KiB: two workgroups per CU
+    constexpr int kWaveFloats = COOP ? kTileWaveFloatsCoop : kTileWaveFloats;
+    __shared__ __attribute__((aligned(16))) float smem[kWaves * kWaveFloats];     // 72 KiB: two workgroups per CU
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int strip = blockIdx.x * kWaves + wave;
-    if (strip >= a.nStrips) return;   // waves are independent: no s_barrier anywhere
+    const int strip = COOP ? (int)blockIdx.x : (int)blockIdx.x * kWaves + wave;
+    if (strip >= a.nStrips) return;   // (not COOP: waves are independent, no s_barrier anywhere; COOP: the whole workgroup leaves)
 
     typedef int i4s __attribute__((ext_vector_type(4)));
     const i4s stq = reinterpret_cast<const i4s *>(strips)[strip];
     struct { int k0, k1, x0; } st = {stq.x, stq.y, stq.z};
     const T *img = src + (int64_t)blockIdx.z * sv.imageStride;
     float *out = dst + (int64_t)blockIdx.z * dv.imageStride + a.outBase;
-    float *line = smem + wave * kTileWaveFloats;
+    float *line = smem + wave * kWaveFloats;
     float *tile = line + 64 * VEC + 8;
     const int col = st.x0 + VEC * lane;
     const int colc = min(col, a.srcW - VEC);
     const int shift = col - colc;
     const int nOut = st.k1 - st.k0;                              // <= 256
     const int nq = (nOut + 63) >> 6;                             // wave-uniform
-    const int kb0 = blockIdx.y * kTileCols;
-    const int nCols = min(kTileCols, a.nB - kb0);
+    const int kb0 = COOP ? ((int)blockIdx.y * kWaves + wave) * kTileCols : (int)blockIdx.y * kTileCols;
+    const int nCols = max(0, min(kTileCols, a.nB - kb0));
 
     const int kl = st.k0 + lane;
     const Win c0 = load_win(laneTab, kl < st.k1 ? kl : st.k0), c1 = load_win(laneTab, kl + 64 < st.k1 ? kl + 64 : st.k0);
@@ -423,6 +428,17 @@ __global__ __launch_bounds__(kWaves * 64) void aai_axis_tile_kernel(AxisLaunch a
         if (nq > 1) tile[(lane + 64) * kTilePitch + j] = horizontal_pass(line, c1.s0 - st.x0, c1.s1 - c1.s0, c1.wF, c1.wM, c1.wL);
         if (nq > 2) tile[(lane + 128) * kTilePitch + j] = horizontal_pass(line, c2.s0 - st.x0, c2.s1 - c2.s0, c2.wF, c2.wM, c2.wL);
         if (nq > 3) tile[(lane + 192) * kTilePitch + j] = horizontal_pass(line, c3.s0 - st.x0, c3.s1 - c3.s0, c3.wF, c3.wM, c3.wL);
+    }
+    if (COOP) {
+        __syncthreads();
+        // lane = dst x within the workgroup's 64 output rows (kb), read from the tile of the wave that computed it; wave w stores
+        // the dst rows r = w, w + 4, ...
+        const int kbBase = (int)blockIdx.y * kWaves * kTileCols;
+        const float *from = smem + (lane >> 4) * kWaveFloats + 64 * VEC + 8 + (lane & (kTileCols - 1));
+        if (kbBase + lane < a.nB)
+            for (int r = wave; r < nOut; r += kWaves)
+                out[(int64_t)(st.k0 + r) * a.outStrideA + (int64_t)(kbBase + lane) * a.outStrideB] = from[r * kTilePitch];
+        return;
     }
     __builtin_amdgcn_wave_barrier();
     // store: four dst rows x 16 dst columns per instruction
@@ -546,12 +562,20 @@ static hipError_t launch_axis_typed(const AxisLaunch &a, const T *src, ImageView
     int tile = a.transposed && a.tapStep <= 1 && (a.outStrideB == 1 || a.outStrideB == -1) && a.maxOutputsPerStrip > 128 &&
                a.maxOutputsPerStrip <= 256;
     if (tune.tile >= 0) tile = tile && tune.tile != 0;
+    if (tune.tile == 2) tile = a.transposed && a.tapStep <= 1 && (a.outStrideB == 1 || a.outStrideB == -1) && a.maxOutputsPerStrip > 64 && a.maxOutputsPerStrip <= 256;      // experiment: from 4:1 down
     if (tile && (a.nB + kTileCols - 1) / kTileCols <= 65535) {
         // transposed quadrants at ratios below 4: LDS tile, stores along dst x (see aai_axis_tile_kernel)
-        dim3 grid((a.nStrips + kWaves - 1) / kWaves, (a.nB + kTileCols - 1) / kTileCols, batch), block(kWaves * 64);
         if (kernelName) *kernelName = "aai_axis_tile_kernel";
-        if (nt) hipLaunchKernelGGL((aai_axis_tile_kernel<true, T>), grid, block, 0, stream, a, a.laneTab, a.rowTab, a.strips, src, sv, dst, dv);
-        else hipLaunchKernelGGL((aai_axis_tile_kernel<false, T>), grid, block, 0, stream, a, a.laneTab, a.rowTab, a.strips, src, sv, dst, dv);
+        const bool coop = tune.tile != 1 && a.nStrips <= 2147483647;      // (experiments: tile=1 keeps the independent-waves form)
+        if (coop) {
+            dim3 grid(a.nStrips, (a.nB + kWaves * kTileCols - 1) / (kWaves * kTileCols), batch), block(kWaves * 64);
+            if (nt) hipLaunchKernelGGL((aai_axis_tile_kernel<true, T, true>), grid, block, 0, stream, a, a.laneTab, a.rowTab, a.strips, src, sv, dst, dv);
+            else hipLaunchKernelGGL((aai_axis_tile_kernel<false, T, true>), grid, block, 0, stream, a, a.laneTab, a.rowTab, a.strips, src, sv, dst, dv);
+            return hipGetLastError();
+        }
+        dim3 grid((a.nStrips + kWaves - 1) / kWaves, (a.nB + kTileCols - 1) / kTileCols, batch), block(kWaves * 64);
+        if (nt) hipLaunchKernelGGL((aai_axis_tile_kernel<true, T, false>), grid, block, 0, stream, a, a.laneTab, a.rowTab, a.strips, src, sv, dst, dv);
+        else hipLaunchKernelGGL((aai_axis_tile_kernel<false, T, false>), grid, block, 0, stream, a, a.laneTab, a.rowTab, a.strips, src, sv, dst, dv);
         return hipGetLastError();
     }
     const int blocksX = (a.nStrips + kWaves - 1) / kWaves;
