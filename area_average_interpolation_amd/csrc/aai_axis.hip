@@ -132,6 +132,37 @@ __device__ __forceinline__ Cols vertical_pass(const T *__restrict__ img, int64_t
     return acc;
 }
 
+// The same in two halves, for callers that keep several output rows' loads in flight: issue_rows starts the loads of a window of
+// at most four source rows (the caller checks), finish_rows does vertical_pass's arithmetic on them, operation for operation.
+template <typename T> struct Rows4 { Raw<T> r0, r1, r2, r3; };
+template <bool NT, typename T>
+__device__ __forceinline__ void issue_rows(const T *__restrict__ img, int64_t rowStride, int colc, const Win e, Rows4<T> &r)
+{
+    const T *p = img + (int64_t)e.s0 * rowStride + colc;
+    r.r0.template load<NT>(p);
+    r.r1.zero(); r.r2.zero(); r.r3.zero();
+    if (e.s0 + 1 <= e.s1) r.r1.template load<NT>(p + rowStride);
+    if (e.s0 + 2 <= e.s1) r.r2.template load<NT>(p + 2 * rowStride);
+    if (e.s0 + 3 <= e.s1) r.r3.template load<NT>(p + 3 * rowStride);
+}
+template <typename T>
+__device__ __forceinline__ Cols finish_rows(const Rows4<T> &r, const Win e)
+{
+    Cols acc;
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) acc.v[i] = 0.f;
+    const int y = e.s0;
+    const float w0 = row_weight(e, y), w1 = row_weight(e, y + 1), w2 = row_weight(e, y + 2), w3 = row_weight(e, y + 3);
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) {
+        acc.v[i] += w0 * r.r0.get(i);
+        acc.v[i] += w1 * r.r1.get(i);
+        acc.v[i] += w2 * r.r2.get(i);
+        acc.v[i] += w3 * r.r3.get(i);
+    }
+    return acc;
+}
+
 // Park the lane's VEC vertical sums in the wave's LDS line (position = column - strip origin).  Near the right
 // image edge a lane loaded the last in-range vector instead of its own (colc = min(col, W - VEC), shift =
 // col - colc): it then holds columns [colc, colc + VEC) and writes only those at or right of its own first column
@@ -417,9 +448,20 @@ __global__ __launch_bounds__(kWaves * 64) void aai_axis_tile_kernel(AxisLaunch a
     const int kl = st.k0 + lane;
     const Win c0 = load_win(laneTab, kl < st.k1 ? kl : st.k0), c1 = load_win(laneTab, kl + 64 < st.k1 ? kl + 64 : st.k0);
     const Win c2 = load_win(laneTab, kl + 128 < st.k1 ? kl + 128 : st.k0), c3 = load_win(laneTab, kl + 192 < st.k1 ? kl + 192 : st.k0);
-    for (int j = 0; j < nCols; ++j) {
-        const Win e = load_win(rowTab, kb0 + j);
-        const Cols v = vertical_pass<NT, T>(img, sv.rowStride, colc, e);
+    // The output rows of a tile in a software pipeline kDepth deep: with 72 KiB of LDS per workgroup a SIMD holds two waves, and a wave
+    // that waits for each output row's source rows before it asks for the next spends its life in load latency (1:1 at 270 degrees:
+    // 2.6 TB/s).  Windows here are at most four source rows tall (ratios below 2); a taller one takes the plain path.
+    constexpr int kDepth = 8;
+    Rows4<T> ring[kDepth];
+    Win wring[kDepth];
+    bool tall = false;
+#pragma unroll
+    for (int d = 0; d < kDepth; ++d) {
+        wring[d] = load_win(rowTab, kb0 + (d < nCols ? d : 0));
+        tall = tall || wring[d].s1 - wring[d].s0 >= 4;
+    }
+    for (int j = kDepth; j < nCols; ++j) { const Win e = load_win(rowTab, kb0 + j); tall = tall || e.s1 - e.s0 >= 4; }
+    auto finish_column = [&](int j, const Cols &v) {
         __builtin_amdgcn_wave_barrier();
         park(line, lane, shift, v);
         __builtin_amdgcn_wave_barrier();
@@ -428,6 +470,27 @@ __global__ __launch_bounds__(kWaves * 64) void aai_axis_tile_kernel(AxisLaunch a
         if (nq > 1) tile[(lane + 64) * kTilePitch + j] = horizontal_pass(line, c1.s0 - st.x0, c1.s1 - c1.s0, c1.wF, c1.wM, c1.wL);
         if (nq > 2) tile[(lane + 128) * kTilePitch + j] = horizontal_pass(line, c2.s0 - st.x0, c2.s1 - c2.s0, c2.wF, c2.wM, c2.wL);
         if (nq > 3) tile[(lane + 192) * kTilePitch + j] = horizontal_pass(line, c3.s0 - st.x0, c3.s1 - c3.s0, c3.wF, c3.wM, c3.wL);
+    };
+    if (tall) {
+        for (int j = 0; j < nCols; ++j) finish_column(j, vertical_pass<NT, T>(img, sv.rowStride, colc, load_win(rowTab, kb0 + j)));
+    } else {
+#pragma unroll
+        for (int d = 0; d < kDepth; ++d)
+            if (d < nCols) issue_rows<NT, T>(img, sv.rowStride, colc, wring[d], ring[d]);
+        for (int j0 = 0; j0 < nCols; j0 += kDepth) {
+#pragma unroll
+            for (int d = 0; d < kDepth; ++d) {
+                const int j = j0 + d;
+                if (j < nCols) {                                  // wave-uniform
+                    const Cols v = finish_rows<T>(ring[d], wring[d]);
+                    if (j + kDepth < nCols) {                     // the slot's next output row: asked for before this one is parked
+                        wring[d] = load_win(rowTab, kb0 + j + kDepth);
+                        issue_rows<NT, T>(img, sv.rowStride, colc, wring[d], ring[d]);
+                    }
+                    finish_column(j, v);
+                }
+            }
+        }
     }
     if (COOP) {
         __syncthreads();
