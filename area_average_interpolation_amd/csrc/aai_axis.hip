@@ -622,10 +622,13 @@ static hipError_t launch_axis_typed(const AxisLaunch &a, const T *src, ImageView
     if (tune.swap >= 0) swapXY = tune.swap;
     // (measured, profiles/r01_axis_transposed.txt: wins below 2:1 -- 1:1 1.8 -> 2.3 TB/s, x4 up-sampling 1.2 -> 1.6 --
     // and loses 5-14 % to the four-column register path between 2:1 and 4:1)
-    int tile = a.transposed && a.tapStep <= 1 && (a.outStrideB == 1 || a.outStrideB == -1) && a.maxOutputsPerStrip > 128 &&
-               a.maxOutputsPerStrip <= 256;
-    if (tune.tile >= 0) tile = tile && tune.tile != 0;
-    if (tune.tile == 2) tile = a.transposed && a.tapStep <= 1 && (a.outStrideB == 1 || a.outStrideB == -1) && a.maxOutputsPerStrip > 64 && a.maxOutputsPerStrip <= 256;      // experiment: from 4:1 down
+    // ... and, since its output rows run in a software pipeline and its waves store together, down to 64 outputs per strip (ratios up
+    // to 4) wherever no output row needs more than the pipeline's four source rows (ratios up to 3): 3:1 at 270 degrees 300 -> 242 us
+    // per 4 images, 2.5:1 351 -> 271, 2:1 285 -> 275 (profiles/r03_axis_tile.txt)
+    const bool tileable = a.transposed && a.tapStep <= 1 && (a.outStrideB == 1 || a.outStrideB == -1) && a.maxOutputsPerStrip <= 256;
+    int tile = tileable && (a.maxOutputsPerStrip > 128 || (a.maxOutputsPerStrip > 64 && a.maxRowSpan <= 4));
+    if (tune.tile == 0) tile = 0;
+    if (tune.tile == 1) tile = tileable && a.maxOutputsPerStrip > 128;      // experiments: the round-1 rule and the independent-waves form
     if (tile && (a.nB + kTileCols - 1) / kTileCols <= 65535) {
         // transposed quadrants at ratios below 4: LDS tile, stores along dst x (see aai_axis_tile_kernel)
         if (kernelName) *kernelName = "aai_axis_tile_kernel";
