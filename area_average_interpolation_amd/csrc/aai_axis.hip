@@ -134,31 +134,37 @@ __device__ __forceinline__ Cols vertical_pass(const T *__restrict__ img, int64_t
 
 // The same in two halves, for callers that keep several output rows' loads in flight: issue_rows starts the loads of a window of
 // at most four source rows (the caller checks), finish_rows does vertical_pass's arithmetic on them, operation for operation.
-template <typename T> struct Rows4 { Raw<T> r0, r1, r2, r3; };
-template <bool NT, typename T>
-__device__ __forceinline__ void issue_rows(const T *__restrict__ img, int64_t rowStride, int colc, const Win e, Rows4<T> &r)
+template <typename T, int NR> struct RowsN { Raw<T> r[NR]; };      // NR = 4 or 8 source rows
+template <bool NT, typename T, int NR>
+__device__ __forceinline__ void issue_rows(const T *__restrict__ img, int64_t rowStride, int colc, const Win e, RowsN<T, NR> &r)
 {
     const T *p = img + (int64_t)e.s0 * rowStride + colc;
-    r.r0.template load<NT>(p);
-    r.r1.zero(); r.r2.zero(); r.r3.zero();
-    if (e.s0 + 1 <= e.s1) r.r1.template load<NT>(p + rowStride);
-    if (e.s0 + 2 <= e.s1) r.r2.template load<NT>(p + 2 * rowStride);
-    if (e.s0 + 3 <= e.s1) r.r3.template load<NT>(p + 3 * rowStride);
+    r.r[0].template load<NT>(p);
+#pragma unroll
+    for (int k = 1; k < NR; ++k) {
+        r.r[k].zero();
+        if (e.s0 + k <= e.s1) r.r[k].template load<NT>(p + k * rowStride);      // (wave-uniform: rows past the window are not loaded)
+    }
 }
-template <typename T>
-__device__ __forceinline__ Cols finish_rows(const Rows4<T> &r, const Win e)
+template <typename T, int NR>
+__device__ __forceinline__ Cols finish_rows(const RowsN<T, NR> &r, const Win e)
 {
     Cols acc;
 #pragma unroll
     for (int i = 0; i < VEC; ++i) acc.v[i] = 0.f;
-    const int y = e.s0;
-    const float w0 = row_weight(e, y), w1 = row_weight(e, y + 1), w2 = row_weight(e, y + 2), w3 = row_weight(e, y + 3);
 #pragma unroll
-    for (int i = 0; i < VEC; ++i) {
-        acc.v[i] += w0 * r.r0.get(i);
-        acc.v[i] += w1 * r.r1.get(i);
-        acc.v[i] += w2 * r.r2.get(i);
-        acc.v[i] += w3 * r.r3.get(i);
+    for (int g = 0; g < NR; g += 4) {
+        // (vertical_pass stops after the group that holds the window's last row: groups past it add nothing there, and w x 0 here)
+        if (g > 0 && e.s0 + g > e.s1) break;
+        const int y = e.s0 + g;
+        const float w0 = row_weight(e, y), w1 = row_weight(e, y + 1), w2 = row_weight(e, y + 2), w3 = row_weight(e, y + 3);
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) {
+            acc.v[i] += w0 * r.r[g].get(i);
+            acc.v[i] += w1 * r.r[g + 1].get(i);
+            acc.v[i] += w2 * r.r[g + 2].get(i);
+            acc.v[i] += w3 * r.r[g + 3].get(i);
+        }
     }
     return acc;
 }
@@ -412,6 +418,45 @@ constexpr int kTileCols = 16;
 constexpr int kTilePitch = kTileCols + 1;              // odd pitch: the transposed reads hit 64 different banks
 constexpr int kTileWaveFloats = 64 * VEC + 8 + 256 * kTilePitch;
 
+// The output rows (columns of the tile) of one wave in a software pipeline kDepth deep: with 72 KiB of LDS per workgroup a SIMD
+// holds two waves, and a wave that waits for each output row's source rows before it asks for the next spends its life in load
+// latency (1:1 at 270 degrees: 2.6 TB/s so, 3.3 with the pipeline).  NR = source rows a window may have; taller ones: the plain path.
+template <bool NT, typename T, int NR, int kDepth, typename Finish>
+__device__ __forceinline__ void tile_columns(const T *__restrict__ img, int64_t rowStride, int colc, const AxisEntry *__restrict__ rowTab, int kb0, int nCols,
+                                             Finish &&finish_column)
+{
+    RowsN<T, NR> ring[kDepth];
+    Win wring[kDepth];
+    bool tall = false;
+#pragma unroll
+    for (int d = 0; d < kDepth; ++d) {
+        wring[d] = load_win(rowTab, kb0 + (d < nCols ? d : 0));
+        tall = tall || wring[d].s1 - wring[d].s0 >= NR;
+    }
+    for (int j = kDepth; j < nCols; ++j) { const Win e = load_win(rowTab, kb0 + j); tall = tall || e.s1 - e.s0 >= NR; }
+    if (tall) {
+        for (int j = 0; j < nCols; ++j) finish_column(j, vertical_pass<NT, T>(img, rowStride, colc, load_win(rowTab, kb0 + j)));
+        return;
+    }
+#pragma unroll
+    for (int d = 0; d < kDepth; ++d)
+        if (d < nCols) issue_rows<NT, T, NR>(img, rowStride, colc, wring[d], ring[d]);
+    for (int j0 = 0; j0 < nCols; j0 += kDepth) {
+#pragma unroll
+        for (int d = 0; d < kDepth; ++d) {
+            const int j = j0 + d;
+            if (j < nCols) {                                  // wave-uniform
+                const Cols v = finish_rows<T, NR>(ring[d], wring[d]);
+                if (j + kDepth < nCols) {                     // the slot's next output row: asked for before this one is parked
+                    wring[d] = load_win(rowTab, kb0 + j + kDepth);
+                    issue_rows<NT, T, NR>(img, rowStride, colc, wring[d], ring[d]);
+                }
+                finish_column(j, v);
+            }
+        }
+    }
+}
+
 // COOP: the four waves of a workgroup take ONE strip and four consecutive groups of 16 output rows, meet at a barrier and store
 // together -- lane = one of 64 consecutive dst x, read from the four waves' tiles: 256 contiguous bytes per dst row and store
 // instruction instead of four 64-byte segments.
@@ -451,16 +496,6 @@ __global__ __launch_bounds__(kWaves * 64) void aai_axis_tile_kernel(AxisLaunch a
     // The output rows of a tile in a software pipeline kDepth deep: with 72 KiB of LDS per workgroup a SIMD holds two waves, and a wave
     // that waits for each output row's source rows before it asks for the next spends its life in load latency (1:1 at 270 degrees:
     // 2.6 TB/s).  Windows here are at most four source rows tall (ratios below 2); a taller one takes the plain path.
-    constexpr int kDepth = 8;
-    Rows4<T> ring[kDepth];
-    Win wring[kDepth];
-    bool tall = false;
-#pragma unroll
-    for (int d = 0; d < kDepth; ++d) {
-        wring[d] = load_win(rowTab, kb0 + (d < nCols ? d : 0));
-        tall = tall || wring[d].s1 - wring[d].s0 >= 4;
-    }
-    for (int j = kDepth; j < nCols; ++j) { const Win e = load_win(rowTab, kb0 + j); tall = tall || e.s1 - e.s0 >= 4; }
     auto finish_column = [&](int j, const Cols &v) {
         __builtin_amdgcn_wave_barrier();
         park(line, lane, shift, v);
@@ -471,27 +506,10 @@ __global__ __launch_bounds__(kWaves * 64) void aai_axis_tile_kernel(AxisLaunch a
         if (nq > 2) tile[(lane + 128) * kTilePitch + j] = horizontal_pass(line, c2.s0 - st.x0, c2.s1 - c2.s0, c2.wF, c2.wM, c2.wL);
         if (nq > 3) tile[(lane + 192) * kTilePitch + j] = horizontal_pass(line, c3.s0 - st.x0, c3.s1 - c3.s0, c3.wF, c3.wM, c3.wL);
     };
-    if (tall) {
-        for (int j = 0; j < nCols; ++j) finish_column(j, vertical_pass<NT, T>(img, sv.rowStride, colc, load_win(rowTab, kb0 + j)));
-    } else {
-#pragma unroll
-        for (int d = 0; d < kDepth; ++d)
-            if (d < nCols) issue_rows<NT, T>(img, sv.rowStride, colc, wring[d], ring[d]);
-        for (int j0 = 0; j0 < nCols; j0 += kDepth) {
-#pragma unroll
-            for (int d = 0; d < kDepth; ++d) {
-                const int j = j0 + d;
-                if (j < nCols) {                                  // wave-uniform
-                    const Cols v = finish_rows<T>(ring[d], wring[d]);
-                    if (j + kDepth < nCols) {                     // the slot's next output row: asked for before this one is parked
-                        wring[d] = load_win(rowTab, kb0 + j + kDepth);
-                        issue_rows<NT, T>(img, sv.rowStride, colc, wring[d], ring[d]);
-                    }
-                    finish_column(j, v);
-                }
-            }
-        }
-    }
+    // windows of at most four source rows (ratios up to 3): eight output rows in flight; up to eight rows (ratios up to 4, where a
+    // strip still holds more than 64 outputs): four; anything taller takes the plain path
+    if (a.maxRowSpan <= 4) tile_columns<NT, T, 4, 8>(img, sv.rowStride, colc, rowTab, kb0, nCols, finish_column);
+    else tile_columns<NT, T, 8, 4>(img, sv.rowStride, colc, rowTab, kb0, nCols, finish_column);
     if (COOP) {
         __syncthreads();
         // lane = dst x within the workgroup's 64 output rows (kb), read from the tile of the wave that computed it; wave w stores
@@ -623,10 +641,10 @@ static hipError_t launch_axis_typed(const AxisLaunch &a, const T *src, ImageView
     // (measured, profiles/r01_axis_transposed.txt: wins below 2:1 -- 1:1 1.8 -> 2.3 TB/s, x4 up-sampling 1.2 -> 1.6 --
     // and loses 5-14 % to the four-column register path between 2:1 and 4:1)
     // ... and, since its output rows run in a software pipeline and its waves store together, down to 64 outputs per strip (ratios up
-    // to 4) wherever no output row needs more than the pipeline's four source rows (ratios up to 3): 3:1 at 270 degrees 300 -> 242 us
-    // per 4 images, 2.5:1 351 -> 271, 2:1 285 -> 275 (profiles/r03_axis_tile.txt)
+    // to 4) wherever no output row needs more than the pipeline's eight source rows: 3:1 at 270 degrees 300 -> 242 us per 4 images,
+    // 2.5:1 351 -> 271, 2:1 285 -> 275 (profiles/r03_axis_tile.txt)
     const bool tileable = a.transposed && a.tapStep <= 1 && (a.outStrideB == 1 || a.outStrideB == -1) && a.maxOutputsPerStrip <= 256;
-    int tile = tileable && (a.maxOutputsPerStrip > 128 || (a.maxOutputsPerStrip > 64 && a.maxRowSpan <= 4));
+    int tile = tileable && (a.maxOutputsPerStrip > 128 || (a.maxOutputsPerStrip > 64 && a.maxRowSpan <= 8));
     if (tune.tile == 0) tile = 0;
     if (tune.tile == 1) tile = tileable && a.maxOutputsPerStrip > 128;      // experiments: the round-1 rule and the independent-waves form
     if (tile && (a.nB + kTileCols - 1) / kTileCols <= 65535) {
