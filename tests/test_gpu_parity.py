@@ -1210,13 +1210,15 @@ def test_concurrent_host_threads(gpu):
 def test_sources_larger_than_4_gib(gpu, po):
     """A 33,000 x 33,000 fp32 source (4.36 GB: byte offsets from the image's first element no longer fit 32 bits) and, for
     K1, a 46,500 x 46,500 one (8.6 GB, 2.16 G elements: past 32-bit element offsets too): K1 streams them, the fp32
-    window kernels of the rotated requests take their 32-bit lane offsets from an anchor row per wave
-    (QuadMap::anchorRows), in every quadrant.  Sampled row bands against the CPU oracle's rows."""
+    window kernels of the rotated requests (one window per dst pixel, or a window in parts for wide footprints) take their 32-bit
+    lane offsets from an anchor row per wave (QuadMap::anchorRows), in every quadrant.  Sampled row bands against the CPU oracle's rows."""
     import torch
     st = torch.cuda.current_stream().cuda_stream
     for (W, H, cases) in ((33000, 33000, ((4.0, 1.0, 0.0, 1, po.MODE_EXACT), (3.0, 1.0, 17.5, 1, po.MODE_EXACT), (3.0, 1.0, 17.5, 2, po.MODE_FAST),
                                           (4.0, 1.0, 90.0, 1, po.MODE_EXACT), (3.0, 1.0, 107.5, 1, po.MODE_EXACT), (2.5, 1.0, 200.0, 2, po.MODE_FAST),
-                                          (3.0, 1.0, 290.0, 1, po.MODE_EXACT))),
+                                          (3.0, 1.0, 290.0, 1, po.MODE_EXACT),
+                                          # wide footprints: a dst pixel is 4 lanes, each with a part of the window
+                                          (8.0, 1.0, 17.5, 1, po.MODE_EXACT), (8.0, 1.0, 107.5, 2, po.MODE_FAST), (11.0, 1.0, 225.0, 1, po.MODE_EXACT))),
                           (46500, 46500, ((4.0, 1.0, 0.0, 1, po.MODE_EXACT), (5.0, 1.0, 180.0, 2, po.MODE_FAST)))):
         src = torch.empty((H, W), dtype=torch.float32, device="cuda")
         gpu.synth_device(src.data_ptr(), W, H, W, 11)
@@ -1227,7 +1229,7 @@ def test_sources_larger_than_4_gib(gpu, po):
             rc, msg, lay = gpu.query(rq)
             assert rc == 0, msg
             out = _device_run(gpu, rq, src)
-            assert ("quad" in gpu.last_kernel()) == (ang % 90.0 != 0.0), gpu.last_kernel()
+            assert any(t in gpu.last_kernel() for t in ("quad", "wide")) == (ang % 90.0 != 0.0), gpu.last_kernel()
             dH, dW = lay.dst_height, lay.dst_width
             for r0 in (0, dH // 3, dH // 2, dH - 8):
                 gold = po.oracle_rows(omode, host, sr, dr, iso, ang, r0, r0 + 8, dW)
