@@ -251,6 +251,10 @@ __device__ __forceinline__ SamplePoint sample_point(const RotLaunch &r, int dx, 
 
 // rows of dst pixels per wave (a wave = 64 consecutive dx): with one row per wave the kernel was bound by the latency of a
 // wave's life -- coordinates, two dependent loads, one store -- not by instructions or bytes
+// dst pixels are written once and never read back: around the caches (with whole lines per wave, below: config 5's
+// bilinear leg 1.01 -> 0.70 ms; either step alone: 0.89 / 1.03)
+__device__ __forceinline__ void sample_store(float *p, float v) { __builtin_nontemporal_store(v, p); }
+
 template <int MODE> struct SampleRows { static constexpr int value = MODE == AAI_MODE_BILINEAR ? 4 : 2; };      // (8 rows: 1.84 ms where 4 take 1.11)
 
 template <int MODE, typename T>
@@ -259,28 +263,44 @@ __global__ __launch_bounds__(kBlock) void aai_sample_kernel(RotLaunch r, const T
 {
     constexpr int R = SampleRows<MODE>::value;
     constexpr int N = MODE == AAI_MODE_BILINEAR ? 2 : 4, FIRST = MODE == AAI_MODE_BILINEAR ? 0 : -1;
-    const int dx = blockIdx.x * 64 + (threadIdx.x & 63);
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);    // wave-uniform: row addresses are scalar
     const int dy0 = r.dyBase + (blockIdx.y * 4 + wave) * R;
-    if (dx >= r.dW || dy0 >= r.dyEnd) return;
+    if (dy0 >= r.dyEnd) return;
     const int nRows = min(R, r.dyEnd - dy0);
     const T *img = src + (int64_t)blockIdx.z * sv.imageStride;
     const int chan = r.chan > 1 ? r.chan : 1;          // interleaved channels share the taps' positions and weights
     float *outRow0 = dst + (int64_t)blockIdx.z * dv.imageStride + (int64_t)(dy0 - r.dyBase) * dv.rowStride;
+    // A wave stores 64 consecutive pixels of a dst row.  Rows of a large output start at any multiple of 4 bytes, so
+    // columns [64 b, 64 b + 64) straddle three 128-byte lines of which two are shared with the neighbouring workgroups --
+    // which run on other XCDs, behind other L2s: 2.15 GB of config 5 went out at 2.3 TB/s whatever the kernel computed
+    // (no loads, fp32 coordinates: the same 0.94 ms).  Each row therefore shifts its columns left to the 256-byte boundary
+    // below them: every store of a wave is two whole lines (the grid has one more column of workgroups).
+    int dxs[R];
+    bool inRow[R];
+#pragma unroll
+    for (int j = 0; j < R; ++j) {
+        const int shift = chan == 1 ? (int)((reinterpret_cast<uintptr_t>(outRow0 + (int64_t)j * dv.rowStride) >> 2) & 63) : 0;
+        dxs[j] = (int)blockIdx.x * 64 + (int)(threadIdx.x & 63) - shift;
+        inRow[j] = j < nRows && dxs[j] >= 0 && dxs[j] < r.dW;
+    }
     if (live && chan == 1) {
-        // the 64 columns of this wave are four 16-column tiles of one tile row: all in a corner of the rotated canvas -> zeros
+        // the columns of this wave lie in the 16-column tiles 4 b - 4 ... 4 b + 3 of one tile row: all in a corner of the
+        // rotated canvas -> zeros
         const int first = live[2 * (dy0 >> 4)], last = live[2 * (dy0 >> 4) + 1];
-        if ((int)blockIdx.x * 4 + 3 < first || (int)blockIdx.x * 4 > last) {
-            for (int j = 0; j < nRows; ++j) outRow0[(int64_t)j * dv.rowStride + dx] = 0.f;
+        if ((int)blockIdx.x * 4 + 3 < first || (int)blockIdx.x * 4 - 4 > last) {
+#pragma unroll
+            for (int j = 0; j < R; ++j)
+                if (inRow[j]) sample_store(outRow0 + (int64_t)j * dv.rowStride + dxs[j], 0.f);
             return;
         }
     }
 
     SamplePoint pt[R];
-    bool whole = true;          // no tap column of this lane is clamped (or the point is outside: no taps at all)
+    bool whole = true;          // no tap column of this lane is clamped (or the point is outside / not in the row: no taps at all)
 #pragma unroll
     for (int j = 0; j < R; ++j) {
-        pt[j] = sample_point(r, dx, dy0 + (j < nRows ? j : 0));
+        pt[j] = sample_point(r, inRow[j] ? dxs[j] : 0, dy0 + (j < nRows ? j : 0));
+        if (!inRow[j]) pt[j].outside = true;
         whole = whole && (pt[j].outside || (pt[j].ix + FIRST >= 0 && pt[j].ix + FIRST + N <= r.W));
     }
     // The N taps of a tap row are neighbours in memory: one vector load per tap row instead of N scalar ones (neighbouring
@@ -324,14 +344,16 @@ __global__ __launch_bounds__(kBlock) void aai_sample_kernel(RotLaunch r, const T
                     v = fmaf(wy[k], row, v);
                 }
             }
-            if (j < nRows) outRow0[(int64_t)j * dv.rowStride + dx] = pt[j].outside ? 0.f : v;
+            if (inRow[j]) sample_store(outRow0 + (int64_t)j * dv.rowStride + dxs[j], pt[j].outside ? 0.f : v);
         }
         return;
     }
     // the general path, row by row: clamp-to-edge taps, typed sources, interleaved channels
-    for (int j = 0; j < nRows; ++j) {
+#pragma unroll
+    for (int j = 0; j < R; ++j) {
+        if (!inRow[j]) continue;
         const SamplePoint p = pt[j];
-        float *out = outRow0 + (int64_t)j * dv.rowStride + (int64_t)dx * chan;
+        float *out = outRow0 + (int64_t)j * dv.rowStride + (int64_t)dxs[j] * chan;
         if (p.outside) {
             for (int c = 0; c < chan; ++c) out[c] = 0.f;
             continue;
@@ -431,7 +453,7 @@ static hipError_t launch_rotated_band(const RotLaunch &r, const QuadMap &m, cons
 {
     if (r.mode == AAI_MODE_BILINEAR || r.mode == AAI_MODE_BICUBIC) {
         const int tileRows = 4 * (r.mode == AAI_MODE_BILINEAR ? SampleRows<AAI_MODE_BILINEAR>::value : SampleRows<AAI_MODE_BICUBIC>::value);
-        dim3 grid((r.dW + 63) / 64, (r.dyEnd - r.dyBase + tileRows - 1) / tileRows, batch);
+        dim3 grid((r.dW + 63) / 64 + (r.chan > 1 ? 0 : 1), (r.dyEnd - r.dyBase + tileRows - 1) / tileRows, batch);    // (+1: rows shift their columns left to a 256-byte boundary)
         if (r.mode == AAI_MODE_BILINEAR) {
             if (kernelName) *kernelName = "aai_sample_kernel<bilinear>";
             hipLaunchKernelGGL((aai_sample_kernel<AAI_MODE_BILINEAR, T>), grid, dim3(kBlock), 0, stream, r, src, sv, dst, dv, flags.live);

@@ -21,6 +21,7 @@
 // Kernels: aai_quad_kernel (plain images), aai_quad_multi_kernel (2..4 interleaved channels, packed LDS slots),
 // aai_quad_fast_kernel (fast mode: window in registers, no LDS), aai_quad_scan_kernel (the plan's scan for all three),
 // aai_flag_list_kernel (flag words -> pixel list).
+#include <cstdlib>
 #include "aai_kernels.hpp"
 #include "aai_rot_quad.hpp"
 #include "aai_quad_src.hpp"
@@ -226,6 +227,53 @@ __global__ __launch_bounds__(kQuadBlock) void aai_quad_fast_kernel(RotLaunch r, 
     *out = value;
 }
 
+// K3 under replication (scale > 1: up-sampling), where the output is many times the source and the STORES set the time:
+// 2.15 GB of config 5 went out in 64-byte pieces (a 16 x 4 tile per wave) that start at any multiple of 4 bytes.  Here a wave
+// owns 64 consecutive pixels of a dst row, shifted left to the 256-byte boundary below them (two whole 128-byte lines per
+// store, written around the caches), and walks the four rows its wave of the 16 x 16 tile owns -- so the skip masks, the
+// live tile spans and the fix-up list keep their tiling.  Per-pixel arithmetic is untouched: results are identical.
+template <typename T, int WIN>
+__global__ __launch_bounds__(kQuadBlock) void aai_quad_fast_rows_kernel(RotLaunch r, QuadConsts<float> q, QuadMap m, const T *__restrict__ src, ImageView sv,
+                                                                       float *__restrict__ dst, ImageView dv, const unsigned long long *__restrict__ skipMasks,
+                                                                       const int *__restrict__ live, int tilesX)
+{
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tileRow = (int)blockIdx.y + r.dyBase / 16;
+    int first = 0, last = 0x7fffffff;
+    if (live) { first = live[2 * tileRow]; last = live[2 * tileRow + 1]; }
+    for (int j = 0; j < 4; ++j) {
+        const int dy = tileRow * 16 + wave * 4 + j;
+        if (dy >= r.dyEnd) break;                                     // (wave-uniform)
+        float *row = dst + (int64_t)blockIdx.z * dv.imageStride + (int64_t)(dy - r.dyBase) * dv.rowStride;
+        const int shift = (int)((reinterpret_cast<uintptr_t>(row) >> 2) & 63);
+        const int dx = (int)blockIdx.x * 64 + lane - shift;
+        if (dx < 0 || dx >= r.dW) continue;
+        const int tx = dx >> 4;
+        if (skipMasks) {
+            const unsigned long long mask = skipMasks[((size_t)tileRow * tilesX + tx) * (kQuadBlock / 64) + wave];
+            if ((mask >> ((j << 4) | (dx & 15))) & 1ull) continue;
+        }
+        float *out = row + dx;
+        // a tile in a corner of the rotated canvas: every pixel is 0 (rot_live_cols), no centre is computed
+        if (tx < first || tx > last) { __builtin_nontemporal_store(0.f, out); continue; }
+        double px, py;
+        pixel_centre(r, dx, dy, px, py);
+        const double cx = floor(px + 0.5), cy = floor(py + 0.5);
+        float value = 0.f;
+        if (cx > -16.0 && cx < (double)r.mW + 16.0 && cy > -16.0 && cy < (double)r.mH + 16.0) {
+            QuadSrc<T, WIN, true> s;
+            s.img = reinterpret_cast<const char *>(src + (int64_t)blockIdx.z * sv.imageStride + m.base);
+            s.m = &m; s.mW = r.mW; s.mH = r.mH; s.lds = nullptr; s.tid = tid;
+            float sum;
+            int count;
+            quad_fast_pixel<float, WIN, false>(q, (int)cx, (int)cy, px - cx, py - cy, r.mW, r.mH, s, sum, count);
+            value = count > 0 ? sum / (float)count : 0.f;                 // Source.cpp:905
+        }
+        __builtin_nontemporal_store(value, out);
+    }
+}
+
 // Interleaved channels: areas once per (dst, src) pair, applied to every channel (four accumulators).  Dynamic LDS:
 // WIN * WIN * words KiB per block.
 template <typename T, int WIN, bool SCALED, int WORDS>
@@ -319,13 +367,24 @@ __global__ __launch_bounds__(256) void aai_flag_list_kernel(const unsigned long 
     }
 }
 
+// AAI_FAST_ROWS=0: the 16 x 4 wave also under replication (A/B switch of tools/)
+static bool quad_fast_rows_enabled()
+{
+    static const bool on = [] { const char *e = getenv("AAI_FAST_ROWS"); return !(e && e[0] == '0'); }();
+    return on;
+}
+
 template <typename T, int WIN>
 hipError_t launch_quad_win(const RotLaunch &r, const QuadConsts<float> &q, const QuadMap &m, const T *src, ImageView sv, float *dst, ImageView dv,
                            int batch, const unsigned long long *skipMasks, hipStream_t stream, const int *live)
 {
     const dim3 grid((r.dW + 15) / 16, (r.dyEnd - r.dyBase + 15) / 16, batch);      // at most 65535 tile rows: the caller bands taller outputs
     if (r.mode == AAI_MODE_FAST) {
-        if (m.scale > 1) hipLaunchKernelGGL((aai_quad_fast_kernel<T, WIN, true>), grid, dim3(kQuadBlock), 0, stream, r, q, m, src, sv, dst, dv, skipMasks, live);
+        if (m.scale > 1 && m.anchorRows == 0 && quad_fast_rows_enabled()) {
+            // (images of 4 GiB and more keep the 16 x 4 wave: their anchor rows are sized for it)
+            const dim3 rows((r.dW + 63) / 64 + 1, grid.y, batch);
+            hipLaunchKernelGGL((aai_quad_fast_rows_kernel<T, WIN>), rows, dim3(kQuadBlock), 0, stream, r, q, m, src, sv, dst, dv, skipMasks, live, (int)grid.x);
+        } else if (m.scale > 1) hipLaunchKernelGGL((aai_quad_fast_kernel<T, WIN, true>), grid, dim3(kQuadBlock), 0, stream, r, q, m, src, sv, dst, dv, skipMasks, live);
         else hipLaunchKernelGGL((aai_quad_fast_kernel<T, WIN, false>), grid, dim3(kQuadBlock), 0, stream, r, q, m, src, sv, dst, dv, skipMasks, live);
         return hipGetLastError();
     }
