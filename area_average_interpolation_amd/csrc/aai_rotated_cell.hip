@@ -149,7 +149,8 @@ __global__ __launch_bounds__(kQuadBlock, cell_min_waves(WIN)) void aai_cell_kern
         },
         [&](int px, int py, float A, float VA, int, bool skip) {
             if (skip) return;                                  // a pixel the plan's scans left to the fix-up pass is not written here
-            image[(int64_t)(py - r.dyBase) * dv.rowStride + px] = A > 0.f ? VA / A : 0.f;         // Source.cpp:577
+            // (written once, never read back: around the caches -- 1 % at configs 3 and 5)
+            __builtin_nontemporal_store(A > 0.f ? VA / A : 0.f, image + ((int64_t)(py - r.dyBase) * dv.rowStride + px));         // Source.cpp:577
         });
 }
 
