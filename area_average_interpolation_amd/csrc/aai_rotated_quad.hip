@@ -227,12 +227,12 @@ __global__ __launch_bounds__(kQuadBlock) void aai_quad_fast_kernel(RotLaunch r, 
     *out = value;
 }
 
-// K3 under replication (scale > 1: up-sampling), where the output is many times the source and the STORES set the time:
+// K3 for outputs as large as their source or larger (replication = up-sampling, and ratios up to 1.6), where the STORES set the time:
 // 2.15 GB of config 5 went out in 64-byte pieces (a 16 x 4 tile per wave) that start at any multiple of 4 bytes.  Here a wave
 // owns 64 consecutive pixels of a dst row, shifted left to the 256-byte boundary below them (two whole 128-byte lines per
 // store, written around the caches), and walks the four rows its wave of the 16 x 16 tile owns -- so the skip masks, the
 // live tile spans and the fix-up list keep their tiling.  Per-pixel arithmetic is untouched: results are identical.
-template <typename T, int WIN>
+template <typename T, int WIN, bool SCALED>
 __global__ __launch_bounds__(kQuadBlock) void aai_quad_fast_rows_kernel(RotLaunch r, QuadConsts<float> q, QuadMap m, const T *__restrict__ src, ImageView sv,
                                                                        float *__restrict__ dst, ImageView dv, const unsigned long long *__restrict__ skipMasks,
                                                                        const int *__restrict__ live, int tilesX)
@@ -262,7 +262,7 @@ __global__ __launch_bounds__(kQuadBlock) void aai_quad_fast_rows_kernel(RotLaunc
         const double cx = floor(px + 0.5), cy = floor(py + 0.5);
         float value = 0.f;
         if (cx > -16.0 && cx < (double)r.mW + 16.0 && cy > -16.0 && cy < (double)r.mH + 16.0) {
-            QuadSrc<T, WIN, true> s;
+            QuadSrc<T, WIN, SCALED> s;
             s.img = reinterpret_cast<const char *>(src + (int64_t)blockIdx.z * sv.imageStride + m.base);
             s.m = &m; s.mW = r.mW; s.mH = r.mH; s.lds = nullptr; s.tid = tid;
             float sum;
@@ -367,11 +367,12 @@ __global__ __launch_bounds__(256) void aai_flag_list_kernel(const unsigned long 
     }
 }
 
-// AAI_FAST_ROWS=0: the 16 x 4 wave also under replication (A/B switch of tools/)
-static bool quad_fast_rows_enabled()
+// AAI_FAST_ROWS (A/B switch of tools/): 0 = always the 16 x 4 wave, 1 = row-shaped wave under replication and at ratios up to
+// 1.6 (default), 2 = row-shaped wave for every plain image below 4 GiB
+static int quad_fast_rows_mode()
 {
-    static const bool on = [] { const char *e = getenv("AAI_FAST_ROWS"); return !(e && e[0] == '0'); }();
-    return on;
+    static const int mode = [] { const char *e = getenv("AAI_FAST_ROWS"); return e && e[0] >= '0' && e[0] <= '2' ? e[0] - '0' : 1; }();
+    return mode;
 }
 
 template <typename T, int WIN>
@@ -380,10 +381,15 @@ hipError_t launch_quad_win(const RotLaunch &r, const QuadConsts<float> &q, const
 {
     const dim3 grid((r.dW + 15) / 16, (r.dyEnd - r.dyBase + 15) / 16, batch);      // at most 65535 tile rows: the caller bands taller outputs
     if (r.mode == AAI_MODE_FAST) {
-        if (m.scale > 1 && m.anchorRows == 0 && quad_fast_rows_enabled()) {
+        // ... and without replication while a dst pixel is at most 1.6 source pixels wide (1.5:1 at 17.5 degrees 237 -> 189 us, 1:1 at
+        // 45 degrees 480 -> 426; from 2:1 on the slanted line of source pixels a row-shaped wave reads costs more than its stores
+        // save: 2:1 at 45 degrees 148 -> 206 us, 3:1 at 17.5 degrees 100 -> 158) -- profiles/r03_store_paths.txt
+        const bool rowShaped = quad_fast_rows_mode() >= 2 || (quad_fast_rows_mode() == 1 && (m.scale > 1 || r.side <= 1.6));
+        if (rowShaped && m.anchorRows == 0) {
             // (images of 4 GiB and more keep the 16 x 4 wave: their anchor rows are sized for it)
             const dim3 rows((r.dW + 63) / 64 + 1, grid.y, batch);
-            hipLaunchKernelGGL((aai_quad_fast_rows_kernel<T, WIN>), rows, dim3(kQuadBlock), 0, stream, r, q, m, src, sv, dst, dv, skipMasks, live, (int)grid.x);
+            if (m.scale > 1) hipLaunchKernelGGL((aai_quad_fast_rows_kernel<T, WIN, true>), rows, dim3(kQuadBlock), 0, stream, r, q, m, src, sv, dst, dv, skipMasks, live, (int)grid.x);
+            else hipLaunchKernelGGL((aai_quad_fast_rows_kernel<T, WIN, false>), rows, dim3(kQuadBlock), 0, stream, r, q, m, src, sv, dst, dv, skipMasks, live, (int)grid.x);
         } else if (m.scale > 1) hipLaunchKernelGGL((aai_quad_fast_kernel<T, WIN, true>), grid, dim3(kQuadBlock), 0, stream, r, q, m, src, sv, dst, dv, skipMasks, live);
         else hipLaunchKernelGGL((aai_quad_fast_kernel<T, WIN, false>), grid, dim3(kQuadBlock), 0, stream, r, q, m, src, sv, dst, dv, skipMasks, live);
         return hipGetLastError();
