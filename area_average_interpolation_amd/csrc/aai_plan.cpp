@@ -177,6 +177,7 @@ RotLaunch make_rot_launch(const Geometry &g, int mode, int policy)
         const double u0 = g.fracX * g.side - g.isoX + g.offX, v0 = g.fracY * g.side - g.isoY + g.offY;
         const double Xa = g.side * g.cs, Xb = g.side * g.sn, X0 = u0 * g.cs + v0 * g.sn + g.isoX;
         const double Ya = -g.side * g.sn, Yb = g.side * g.cs, Y0 = -u0 * g.sn + v0 * g.cs + g.isoY;
+        r.cXa = Xa; r.cXb = Xb; r.cX0 = X0; r.cYa = Ya; r.cYb = Yb; r.cY0 = Y0;
         const double is = 1.0 / g.scale;
         // continuous virtual -> continuous original coordinates per quadrant, then (v + 1/2) / scale - 1/2
         double xa, xb, x0, ya, yb, y0;       // virtual-lattice combination that feeds source x / source y

@@ -55,6 +55,9 @@ struct RotLaunch {
     // affine in (dx, dy): sx = sAx dx + sBx dy + sCx, sy alike -- pixel_centre, the quadrant's pre-rotation
     // (Source.cpp:164-167) and the 1/scale of the replication composed once on the host in double precision
     double sAx, sBx, sCx, sAy, sBy, sCy;
+    // the fp32 window kernels (aai_rotated_quad.hip): the dst pixel centre in virtual-lattice coordinates as two fused
+    // multiply-adds per coordinate, X = cXa dx + cXb dy + cX0, Y alike (quad_centre)
+    double cXa, cXb, cX0, cYa, cYb, cY0;
 };
 
 // Decisions closer than this (in virtual-source pixels) to their threshold are "knife edges": the fast
@@ -261,6 +264,18 @@ AAI_HD void pixel_centre(const RotLaunch &r, int dx, int dy, double &px, double 
     const double v = (dy + r.fracY) * r.side - r.isoY + r.offY;
     px = u * r.cs + v * r.sn + r.isoX;
     py = -u * r.sn + v * r.cs + r.isoY;
+}
+
+// The same centre from host-composed coefficients: 4 fused multiply-adds instead of 14 additions and 6 products in double precision
+// (a sixth of the fast-mode window kernel's issue time at config 5).  It differs from pixel_centre -- the reference's own operation
+// order, which the double-precision kernels and the knife-edge scan keep -- by ~1e-12 virtual pixels; the kernels that use it work
+// in fp32 relative to the nearest lattice point and leave every decision closer than 3 eps_coord(fp32) to its threshold to the
+// double-precision pass, and their plan-time scans and CPU replays use this function too.
+AAI_HD void quad_centre(const RotLaunch &r, int dx, int dy, double &px, double &py)
+{
+    const double x = (double)dx, y = (double)dy;
+    px = fma(x, r.cXa, fma(y, r.cXb, r.cX0));
+    py = fma(x, r.cYa, fma(y, r.cYb, r.cY0));
 }
 
 // The dst columns of rows [ya, yb] whose centres lie within rho virtual pixels of the lattice's extent -- a superset, lo > hi: none.

@@ -172,7 +172,7 @@ __global__ __launch_bounds__(kQuadBlock, quad_waves_per_simd(WIN) - (HP && quad_
     }
 
     double px, py;
-    pixel_centre(r, dx, dy, px, py);
+    quad_centre(r, dx, dy, px, py);
     const double cx = floor(px + 0.5), cy = floor(py + 0.5);
     float value = 0.f;
     // a centre further than the window's reach from the lattice touches nothing (and stays inside int range)
@@ -212,7 +212,7 @@ __global__ __launch_bounds__(kQuadBlock) void aai_quad_fast_kernel(RotLaunch r, 
     }
 
     double px, py;
-    pixel_centre(r, dx, dy, px, py);
+    quad_centre(r, dx, dy, px, py);
     const double cx = floor(px + 0.5), cy = floor(py + 0.5);
     float value = 0.f;
     if (cx > -16.0 && cx < (double)r.mW + 16.0 && cy > -16.0 && cy < (double)r.mH + 16.0) {
@@ -258,7 +258,7 @@ __global__ __launch_bounds__(kQuadBlock) void aai_quad_fast_rows_kernel(RotLaunc
         // a tile in a corner of the rotated canvas: every pixel is 0 (rot_live_cols), no centre is computed
         if (tx < first || tx > last) { __builtin_nontemporal_store(0.f, out); continue; }
         double px, py;
-        pixel_centre(r, dx, dy, px, py);
+        quad_centre(r, dx, dy, px, py);
         const double cx = floor(px + 0.5), cy = floor(py + 0.5);
         float value = 0.f;
         if (cx > -16.0 && cx < (double)r.mW + 16.0 && cy > -16.0 && cy < (double)r.mH + 16.0) {
@@ -296,7 +296,7 @@ void aai_quad_multi_kernel(RotLaunch r, QuadConsts<float> q, QuadMap m, const T 
     float *out = dst + (int64_t)blockIdx.z * dv.imageStride + (int64_t)(dy - r.dyBase) * dv.rowStride + (int64_t)dx * chan;
 
     double px, py;
-    pixel_centre(r, dx, dy, px, py);
+    quad_centre(r, dx, dy, px, py);
     const double cx = floor(px + 0.5), cy = floor(py + 0.5);
     float value[kQuadMaxChan] = {0.f, 0.f, 0.f, 0.f};
     if (cx > -16.0 && cx < (double)r.mW + 16.0 && cy > -16.0 && cy < (double)r.mH + 16.0) {
@@ -329,7 +329,7 @@ __global__ __launch_bounds__(kQuadBlock) void aai_quad_scan_kernel(RotLaunch r, 
     bool uncertain = false;
     if (dx < r.dW && dy < r.dH) {
         double px, py;
-        pixel_centre(r, dx, dy, px, py);
+        quad_centre(r, dx, dy, px, py);
         const double cx = floor(px + 0.5), cy = floor(py + 0.5);
         if (cx > -16.0 && cx < (double)r.mW + 16.0 && cy > -16.0 && cy < (double)r.mH + 16.0) {
             NoSrc s;

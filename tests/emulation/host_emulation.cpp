@@ -441,6 +441,8 @@ static void emu_rotated(const Geometry &g, const aai_request &rq, const float *i
         for (int dx = 0; dx < r.dW; ++dx) {
             double px, py;
             pixel_centre(r, dx, dy, px, py);
+            double qx, qy;                       // the centre as the fp32 window kernels compute it (aai_rotated_quad.hip)
+            quad_centre(r, dx, dy, qx, qy);
             const double hb = r.h * (r.c + r.s);
             const int x0 = std::max(0, (int)std::floor(px - hb + 0.5 - AAI_KNIFE_GUARD)), x1 = std::min(r.mW - 1, (int)std::ceil(px + hb - 0.5 + AAI_KNIFE_GUARD));
             const int y0 = std::max(0, (int)std::floor(py - hb + 0.5 - AAI_KNIFE_GUARD)), y1 = std::min(r.mH - 1, (int)std::ceil(py + hb - 0.5 + AAI_KNIFE_GUARD));
@@ -471,13 +473,13 @@ static void emu_rotated(const Geometry &g, const aai_request &rq, const float *i
                     }
                 } else if (fastQuad) {
                     switch (qc.winFast) {
-                    case 2: done = emu_quad_fast_pixel<2>(qc, r, img, srcStride, px, py, value); break;
-                    case 3: done = emu_quad_fast_pixel<3>(qc, r, img, srcStride, px, py, value); break;
-                    case 4: done = emu_quad_fast_pixel<4>(qc, r, img, srcStride, px, py, value); break;
-                    case 5: done = emu_quad_fast_pixel<5>(qc, r, img, srcStride, px, py, value); break;
-                    case 6: done = emu_quad_fast_pixel<6>(qc, r, img, srcStride, px, py, value); break;
-                    case 7: done = emu_quad_fast_pixel<7>(qc, r, img, srcStride, px, py, value); break;
-                    default: done = emu_quad_fast_pixel<8>(qc, r, img, srcStride, px, py, value); break;
+                    case 2: done = emu_quad_fast_pixel<2>(qc, r, img, srcStride, qx, qy, value); break;
+                    case 3: done = emu_quad_fast_pixel<3>(qc, r, img, srcStride, qx, qy, value); break;
+                    case 4: done = emu_quad_fast_pixel<4>(qc, r, img, srcStride, qx, qy, value); break;
+                    case 5: done = emu_quad_fast_pixel<5>(qc, r, img, srcStride, qx, qy, value); break;
+                    case 6: done = emu_quad_fast_pixel<6>(qc, r, img, srcStride, qx, qy, value); break;
+                    case 7: done = emu_quad_fast_pixel<7>(qc, r, img, srcStride, qx, qy, value); break;
+                    default: done = emu_quad_fast_pixel<8>(qc, r, img, srcStride, qx, qy, value); break;
                     }
                 } else if (r.wide) {
                     switch (qc.win) {
@@ -488,12 +490,12 @@ static void emu_rotated(const Geometry &g, const aai_request &rq, const float *i
                     }
                 } else {
                     switch (qc.win) {
-                    case 3: done = emu_quad_pixel<3>(qc, r, img, srcStride, px, py, value); break;
-                    case 4: done = emu_quad_pixel<4>(qc, r, img, srcStride, px, py, value); break;
-                    case 5: done = emu_quad_pixel<5>(qc, r, img, srcStride, px, py, value); break;
-                    case 6: done = emu_quad_pixel<6>(qc, r, img, srcStride, px, py, value); break;
-                    case 7: done = emu_quad_pixel<7>(qc, r, img, srcStride, px, py, value); break;
-                    default: done = emu_quad_pixel<8>(qc, r, img, srcStride, px, py, value); break;
+                    case 3: done = emu_quad_pixel<3>(qc, r, img, srcStride, qx, qy, value); break;
+                    case 4: done = emu_quad_pixel<4>(qc, r, img, srcStride, qx, qy, value); break;
+                    case 5: done = emu_quad_pixel<5>(qc, r, img, srcStride, qx, qy, value); break;
+                    case 6: done = emu_quad_pixel<6>(qc, r, img, srcStride, qx, qy, value); break;
+                    case 7: done = emu_quad_pixel<7>(qc, r, img, srcStride, qx, qy, value); break;
+                    default: done = emu_quad_pixel<8>(qc, r, img, srcStride, qx, qy, value); break;
                     }
                 }
                 if (done) { *out = value; ++g_quadPixels; continue; }
@@ -680,7 +682,7 @@ int aai_emu_quad_slot_debug(const aai_request *rq, int dx, int dy, double *f32ar
     Geometry g; std::string msg;
     if (make_geometry(*rq, g, msg) != AAI_OK) return -1;
     const RotLaunch r = make_rot_launch(g, AAI_MODE_AREA, rq->policy);
-    double px, py; pixel_centre(r, dx, dy, px, py);
+    double px, py; quad_centre(r, dx, dy, px, py);
     const QuadConsts<float> q = make_quad_consts<float>(r.side, r.c, r.s, r.policy, r.scale);
     switch (q.win) {
     case 3: emu_quad_slot_areas<float, 3>(r, px, py, f32areas); emu_quad_slot_areas<double, 3>(r, px, py, f64areas); break;
@@ -939,7 +941,7 @@ int aai_emu_quad_pixel_debug(const aai_request *rq, int dx, int dy, const float 
     Geometry g; std::string msg;
     if (make_geometry(*rq, g, msg) != AAI_OK) return -1;
     const RotLaunch r = make_rot_launch(g, AAI_MODE_AREA, rq->policy);
-    double px, py; pixel_centre(r, dx, dy, px, py);
+    double px, py; quad_centre(r, dx, dy, px, py);
     const QuadConsts<float> q = make_quad_consts<float>(r.side, r.c, r.s, r.policy, r.scale);
     switch (q.win) {
     case 3: emu_quad_sums<float, 3>(r, img, px, py, out4 + 0, out4 + 1); emu_quad_sums<double, 3>(r, img, px, py, out4 + 2, out4 + 3); break;
