@@ -319,20 +319,21 @@ AAI_HD bool cell_eval(const QuadConsts<F> &q, const CellConsts<F> &z, int Zx, in
 // depends on the column only (once per lane and strip) and the step down the rows (two fused multiply-adds): the kernel, its
 // scan and the CPU replay all come through here, so they agree to the last bit.  (Source.cpp:212-219 up to rounding ~1e-12.)
 struct CellColumn { double bx, by; };
+// The zone centre of cell (dx, dy) is affine in (dx, dy) (RotLaunch::cXa ... cY0, the coefficients of quad_centre, plus the zone's
+// offset): the column's part once per wave, two fused multiply-adds per row
 template <typename F>
 AAI_HD CellColumn cell_column(const RotLaunch &r, const CellConsts<F> &z, int dx)
 {
-    const double u = (dx + r.fracX) * r.side - r.isoX + r.offX;
     CellColumn col;
-    col.bx = (u * r.cs + r.isoX) + z.zx;
-    col.by = (-u * r.sn + r.isoY) + z.zy;
+    col.bx = qfma((double)dx, r.cXa, r.cX0 + z.zx);
+    col.by = qfma((double)dx, r.cYa, r.cY0 + z.zy);
     return col;
 }
 // false: so far from the lattice that the cell touches nothing (and the integers below would leave int range)
 AAI_HD bool cell_anchor(const RotLaunch &r, const CellColumn &col, int dy, int &Zx, int &Zy, double &dfx, double &dfy)
 {
-    const double v = (dy + r.fracY) * r.side - r.isoY + r.offY;
-    const double zx = qfma(v, r.sn, col.bx), zy = qfma(v, r.cs, col.by);
+    const double v = (double)dy;
+    const double zx = qfma(v, r.cXb, col.bx), zy = qfma(v, r.cYb, col.by);
     const double cx = floor(zx + 0.5), cy = floor(zy + 0.5);
     if (!(cx > -16.0 && cx < (double)r.mW + 16.0 && cy > -16.0 && cy < (double)r.mH + 16.0)) return false;
     Zx = (int)cx; Zy = (int)cy; dfx = zx - cx; dfy = zy - cy;
