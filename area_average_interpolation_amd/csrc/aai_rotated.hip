@@ -249,12 +249,12 @@ __device__ __forceinline__ SamplePoint sample_point(const RotLaunch &r, int dx, 
     return p;
 }
 
-// rows of dst pixels per wave (a wave = 64 consecutive dx): with one row per wave the kernel was bound by the latency of a
-// wave's life -- coordinates, two dependent loads, one store -- not by instructions or bytes
 // dst pixels are written once and never read back: around the caches (with whole lines per wave, below: config 5's
 // bilinear leg 1.01 -> 0.70 ms; either step alone: 0.89 / 1.03)
 __device__ __forceinline__ void sample_store(float *p, float v) { __builtin_nontemporal_store(v, p); }
 
+// rows of dst pixels per wave (a wave = 64 consecutive dx): with one row per wave the kernel was bound by the latency of a
+// wave's life -- coordinates, two dependent loads, one store -- not by instructions or bytes
 template <int MODE> struct SampleRows { static constexpr int value = MODE == AAI_MODE_BILINEAR ? 4 : 2; };      // (8 rows: 1.84 ms where 4 take 1.11)
 
 template <int MODE, typename T>
@@ -355,7 +355,7 @@ __global__ __launch_bounds__(kBlock) void aai_sample_kernel(RotLaunch r, const T
         const SamplePoint p = pt[j];
         float *out = outRow0 + (int64_t)j * dv.rowStride + (int64_t)dxs[j] * chan;
         if (p.outside) {
-            for (int c = 0; c < chan; ++c) out[c] = 0.f;
+            for (int c = 0; c < chan; ++c) sample_store(out + c, 0.f);
             continue;
         }
         int xo[N];
@@ -387,7 +387,7 @@ __global__ __launch_bounds__(kBlock) void aai_sample_kernel(RotLaunch r, const T
                 }
                 v = acc;
             }
-            out[c] = v;
+            sample_store(out + c, v);
         }
     }
 }
