@@ -328,6 +328,14 @@ static int build_plan(Plan &p)
                 // keep the masks: the fp32 kernel skips the flagged pixels and the fix-up pass runs beside it
                 p.dMasks = dMasks;
                 dMasks = nullptr;
+                // ... and asks for the per-pixel masks only in tiles that hold a flagged pixel: one bit per 16 x 16 tile
+                const unsigned tilesX = (unsigned)((g.dW + 15) / 16), tilesY = (unsigned)((g.dH + 15) / 16);
+                p.tileFlagWords = (int)aai::tile_flag_row_words(tilesX);
+                const size_t bytes = (size_t)tilesY * (size_t)p.tileFlagWords * sizeof(unsigned);
+                e = hipMalloc((void **)&p.dTileFlags, bytes);
+                if (e == hipSuccess) e = hipMemsetAsync(p.dTileFlags, 0, bytes, bs);
+                if (e == hipSuccess) e = aai::launch_tile_flags(p.dMasks, tilesX, tilesY, p.dTileFlags, bs);
+                if (e == hipSuccess) e = hipStreamSynchronize(bs);
                 for (int k = 0; k < Plan::kSideSlots && e == hipSuccess; ++k) {
                     e = hipStreamCreateWithFlags(&p.side[k], hipStreamNonBlocking);
                     if (e == hipSuccess) e = hipEventCreateWithFlags(&p.fork[k], hipEventDisableTiming);
@@ -493,7 +501,7 @@ int enqueue(const aai_request &rq, int batch, const void *dSrc, int srcType, int
         aai::RotFlags flags;
         flags.list = p->dList; flags.count = p->flaggedPixels; flags.dense = p->dense;
         const unsigned slot = p->nextSide++ % Plan::kSideSlots;      // (under p->launch)
-        flags.masks = p->dMasks; flags.live = p->dLive; flags.side = p->side[slot]; flags.fork = p->fork[slot]; flags.join = p->join[slot]; flags.form = p->form;
+        flags.masks = p->dMasks; flags.tileFlags = p->dTileFlags; flags.tileFlagWords = p->tileFlagWords; flags.live = p->dLive; flags.side = p->side[slot]; flags.fork = p->fork[slot]; flags.join = p->join[slot]; flags.form = p->form;
         e = hipSuccess;
         for (int b0 = 0; b0 < batch && e == hipSuccess; b0 += kMaxGridZ)
             e = aai::launch_rotated(r, qm, src_at(dSrc, srcType, (int64_t)b0 * srcImageStride), srcType, sv, dDst + (int64_t)b0 * dstImageStride, dv,

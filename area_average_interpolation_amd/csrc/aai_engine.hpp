@@ -49,6 +49,8 @@ struct Plan {
     bool dense = false;
     // fp32 rotated kernels: the lane masks of the flagged pixels (they skip them) and the side stream the fix-up pass runs on
     unsigned long long *dMasks = nullptr;
+    unsigned *dTileFlags = nullptr;  // one bit per 16 x 16 tile with a flagged pixel (aai::launch_tile_flags), tileFlagWords words per tile row
+    int tileFlagWords = 0;
     int *dLive = nullptr;            // per-pixel kernels on a rotated canvas: live tile span per tile row (aai::rotated_live_spans), or none
     // (kSideSlots of them, dealt round-robin per call under `launch`: the fix-up passes of callers on different streams run beside
     // each other instead of queueing on one stream)
@@ -72,6 +74,7 @@ struct Plan {
             if (join[k]) (void)hipEventDestroy(join[k]);
         }
         if (dMasks) (void)hipFree(dMasks);
+        if (dTileFlags) (void)hipFree(dTileFlags);
         if (dLive) (void)hipFree(dLive);
         if (dList) (void)hipFree(dList);
         if (dLane) (void)hipFree(dLane);

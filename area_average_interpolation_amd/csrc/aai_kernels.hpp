@@ -56,6 +56,8 @@ struct RotFlags {
     // FOLLOW it: it runs beside it on the plan's side stream (fork / join through two events), where its few,
     // latency-bound waves cost nothing instead of ~40 us behind the production pass.
     const unsigned long long *masks = nullptr;
+    const unsigned *tileFlags = nullptr;   // one bit per 16 x 16 tile that holds a flagged pixel (launch_tile_flags), tileFlagWords words per tile row
+    int tileFlagWords = 0;
     const int *live = nullptr;         // per 16-row tile row of the canvas: first and last 16-column tile that can hold a non-zero pixel (rotated_live_spans)
     int form = 0;                      // which fp32 formulation's scan produced the flags: ROT_FORM_QUAD or ROT_FORM_CELL (it serves the launch)
     hipStream_t side = nullptr;
@@ -71,6 +73,9 @@ void launch_rotated_fixup(const RotLaunch &r, int batch, const void *src, int sr
 // axis-aligned geometries (K1): dst pixels whose weights the separable model gets wrong (aai_axis_verify.hpp), same layout
 hipError_t launch_axis_verify(const RotLaunch &r, unsigned long long *laneMasks, unsigned *counter, hipStream_t stream);
 hipError_t launch_quad_scan(const RotLaunch &r, unsigned long long *laneMasks, unsigned *counter, hipStream_t stream);
+// one bit per 16 x 16 tile whose lane masks are not all zero: out[tileRow * rowWords + (tileX >> 5)] bit (tileX & 31); out zeroed by the caller
+inline unsigned tile_flag_row_words(unsigned tilesX) { return (tilesX + 31u) / 32u + 1u; }
+hipError_t launch_tile_flags(const unsigned long long *laneMasks, unsigned tilesX, unsigned tilesY, unsigned *out, hipStream_t stream);
 hipError_t launch_flag_list(const unsigned long long *laneMasks, size_t waves, unsigned tilesX, void *list, unsigned *cursor, unsigned capacity,
                             hipStream_t stream);
 hipError_t launch_rotated(const RotLaunch &r, const QuadMap &m, const void *src, int srcType, ImageView sv, float *dst, ImageView dv,

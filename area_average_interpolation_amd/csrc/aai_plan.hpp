@@ -71,7 +71,11 @@ struct QuadMap {
     // interleaved 8- / 16-bit pixels are fetched with one 4- / 8-byte load each, which may reach past the pixel: loads start
     // no later than lastLoad4 / lastLoad8 (byte offsets of the last 4 / 8 bytes of the image) and shift the rest away
     uint32_t lastLoad4, lastLoad8;
-    int anchorRows;              // set by the launcher for plain images of 4 GiB and more: offsets are relative to an anchor row per wave (QuadSrc::issue)
+    int anchorRows;              // set by the launcher for plain images of 4 GiB and more: offsets are relative to an anchor row per wave (QuadSrc::issue)    // set by the launcher when the kernel skips the pixels the plan's scans flagged: one bit per 16 x 16 dst tile, set where the tile holds
+    // a flagged pixel (tileFlagWords 32-bit words per tile row, one more than the tiles need: a wave reads two words at once), so that
+    // a wave of the cell kernel asks for the per-pixel masks only where there is something to find; NULL = no summary
+    const unsigned *tileFlags;
+    int tileFlagWords;
 };
 QuadMap make_quad_map(const Geometry &g, int64_t rowStride, int srcRow0, int channels = 1, int elementBytes = 4);      // channels: elements per pixel (interleaved)
 

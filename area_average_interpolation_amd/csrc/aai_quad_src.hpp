@@ -24,6 +24,14 @@ __device__ __forceinline__ void load_line(const float *p, float (&seg)[N])
     else if (N - at == 1) seg[at] = p[at];
 }
 
+// does any of the 16 x 16 tiles [tx0, tx0 + n) (n <= 32) of tile row `tileRow` hold a flagged pixel?  Wave-uniform arguments: scalar loads
+__device__ __forceinline__ bool tiles_flagged(const unsigned *__restrict__ tileFlags, int rowWords, int tileRow, int tx0, int n)
+{
+    const unsigned *p = tileFlags + (size_t)tileRow * rowWords + (tx0 >> 5);
+    const unsigned long long both = ((unsigned long long)p[1] << 32) | p[0];
+    return ((both >> (tx0 & 31)) & ((1ull << n) - 1ull)) != 0;
+}
+
 // The staged window of one lane.  Offsets are unsigned bytes from the image's first element (QuadMap: non-negative
 // strides), one table per axis; positions outside the lattice are clamped onto it -- their values are fetched but
 // never read (quad_pixel only reads slots whose valid bit is set).

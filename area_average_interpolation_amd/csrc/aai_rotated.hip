@@ -561,7 +561,10 @@ static hipError_t launch_rotated_typed(const RotLaunch &r, const QuadMap &m, con
         rb.dyEnd = r.dyEnd - y0 > maxRows ? y0 + maxRows : r.dyEnd;
         RotFlags fb = flags;
         if (!beside) fb.masks = nullptr;
-        e = launch_rotated_band(rb, m, src, srcType, sv, dst + (int64_t)(y0 - r.dyBase) * dv.rowStride, dv, batch, fb, stream, kernelName);
+        QuadMap mb = m;
+        mb.tileFlags = fb.masks ? flags.tileFlags : nullptr;
+        mb.tileFlagWords = flags.tileFlagWords;
+        e = launch_rotated_band(rb, mb, src, srcType, sv, dst + (int64_t)(y0 - r.dyBase) * dv.rowStride, dv, batch, fb, stream, kernelName);
     }
     if (beside) {
         // whatever happened above, the side stream's writes to dst are ordered before anything the caller enqueues next

@@ -132,10 +132,17 @@ __global__ __launch_bounds__(kQuadBlock, cell_min_waves(WIN)) void aai_cell_kern
     const CellColumn col = cell_column(r, z, x0 + (lane & (TW - 1)));
     int liveLo, liveHi;
     cell_live_rows(r, z, x0, x0 + TW - 1, liveLo, liveHi);     // wave-uniform
+    // per-pixel masks only where a 16 x 16 tile this strip touches holds a flagged pixel (QuadMap::tileFlags; wave-uniform, scalar loads)
+    const unsigned long long *masks = skipMasks;
+    if (masks && m.tileFlags && TW == 64) {
+        bool any = false;
+        for (int tr = y0 >> 4; tr <= (y1 - 1) >> 4; ++tr) any = any || tiles_flagged(m.tileFlags, m.tileFlagWords, tr, x0 >> 4, 5);
+        if (!any) masks = nullptr;
+    }
     cell_walk<TW>(r.dW, x0, y0, y1, liveLo, liveHi, lane,
         [&](int px, int py, bool wanted) -> bool {
             // is the pixel one the plan's scans left to the fix-up pass?  (requested here, used after the cell is evaluated)
-            return skipMasks && wanted && ((skipMasks[flag_word(px, py, tilesX)] >> flag_bit(px, py)) & 1ull);
+            return masks && wanted && ((masks[flag_word(px, py, tilesX)] >> flag_bit(px, py)) & 1ull);
         },
         [&](int cx, int cy, float (&sA)[4], float (&sVA)[4]) -> bool {
             int Zx, Zy;

@@ -21,6 +21,7 @@
 // Kernels: aai_quad_kernel (plain images), aai_quad_multi_kernel (2..4 interleaved channels, packed LDS slots),
 // aai_quad_fast_kernel (fast mode: window in registers, no LDS), aai_quad_scan_kernel (the plan's scan for all three),
 // aai_flag_list_kernel (flag words -> pixel list).
+#include <algorithm>
 #include <cstdlib>
 #include "aai_kernels.hpp"
 #include "aai_rot_quad.hpp"
@@ -375,6 +376,19 @@ static int quad_fast_rows_mode()
     return mode;
 }
 
+// summary of the lane masks: one bit per 16 x 16 tile that holds a flagged pixel (QuadMap::tileFlags)
+__global__ __launch_bounds__(256) void aai_tile_flags_kernel(const unsigned long long *__restrict__ laneMasks, unsigned tilesX, unsigned tilesY, unsigned rowWords,
+                                                            unsigned *__restrict__ out)
+{
+    const size_t tiles = (size_t)tilesX * tilesY;
+    for (size_t t = (size_t)blockIdx.x * 256 + threadIdx.x; t < tiles; t += (size_t)gridDim.x * 256) {
+        if (laneMasks[4 * t] | laneMasks[4 * t + 1] | laneMasks[4 * t + 2] | laneMasks[4 * t + 3]) {
+            const unsigned tx = (unsigned)(t % tilesX), ty = (unsigned)(t / tilesX);
+            atomicOr(out + (size_t)ty * rowWords + (tx >> 5), 1u << (tx & 31u));
+        }
+    }
+}
+
 template <typename T, int WIN>
 hipError_t launch_quad_win(const RotLaunch &r, const QuadConsts<float> &q, const QuadMap &m, const T *src, ImageView sv, float *dst, ImageView dv,
                            int batch, const unsigned long long *skipMasks, hipStream_t stream, const int *live)
@@ -533,6 +547,15 @@ hipError_t launch_quad_scan(const RotLaunch &r, unsigned long long *laneMasks, u
         if (e != hipSuccess) return e;
     }
     return hipSuccess;
+}
+
+hipError_t launch_tile_flags(const unsigned long long *laneMasks, unsigned tilesX, unsigned tilesY, unsigned *out, hipStream_t stream)
+{
+    const size_t tiles = (size_t)tilesX * tilesY;
+    if (!tiles) return hipSuccess;
+    const unsigned blocks = (unsigned)std::min<size_t>((tiles + 255) / 256, 65536);
+    hipLaunchKernelGGL(aai_tile_flags_kernel, dim3(blocks), dim3(256), 0, stream, laneMasks, tilesX, tilesY, tile_flag_row_words(tilesX), out);
+    return hipGetLastError();
 }
 
 hipError_t launch_flag_list(const unsigned long long *laneMasks, size_t waves, unsigned tilesX, void *list, unsigned *cursor, unsigned capacity,
