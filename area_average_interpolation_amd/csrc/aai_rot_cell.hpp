@@ -335,7 +335,9 @@ AAI_HD bool cell_anchor(const RotLaunch &r, const CellColumn &col, int dy, int &
     const double v = (double)dy;
     const double zx = qfma(v, r.cXb, col.bx), zy = qfma(v, r.cYb, col.by);
     const double cx = floor(zx + 0.5), cy = floor(zy + 0.5);
-    if (!(cx > -16.0 && cx < (double)r.mW + 16.0 && cy > -16.0 && cy < (double)r.mH + 16.0)) return false;
+    // (one test, not four nested ones: the kernel evaluates this in every row, and short-circuit branches cost more than the compares)
+    const bool inReach = (cx > -16.0) & (cx < (double)r.mW + 16.0) & (cy > -16.0) & (cy < (double)r.mH + 16.0);
+    if (!inReach) return false;
     Zx = (int)cx; Zy = (int)cy; dfx = zx - cx; dfy = zy - cy;
     return true;
 }
