@@ -313,6 +313,14 @@ def debug_cell_min_waves(waves):
     lib.aai_debug_cell_min_waves(int(waves))
 
 
+def debug_skip_fixup(skip):
+    """tests only: True = the double-precision fix-up pass is not launched, flagged pixels keep the caller's bytes"""
+    lib = L.load()
+    lib.aai_debug_skip_fixup.restype = None
+    lib.aai_debug_skip_fixup.argtypes = [ctypes.c_int]
+    lib.aai_debug_skip_fixup(1 if skip else 0)
+
+
 def shutdown():
     """aai_shutdown: drop every cached plan now (optional; a process may simply exit)."""
     L.load().aai_shutdown()

@@ -304,6 +304,8 @@ int aai_shutdown(void)
 void aai_debug_axis_tune(const char *spec) { aai::set_axis_tune(spec); }
 /* tests only: the smallest output (in cell waves) the cell kernel takes; 0 = every output, < 0 = the default */
 void aai_debug_cell_min_waves(int waves) { aai::set_cell_min_waves(waves); }
+/* tests only: != 0: the double-precision fix-up pass is not launched -- the pixels the plan's scans flagged stay as the caller left them */
+void aai_debug_skip_fixup(int skip) { aai::set_skip_fixup(skip != 0); }
 
 const char *aai_debug_plan_shape(const aai_request *req)
 {

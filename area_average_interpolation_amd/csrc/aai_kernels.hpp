@@ -65,6 +65,7 @@ struct RotFlags {
 };
 enum RotForm { ROT_FORM_QUAD = 0, ROT_FORM_CELL = 1 };
 size_t rotated_flag_words(const RotLaunch &r);      // waves of the tiling = 64-bit words of the mask array
+void set_skip_fixup(bool skip);                      // tests only: leave the flagged pixels unwritten (aai_debug_skip_fixup)
 hipError_t launch_knife_scan(const RotLaunch &r, unsigned long long *laneMasks, unsigned *counter, hipStream_t stream);
 // the double-precision fix-up pass over a list of dst pixels (defined in aai_rotated_strict.hip);
 // pixelList == NULL: the whole image (grid as for the production pass, at most 65535 tile rows)

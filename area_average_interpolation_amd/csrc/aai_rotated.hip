@@ -515,6 +515,11 @@ static hipError_t launch_rotated_band(const RotLaunch &r, const QuadMap &m, cons
     return hipGetLastError();
 }
 
+// tests only (aai_debug_skip_fixup): the double-precision pass over the flagged pixels is not launched, so a dst buffer filled with a
+// sentinel shows exactly which pixels the production kernels leave alone
+static bool g_skipFixup = false;
+void set_skip_fixup(bool skip) { g_skipFixup = skip; }
+
 template <typename T>
 static hipError_t launch_rotated_typed(const RotLaunch &r, const QuadMap &m, const T *src, int srcType, ImageView sv, float *dst, ImageView dv,
                                        int batch, const RotFlags &flags, hipStream_t stream, const char **kernelName)
@@ -551,7 +556,7 @@ static hipError_t launch_rotated_typed(const RotLaunch &r, const QuadMap &m, con
         e = hipEventRecord(flags.fork, stream);
         if (e == hipSuccess) e = hipStreamWaitEvent(flags.side, flags.fork, 0);
         if (e != hipSuccess) return e;
-        launch_rotated_fixup(r, batch, src, srcType, sv, dst, dv, static_cast<const uint2 *>(flags.list), flags.count, flags.side);
+        if (!g_skipFixup) launch_rotated_fixup(r, batch, src, srcType, sv, dst, dv, static_cast<const uint2 *>(flags.list), flags.count, flags.side);
         e = hipEventRecord(flags.join, flags.side);
         if (e != hipSuccess) return e;           // (nothing was enqueued on the side stream after the fork that the caller could race with)
     }
@@ -572,7 +577,7 @@ static hipError_t launch_rotated_typed(const RotLaunch &r, const QuadMap &m, con
         return e != hipSuccess ? e : j;
     }
     if (e != hipSuccess) return e;
-    if (fixup) launch_rotated_fixup(r, batch, src, srcType, sv, dst, dv, static_cast<const uint2 *>(flags.list), flags.count, stream);
+    if (fixup && !g_skipFixup) launch_rotated_fixup(r, batch, src, srcType, sv, dst, dv, static_cast<const uint2 *>(flags.list), flags.count, stream);
     return hipGetLastError();
 }
 

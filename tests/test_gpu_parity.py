@@ -1289,3 +1289,55 @@ print("dense ok")
     env = dict(os.environ, AAI_MAX_LISTED_PIXELS="10")
     p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=600)
     assert p.returncode == 0 and "dense ok" in p.stdout, (p.stdout[-2000:], p.stderr[-3000:])
+
+
+@pytest.mark.gpu
+def test_production_kernels_leave_exactly_the_flagged_pixels_alone(gpu):
+    """The fp32 kernels skip the dst pixels the plan's scans flagged (the double-precision pass writes those, beside them on a side
+    stream): with that pass switched off (tests-only hook aai_debug_skip_fixup) a dst buffer filled with a sentinel must keep the
+    sentinel in exactly `flagged` pixels (aai_plan_info), and the normal call must differ from that run in exactly those pixels.
+    Every skipping kernel: cell (with its one-bit-per-tile summary of the masks: strips without a flagged tile never look at the
+    masks), quad, fast (16 x 4 and row-shaped waves), wide area / fast; plain fp32, up- and down-sampling."""
+    import re
+    import torch
+    SENTINEL = -7.0
+    st = torch.cuda.current_stream().cuda_stream
+    cases = [  # (W, H, srcRes, dstRes, angle, mode, kernel)
+        (2048, 2048, 8192.0, 2731.0, 17.5, 1, "aai_cell_kernel"), (512, 512, 1.0, 4.0, 45.0, 1, "aai_cell_kernel"), (1500, 1100, 1.0, 1.0, 30.0, 1, "aai_cell_kernel"),
+        (300, 260, 3.0, 1.0, 30.0, 1, "aai_quad_kernel"),
+        (2048, 2048, 8192.0, 2731.0, 17.5, 2, "aai_quad_fast_kernel"), (512, 512, 1.0, 4.0, 40.0, 2, "aai_quad_fast_kernel"), (1200, 1000, 1.5, 1.0, 30.0, 2, "aai_quad_fast_kernel"),
+        (512, 512, 1.0, 2.0, 45.0, 2, "aai_quad_fast_kernel"), (600, 600, 2.0, 1.0, 45.0, 2, "aai_quad_fast_kernel"), (512, 512, 1.0, 4.0, 45.0, 2, "aai_quad_fast_kernel"),
+        (2048, 2048, 8.0, 1.0, 17.5, 1, "aai_wide_kernel"), (2048, 2048, 8.0, 1.0, 17.5, 2, "aai_wide_fast_kernel"),
+    ]
+    exercised = set()
+    try:
+        for (W, H, sr, dr, ang, mode, kernel) in cases:
+            iso = ((W - 1) / 2.0, (H - 1) / 2.0)         # isocenter on the lattice: the symmetric geometry has knife-edge pixels at these angles
+            rq = gpu.make_request(W, H, sr, dr, iso, ang, mode=mode)
+            rc, msg, lay = gpu.query(rq)
+            assert rc == 0, msg
+            src = torch.rand((H, W), dtype=torch.float32, device="cuda") + 0.25
+            gpu.prepare(rq)
+            m = re.search(r"flagged=(\d+) dense=(\d+)", gpu.plan_shape(rq))
+            assert m, gpu.plan_shape(rq)
+            flagged, dense = int(m.group(1)), int(m.group(2))
+            assert dense == 0, (W, H, sr, dr, ang, mode, gpu.plan_shape(rq))
+            if flagged == 0:
+                continue                                   # (fast mode flags little: a centre has to lie within ~1e-7 of an edge)
+            full = torch.full((lay.dst_height, lay.dst_width), SENTINEL, dtype=torch.float32, device="cuda")
+            gpu.resample_device(rq, src.data_ptr(), W, full.data_ptr(), lay.dst_width, st)
+            torch.cuda.synchronize()
+            assert kernel in gpu.last_kernel(), (kernel, gpu.last_kernel())
+            assert int((full == SENTINEL).sum().item()) == 0
+            gpu.debug_skip_fixup(True)
+            holes = torch.full((lay.dst_height, lay.dst_width), SENTINEL, dtype=torch.float32, device="cuda")
+            gpu.resample_device(rq, src.data_ptr(), W, holes.data_ptr(), lay.dst_width, st)
+            torch.cuda.synchronize()
+            gpu.debug_skip_fixup(False)
+            left = holes == SENTINEL
+            assert int(left.sum().item()) == flagged, (kernel, W, H, sr, dr, ang, mode, int(left.sum().item()), flagged)
+            assert torch.equal(holes[~left], full[~left]), (kernel, W, H, sr, dr, ang, mode)
+            exercised.add(kernel)
+        assert {"aai_cell_kernel", "aai_quad_kernel", "aai_quad_fast_kernel"} <= exercised, exercised
+    finally:
+        gpu.debug_skip_fixup(False)
