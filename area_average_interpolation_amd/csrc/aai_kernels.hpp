@@ -7,7 +7,21 @@
 #include "aai_plan.hpp"
 #include "aai_rot_math.hpp"
 
+#include <cstdlib>
+
 namespace aai {
+
+// Launch heuristics can be overridden from the environment for experiments (tools/*_ab.sh) -- only in a build made with
+// `make EXTRA=-DAAI_EXPERIMENTS`: the shipping library never reads these variables.
+inline const char *experiment_env(const char *name)
+{
+#if defined(AAI_EXPERIMENTS)
+    return getenv(name);
+#else
+    (void)name;
+    return nullptr;
+#endif
+}
 
 // Image addressing shared by every kernel: element (x,y) of image b is base[b*imageStride + y*rowStride + x].
 // Source element types (AAI_DTYPE_* in include/aai.h).  Outputs are always fp32.
@@ -95,7 +109,6 @@ hipError_t launch_wide(const RotLaunch &r, const QuadMap &m, const void *src, in
 
 // the cell formulation (aai_rotated_cell.hip): one lane per cell of the dst grid, every (dst, src) pair evaluated once
 bool cell_can_serve(const RotLaunch &r, int srcType, ImageView sv);      // r.chan set; plain images below 4 GiB, area mode
-int cell_rows_per_strip(int dW, int rows, int batch, int tileWidth);
 void set_cell_min_waves(int waves);      // tests / experiments: outputs of fewer cell waves than this stay on the quad kernel (default 1024; < 0 restores it)
 hipError_t launch_cell_scan(const RotLaunch &r, unsigned long long *laneMasks, unsigned *counter, hipStream_t stream);
 hipError_t launch_cell(const RotLaunch &r, const QuadMap &m, const void *src, int srcType, ImageView sv, float *dst, ImageView dv,

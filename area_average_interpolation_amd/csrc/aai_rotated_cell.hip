@@ -31,18 +31,26 @@
 
 namespace aai {
 
+// dst rows a wave walks.  A workgroup of 4 waves pays 4 R + 1 cell rows for 4 R dst rows, so taller is cheaper -- as long as the
+// launch still has several waves for every SIMD of the chip (1024 SIMDs x ~6 wave slots)
+static int cell_rows_per_wave(int dW, int rows, int batch)
+{
+    const char *e = experiment_env("AAI_CELL_ROWS");
+    if (e && atoi(e) > 0) return atoi(e);
+    const int64_t strips = ((int64_t)dW + 62) / 63 * batch;
+    int R = 32;
+    while (R > 4 && strips * ((rows + R - 1) / R) < 24576) R >>= 1;
+    while ((rows + 4 * R - 1) / (4 * R) > 65535) R <<= 1;       // grid.y
+    return R;
+}
+
 namespace {
 
-// lane i <- lane i + 1 within a tile row of TW lanes (the row's last lane gets 0: it never stores): one DPP move
-// (wave_shl:1 across the wave, a gfx9 control; row_shl:1 within 16 lanes) instead of a round trip through the LDS crossbar
-template <int TW>
-__device__ __forceinline__ int from_next_lane_bits(int v)
-{
-    if (TW == 64) return __builtin_amdgcn_update_dpp(0, v, 0x130, 0xf, 0xf, false);      // wave_shl:1
-    return __builtin_amdgcn_update_dpp(0, v, 0x101, 0xf, 0xf, false);                     // row_shl:1 (rows of 16 lanes)
-}
-template <int TW> __device__ __forceinline__ float from_next_lane(float v) { return __int_as_float(from_next_lane_bits<TW>(__float_as_int(v))); }
-template <int TW> __device__ __forceinline__ int from_next_lane(int v) { return from_next_lane_bits<TW>(v); }
+// lane i <- lane i + 1 (the wave's last lane gets 0: it never stores): one DPP move (wave_shl:1, a gfx9 control) instead of a
+// round trip through the LDS crossbar
+__device__ __forceinline__ int from_next_lane_bits(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x130, 0xf, 0xf, false); }
+__device__ __forceinline__ float from_next_lane(float v) { return __int_as_float(from_next_lane_bits(__float_as_int(v))); }
+__device__ __forceinline__ int from_next_lane(int v) { return from_next_lane_bits(v); }
 
 // waves per SIMD the staged windows leave room for: WIN * WIN KiB of LDS per 256-lane block, 160 KiB per CU
 constexpr int cell_waves_per_simd(int win) { return 160 / (win * win) >= 8 ? 8 : 160 / (win * win); }
@@ -55,103 +63,117 @@ constexpr int cell_min_waves(int win) { return win <= 4 ? 6 : (cell_waves_per_si
 __device__ __forceinline__ size_t flag_word(int dx, int dy, int tilesX) { return ((size_t)(dy >> 4) * tilesX + (dx >> 4)) * 4 + ((dy & 15) >> 2); }
 __device__ __forceinline__ int flag_bit(int dx, int dy) { return ((dy & 3) << 4) | (dx & 15); }
 
-// The walk both kernels share.  Per iteration every lane evaluates one cell (eval(cx, cy, sA, sVA) -> this cell is
-// uncertain, SCAN only) and finishes at most one dst pixel: emit(px, py, A, VA, uncertain).  rowsPerStrip is a multiple of
-// TR = 64 / TW.
-// Cell rows outside [liveLo, liveHi] cannot touch the image (cell_live_rows): their iterations only finish the pixels waiting above.
+constexpr int kCellWaves = kQuadBlock / 64;          // waves of a workgroup: consecutive row segments of ONE strip of 63 dst columns
+
+// What the waves of a workgroup hand to the wave above them: the N / NW parts of their first cell row (which finish the last
+// dst row of the segment above), [wave][A, VA, uncertain][lane]
+struct CellHandoff { float a[kCellWaves][64], va[kCellWaves][64]; int u[kCellWaves][64]; };
+
+// The walk both kernels share.  A workgroup owns 63 dst columns x (kCellWaves x rowsPerWave) dst rows; wave w walks DOWN the
+// dst rows [y0, y1) of its segment: per iteration every lane evaluates one cell (eval(cx, cy, sA, sVA, upOnly) -> this cell is
+// uncertain, SCAN only) and finishes one dst pixel of the row above: emit(px, py, A, VA, uncertain, seen).  A segment of R dst rows
+// needs R + 1 cell rows; the extra one IS the first cell row of the segment below, so every wave parks the N / NW parts of its
+// first row in LDS (one barrier per workgroup, right after the first row) and only the workgroup's last segment (ownsBottom)
+// evaluates its bottom cell row itself -- 4 R + 1 cell rows per 4 R dst rows where one wave per strip paid R + 1 per R, and
+// waves that live a quarter as long at the same overhead (the drain of a launch is one wave's life).
+// Cell rows outside [liveLo, liveHi] cannot touch the image (cell_live_rows): they only finish the pixels waiting above.
 // look(px, py) runs at the top of the iteration that will finish pixel (px, py) and its result is handed to emit: whatever emit
 // needs from memory (the flag word of the pixel) is requested before the cell is evaluated, not waited for after it.
-template <int TW, typename Look, typename Eval, typename Emit>
-__device__ __forceinline__ void cell_walk(int dW, int x0, int y0, int y1, int liveLo, int liveHi, int lane, Look look, Eval eval, Emit emit)
+// Every wave of the workgroup must call this (the barrier), also with an empty segment (y0 >= y1).
+template <typename Look, typename Eval, typename Emit>
+__device__ __forceinline__ void cell_walk(int dW, int x0, int y0, int y1, bool ownsBottom, int wave, CellHandoff &hand, int liveLo, int liveHi, int lane,
+                                          Look look, Eval eval, Emit emit)
 {
-    constexpr int TR = 64 / TW;
-    const int lx = lane & (TW - 1), ly = lane / TW;
-    const int cx = x0 + lx;
-    const bool column = lx < TW - 1 && cx < dW;                 // this lane's column is one the wave completes
-    float carryA = 0.f, carryVA = 0.f;                           // own + W of the tile's last row, waiting for the next iteration
-    int carryU = 0;
-    for (int yb = y0; yb <= y1; yb += TR) {
-        const int cy = yb + ly;
-        // the pixel this lane finishes in this iteration (if any): the carried row for the tile's last row of lanes
-        const int py = ly == TR - 1 ? yb - 1 : cy;
-        const bool finishes = column && (ly == TR - 1 ? yb > y0 : cy < y1);
-        const auto seen = look(cx, finishes ? py : y0, finishes);
-        if (yb > liveHi || yb + TR - 1 < liveLo) {               // wave-uniform: every cell of this iteration misses the image
-            if (ly == TR - 1) {
-                if (finishes) emit(cx, py, carryA, carryVA, carryU, seen);
-                carryA = 0.f; carryVA = 0.f; carryU = 0;
-            } else if (finishes) emit(cx, py, 0.f, 0.f, 0, seen);
-            continue;
-        }
+    const int cx = x0 + lane;
+    const bool column = lane < 63 && cx < dW;                   // this lane's column is one the wave completes
+    float ownA = 0.f, ownVA = 0.f, belowA = 0.f, belowVA = 0.f;
+    int rowU = 0;
+    // one cell row: own + W of this row (own*), N + NW for the row above (below*)
+    auto row = [&](int cy, bool upOnly) {
+        ownA = 0.f; ownVA = 0.f; belowA = 0.f; belowVA = 0.f; rowU = 0;
+        if (cy > liveHi || cy < liveLo) return;                  // wave-uniform: every cell of this row misses the image
         float sA[4] = {0.f, 0.f, 0.f, 0.f}, sVA[4] = {0.f, 0.f, 0.f, 0.f};
         int unc = 0;
-        if (cx <= dW && cy <= y1) unc = eval(cx, cy, sA, sVA) ? 1 : 0;
-        const float ownA = sA[CELL_O] + from_next_lane<TW>(sA[CELL_W]), ownVA = sVA[CELL_O] + from_next_lane<TW>(sVA[CELL_W]);
-        const float belowA = sA[CELL_N] + from_next_lane<TW>(sA[CELL_NW]), belowVA = sVA[CELL_N] + from_next_lane<TW>(sVA[CELL_NW]);
-        const int rowU = unc | from_next_lane<TW>(unc);          // the two cells of this tile row that feed column cx
-        if (TR == 1) {
-            // the row above is finished by this iteration's N / NW parts
-            if (finishes) emit(cx, py, carryA + belowA, carryVA + belowVA, carryU | rowU, seen);
-            carryA = ownA; carryVA = ownVA; carryU = rowU;
-        } else {
-            // the tile's last row of the PREVIOUS iteration (held by the lanes of row TR - 1) is finished by this iteration's
-            // first row; every other row by the row below it in this tile
-            const int up = (lane + 64 - (TR - 1) * TW) & 63, down = (lane + TW) & 63;
-            const float topA = __shfl(belowA, up), topVA = __shfl(belowVA, up);
-            const int topU = __shfl(rowU, up);
-            const float nextA = __shfl(belowA, down), nextVA = __shfl(belowVA, down);
-            const int nextU = __shfl(rowU, down);
-            if (ly == TR - 1) {
-                if (finishes) emit(cx, py, carryA + topA, carryVA + topVA, carryU | topU, seen);
-                carryA = ownA; carryVA = ownVA; carryU = rowU;
-            } else if (finishes) emit(cx, py, ownA + nextA, ownVA + nextVA, rowU | nextU, seen);
-        }
+        if (cx <= dW) unc = eval(cx, cy, sA, sVA, upOnly) ? 1 : 0;
+        ownA = sA[CELL_O] + from_next_lane(sA[CELL_W]); ownVA = sVA[CELL_O] + from_next_lane(sVA[CELL_W]);
+        belowA = sA[CELL_N] + from_next_lane(sA[CELL_NW]); belowVA = sVA[CELL_N] + from_next_lane(sVA[CELL_NW]);
+        rowU = unc | from_next_lane(unc);                        // the two cells of this row that feed column cx
+    };
+    const bool active = y0 < y1;
+    float carryA = 0.f, carryVA = 0.f;                           // own + W of the row above, waiting for this row's N / NW parts
+    int carryU = 0;
+    // ONE loop over the cell rows y0 .. y1 (one copy of the cell evaluation in the code): the first iteration parks its N / NW parts
+    // and meets the other waves at the barrier, the last one takes them from the wave below unless this wave owns the bottom row
+    for (int cy = y0;; ++cy) {
+        const bool first = cy == y0, last = cy == y1;             // (an empty segment: both)
+        decltype(look(cx, cy, false)) seen = {};
+        if (!first) seen = look(cx, cy - 1, column);
+        if (active && (!last || ownsBottom)) row(cy, last);
+        else if (active) { belowA = hand.a[wave + 1][lane]; belowVA = hand.va[wave + 1][lane]; rowU = hand.u[wave + 1][lane]; }
+        if (first) {
+            if (active) { hand.a[wave][lane] = belowA; hand.va[wave][lane] = belowVA; hand.u[wave][lane] = rowU; }
+            __syncthreads();
+            if (!active) break;
+        } else if (column) emit(cx, cy - 1, carryA + belowA, carryVA + belowVA, carryU | rowU, seen);
+        if (last) break;
+        carryA = ownA; carryVA = ownVA; carryU = rowU;
     }
 }
 
-template <typename T, int WIN, bool SCALED, bool HP, int TW>
+// dst rows [y0, y1) of wave `wave` of the workgroup whose rows start at blockY0 and end before blockY1; ownsBottom: no wave below
+// it in the workgroup has rows
+__device__ __forceinline__ void cell_segment(int blockY0, int blockY1, int rowsPerWave, int wave, int &y0, int &y1, bool &ownsBottom)
+{
+    y0 = min(blockY0 + wave * rowsPerWave, blockY1);
+    y1 = min(y0 + rowsPerWave, blockY1);
+    ownsBottom = wave == kCellWaves - 1 || y1 >= blockY1;
+}
+
+template <typename T, int WIN, bool SCALED, bool HP>
 __global__ __launch_bounds__(kQuadBlock, cell_min_waves(WIN)) void aai_cell_kernel(
     RotLaunch r, QuadConsts<float> q, CellConsts<float> z, QuadMap m, const T *__restrict__ src, ImageView sv, float *__restrict__ dst, ImageView dv,
-    const unsigned long long *__restrict__ skipMasks, int tilesX, int rowsPerStrip, int bigStrips, int tailRows)
+    const unsigned long long *__restrict__ skipMasks, int tilesX, int rowsPerWave, int bigBlocks, int tailRows)
 {
     __shared__ float window[WIN * WIN][kQuadBlock];
+    __shared__ CellHandoff hand;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int x0 = (blockIdx.x * (kQuadBlock / 64) + wave) * (TW - 1);
-    if (x0 >= r.dW) return;                                   // wave-uniform; no barrier below
-    // (row bands in launch order: dealing them from the middle outwards, so that the launch's tail is made of the cheap
-    // corner bands, measured 5 % SLOWER at config 3 -- profiles/r03_cell_kernel.txt)
-    // the last strips of a launch are shorter (tailRows rows instead of rowsPerStrip): the waves that finish it live a fraction
-    // as long, and the chip drains in a fraction of the time
+    const int x0 = blockIdx.x * 63;                            // (block-uniform: every wave reaches the walk's barrier)
+    // the last workgroups of a launch are shorter (tailRows rows per wave instead of rowsPerWave): the waves that finish it live a
+    // fraction as long, and the chip drains in a fraction of the time
     const int by = blockIdx.y;
-    const int y0 = r.dyBase + (by < bigStrips ? by * rowsPerStrip : bigStrips * rowsPerStrip + (by - bigStrips) * tailRows);
-    const int y1 = min(y0 + (by < bigStrips ? rowsPerStrip : tailRows), r.dyEnd);           // dst rows [y0, y1); cells rows y0 .. y1
+    const int rpw = by < bigBlocks ? rowsPerWave : tailRows;
+    const int blockY0 = r.dyBase + (by < bigBlocks ? by * (kCellWaves * rowsPerWave) : bigBlocks * (kCellWaves * rowsPerWave) + (by - bigBlocks) * (kCellWaves * tailRows));
+    const int blockY1 = min(blockY0 + kCellWaves * rpw, r.dyEnd);
+    int y0, y1;
+    bool ownsBottom;
+    cell_segment(blockY0, blockY1, rpw, wave, y0, y1, ownsBottom);           // dst rows [y0, y1); cell rows y0 .. y1
     float *image = dst + (int64_t)blockIdx.z * dv.imageStride;
     const char *img = reinterpret_cast<const char *>(src + (int64_t)blockIdx.z * sv.imageStride + m.base);
-    const CellColumn col = cell_column(r, z, x0 + (lane & (TW - 1)));
+    const CellColumn col = cell_column(r, z, x0 + lane);
     int liveLo, liveHi;
-    cell_live_rows(r, z, x0, x0 + TW - 1, liveLo, liveHi);     // wave-uniform
-    // per-pixel masks only where a 16 x 16 tile this strip touches holds a flagged pixel (QuadMap::tileFlags; wave-uniform, scalar loads)
+    cell_live_rows(r, z, x0, x0 + 63, liveLo, liveHi);         // wave-uniform
+    // per-pixel masks only where a 16 x 16 tile this segment touches holds a flagged pixel (QuadMap::tileFlags; wave-uniform, scalar loads)
     const unsigned long long *masks = skipMasks;
-    if (masks && m.tileFlags && TW == 64) {
+    if (masks && m.tileFlags) {
         bool any = false;
         for (int tr = y0 >> 4; tr <= (y1 - 1) >> 4; ++tr) any = any || tiles_flagged(m.tileFlags, m.tileFlagWords, tr, x0 >> 4, 5);
         if (!any) masks = nullptr;
     }
-    cell_walk<TW>(r.dW, x0, y0, y1, liveLo, liveHi, lane,
+    cell_walk(r.dW, x0, y0, y1, ownsBottom, wave, hand, liveLo, liveHi, lane,
         [&](int px, int py, bool wanted) -> bool {
             // is the pixel one the plan's scans left to the fix-up pass?  (requested here, used after the cell is evaluated)
             return masks && wanted && ((masks[flag_word(px, py, tilesX)] >> flag_bit(px, py)) & 1ull);
         },
-        [&](int cx, int cy, float (&sA)[4], float (&sVA)[4]) -> bool {
+        [&](int cx, int cy, float (&sA)[4], float (&sVA)[4], bool upOnly) -> bool {
             int Zx, Zy;
             double dfx, dfy;
             if (!cell_anchor(r, col, cy, Zx, Zy, dfx, dfy)) return false;
             QuadSrc<T, WIN, SCALED, true> s;
             s.img = img; s.m = &m; s.mW = r.mW; s.mH = r.mH; s.lds = window; s.tid = tid;
-            // (the extra cell row below the strip only feeds the strip's last pixel row: its interior / left-edge zones are skipped)
-            cell_eval<float, WIN, false, HP>(q, z, Zx, Zy, dfx, dfy, r.mW, r.mH, s, sA, sVA, TW == 64 && cy == y1);
+            // (the workgroup's bottom cell row only feeds its last pixel row: its interior / left-edge zones are skipped)
+            cell_eval<float, WIN, false, HP>(q, z, Zx, Zy, dfx, dfy, r.mW, r.mH, s, sA, sVA, upOnly);
             return false;
         },
         [&](int px, int py, float A, float VA, int, bool skip) {
@@ -166,22 +188,24 @@ __global__ __launch_bounds__(kQuadBlock, cell_min_waves(WIN)) void aai_cell_kern
 // lane masks of the 16 x 16 tiling (on top of the knife-edge scan's bits) and counts the newly set bits in counter[0].
 template <int WIN, bool HP>
 __global__ __launch_bounds__(kQuadBlock) void aai_cell_scan_kernel(RotLaunch r, QuadConsts<float> q, CellConsts<float> z, unsigned long long *__restrict__ laneMasks,
-                                                                  unsigned *__restrict__ counter, int tilesX, int rowsPerStrip, int band0)
+                                                                  unsigned *__restrict__ counter, int tilesX, int rowsPerWave, int band0)
 {
-    constexpr int TW = 64;
+    __shared__ CellHandoff hand;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int x0 = (blockIdx.x * (kQuadBlock / 64) + wave) * (TW - 1);
-    if (x0 >= r.dW) return;
-    const int y0 = (band0 + blockIdx.y) * rowsPerStrip;
-    const int y1 = min(y0 + rowsPerStrip, r.dH);
+    const int x0 = blockIdx.x * 63;
+    const int blockY0 = (band0 + blockIdx.y) * (kCellWaves * rowsPerWave);
+    const int blockY1 = min(blockY0 + kCellWaves * rowsPerWave, r.dH);
+    int y0, y1;
+    bool ownsBottom;
+    cell_segment(blockY0, blockY1, rowsPerWave, wave, y0, y1, ownsBottom);
     const CellColumn col = cell_column(r, z, x0 + lane);
     int liveLo, liveHi;
-    cell_live_rows(r, z, x0, x0 + TW - 1, liveLo, liveHi);
-    cell_walk<TW>(r.dW, x0, y0, y1, liveLo, liveHi, lane,
+    cell_live_rows(r, z, x0, x0 + 63, liveLo, liveHi);
+    cell_walk(r.dW, x0, y0, y1, ownsBottom, wave, hand, liveLo, liveHi, lane,
         [&](int, int, bool) -> int { return 0; },
-        [&](int cx, int cy, float (&sA)[4], float (&sVA)[4]) -> bool {
+        [&](int cx, int cy, float (&sA)[4], float (&sVA)[4], bool) -> bool {
             int Zx, Zy;
             double dfx, dfy;
             if (!cell_anchor(r, col, cy, Zx, Zy, dfx, dfy)) return false;
@@ -197,41 +221,32 @@ __global__ __launch_bounds__(kQuadBlock) void aai_cell_scan_kernel(RotLaunch r, 
         });
 }
 
-// tile width per wave (see the header): 64; a build with -DAAI_CELL_TILE16 also holds the 16 x 4 variant, chosen by AAI_CELL_TW=16
-static int cell_tile_width(const QuadMap &)
-{
-#if defined(AAI_CELL_TILE16)
-    static const int forced = [] { const char *e = getenv("AAI_CELL_TW"); return e ? atoi(e) : 0; }();
-    if (forced == 16) return 16;
-#endif
-    return 64;
-}
-
-template <typename T, int WIN, int TW>
+template <typename T, int WIN>
 hipError_t launch_cell_tile(const RotLaunch &r, const QuadConsts<float> &q, const CellConsts<float> &z, const QuadMap &m, const T *src, ImageView sv,
                             float *dst, ImageView dv, int batch, const unsigned long long *skipMasks, hipStream_t stream)
 {
-    const int rowsPerStrip = cell_rows_per_strip(r.dW, r.dyEnd - r.dyBase, batch, TW);
-    const int strips = (r.dW + TW - 2) / (TW - 1);
     const int rows = r.dyEnd - r.dyBase;
-    // A launch with few waves (rowsPerStrip already at its minimum of 8: fewer than four rounds of the chip's wave slots) spends a
-    // fifth of its time draining: its last tenth of the rows goes in strips of 4, whose waves live half as long (config 3, one
-    // image: 211 -> 201 us; config 5, 32-row strips and 190 k waves, loses 0.4 ... 7 % to any tail: tools/cell_tail_ab.sh).
-    // Experiments: AAI_CELL_TAIL="<percent of the rows>,<rows per tail strip>".
-    static const int forcedPct = [] { const char *e = getenv("AAI_CELL_TAIL"); return e ? atoi(e) : -1; }();
-    static const int forcedR = [] { const char *e = getenv("AAI_CELL_TAIL"); const char *c = e ? strchr(e, ',') : nullptr; return c ? atoi(c + 1) : 2; }();
-    const int tailPct = forcedPct >= 0 ? forcedPct : (rowsPerStrip == 8 ? 10 : 0), tailR = forcedPct >= 0 ? forcedR : 4;
-    int bigStrips = (rows + rowsPerStrip - 1) / rowsPerStrip, tailRows = rowsPerStrip, tailStrips = 0;
-    if (tailPct > 0 && TW == 64 && tailR > 0 && tailR < rowsPerStrip) {
-        bigStrips = (int)((int64_t)rows * (100 - tailPct) / 100 / rowsPerStrip);
-        tailRows = tailR;
-        tailStrips = (rows - bigStrips * rowsPerStrip + tailRows - 1) / tailRows;
-        if (bigStrips + tailStrips > 65535) { bigStrips = (rows + rowsPerStrip - 1) / rowsPerStrip; tailRows = rowsPerStrip; tailStrips = 0; }      // grid.y
+    const int rowsPerWave = cell_rows_per_wave(r.dW, rows, batch);
+    const int strips = (r.dW + 62) / 63;
+    const int blockRows = kCellWaves * rowsPerWave;
+    // A launch with few waves spends part of its time draining: its last rows go in segments of half the height, whose waves
+    // live half as long.  Experiments (-DAAI_EXPERIMENTS): AAI_CELL_TAIL="<percent of the rows>,<rows per wave in the tail>".
+    int tailPct = rowsPerWave == 4 ? 10 : 0, tailR = 2;
+    {
+        const char *e = experiment_env("AAI_CELL_TAIL");
+        if (e) { tailPct = atoi(e); const char *c = strchr(e, ','); tailR = c ? atoi(c + 1) : 2; }
     }
-    const dim3 grid((strips + 3) / 4, bigStrips + tailStrips, batch);
+    int bigBlocks = (rows + blockRows - 1) / blockRows, tailRows = rowsPerWave, tailBlocks = 0;
+    if (tailPct > 0 && tailR > 0 && tailR < rowsPerWave) {
+        bigBlocks = (int)((int64_t)rows * (100 - tailPct) / 100 / blockRows);
+        tailRows = tailR;
+        tailBlocks = (rows - bigBlocks * blockRows + kCellWaves * tailRows - 1) / (kCellWaves * tailRows);
+        if (bigBlocks + tailBlocks > 65535) { bigBlocks = (rows + blockRows - 1) / blockRows; tailRows = rowsPerWave; tailBlocks = 0; }      // grid.y
+    }
+    const dim3 grid(strips, bigBlocks + tailBlocks, batch);
     const int tilesX = (r.dW + 15) / 16;
 #define AAI_CELL_LAUNCH(SCALED, HP) \
-    hipLaunchKernelGGL((aai_cell_kernel<T, WIN, SCALED, HP, TW>), grid, dim3(kQuadBlock), 0, stream, r, q, z, m, src, sv, dst, dv, skipMasks, tilesX, rowsPerStrip, bigStrips, tailRows)
+    hipLaunchKernelGGL((aai_cell_kernel<T, WIN, SCALED, HP>), grid, dim3(kQuadBlock), 0, stream, r, q, z, m, src, sv, dst, dv, skipMasks, tilesX, rowsPerWave, bigBlocks, tailRows)
     if (m.scale > 1) {
         if (q.hiPrec) AAI_CELL_LAUNCH(true, true); else AAI_CELL_LAUNCH(true, false);
     } else {
@@ -241,17 +256,6 @@ hipError_t launch_cell_tile(const RotLaunch &r, const QuadConsts<float> &q, cons
     return hipGetLastError();
 }
 
-template <typename T, int WIN>
-hipError_t launch_cell_win(const RotLaunch &r, const QuadConsts<float> &q, const CellConsts<float> &z, const QuadMap &m, const T *src, ImageView sv,
-                           float *dst, ImageView dv, int batch, const unsigned long long *skipMasks, hipStream_t stream)
-{
-#if defined(AAI_CELL_TILE16)
-    if (cell_tile_width(m) == 16) return launch_cell_tile<T, WIN, 16>(r, q, z, m, src, sv, dst, dv, batch, skipMasks, stream);
-#endif
-    (void)cell_tile_width;
-    return launch_cell_tile<T, WIN, 64>(r, q, z, m, src, sv, dst, dv, batch, skipMasks, stream);
-}
-
 template <typename T>
 hipError_t launch_cell_typed(const RotLaunch &r, const QuadMap &m, const T *src, ImageView sv, float *dst, ImageView dv, int batch,
                              const unsigned long long *skipMasks, hipStream_t stream)
@@ -259,32 +263,18 @@ hipError_t launch_cell_typed(const RotLaunch &r, const QuadMap &m, const T *src,
     const QuadConsts<float> q = make_cell_quad_consts<float>(r.side, r.c, r.s, r.policy);
     const CellConsts<float> z = make_cell_consts<float>(r.side, r.c, r.s);
     switch (z.win) {
-    case 2: return launch_cell_win<T, 2>(r, q, z, m, src, sv, dst, dv, batch, skipMasks, stream);
-    case 3: return launch_cell_win<T, 3>(r, q, z, m, src, sv, dst, dv, batch, skipMasks, stream);
-    case 4: return launch_cell_win<T, 4>(r, q, z, m, src, sv, dst, dv, batch, skipMasks, stream);
-    case 5: return launch_cell_win<T, 5>(r, q, z, m, src, sv, dst, dv, batch, skipMasks, stream);
-    case 6: return launch_cell_win<T, 6>(r, q, z, m, src, sv, dst, dv, batch, skipMasks, stream);
-    case 7: return launch_cell_win<T, 7>(r, q, z, m, src, sv, dst, dv, batch, skipMasks, stream);
-    case 8: return launch_cell_win<T, 8>(r, q, z, m, src, sv, dst, dv, batch, skipMasks, stream);
+    case 2: return launch_cell_tile<T, 2>(r, q, z, m, src, sv, dst, dv, batch, skipMasks, stream);
+    case 3: return launch_cell_tile<T, 3>(r, q, z, m, src, sv, dst, dv, batch, skipMasks, stream);
+    case 4: return launch_cell_tile<T, 4>(r, q, z, m, src, sv, dst, dv, batch, skipMasks, stream);
+    case 5: return launch_cell_tile<T, 5>(r, q, z, m, src, sv, dst, dv, batch, skipMasks, stream);
+    case 6: return launch_cell_tile<T, 6>(r, q, z, m, src, sv, dst, dv, batch, skipMasks, stream);
+    case 7: return launch_cell_tile<T, 7>(r, q, z, m, src, sv, dst, dv, batch, skipMasks, stream);
+    case 8: return launch_cell_tile<T, 8>(r, q, z, m, src, sv, dst, dv, batch, skipMasks, stream);
     default: return hipErrorInvalidValue;
     }
 }
 
 }  // namespace
-
-// dst rows a wave walks: a strip of R rows costs R + 1 cell rows (R + 64 / tileWidth for tiles of several rows), so taller is
-// cheaper -- as long as the launch still has several waves for every SIMD of the chip (1024 SIMDs x ~6 wave slots)
-int cell_rows_per_strip(int dW, int rows, int batch, int tileWidth)
-{
-    static const int forced = [] { const char *e = getenv("AAI_CELL_ROWS"); return e ? atoi(e) : 0; }();
-    const int tr = 64 / tileWidth;
-    if (forced > 0) return (forced + tr - 1) / tr * tr;
-    const int64_t strips = ((int64_t)dW + tileWidth - 2) / (tileWidth - 1) * batch;
-    int R = 32;
-    while (R > 8 && strips * ((rows + R - 1) / R) < 24576) R >>= 1;
-    while ((rows + R - 1) / R > 65535) R <<= 1;               // grid.y
-    return R;
-}
 
 // (tests: aai_debug_cell_min_waves(0) sends small images to the cell kernel too)
 static int g_cellMinWaves = 1024;
@@ -293,7 +283,7 @@ void set_cell_min_waves(int waves) { g_cellMinWaves = waves < 0 ? 1024 : waves; 
 bool cell_can_serve(const RotLaunch &r, int srcType, ImageView sv)
 {
     // plain images below 4 GiB (lanes address their pixels with unsigned 32-bit byte offsets from the image's first element)
-    static const bool enabled = [] { const char *e = getenv("AAI_CELL"); return !(e && atoi(e) == 0); }();      // experiments: AAI_CELL=0 keeps the quad kernel
+    static const bool enabled = [] { const char *e = experiment_env("AAI_CELL"); return !(e && atoi(e) == 0); }();      // experiments: AAI_CELL=0 keeps the quad kernel
     if (!enabled || !r.cell || r.chan > 1 || r.mode != AAI_MODE_AREA) return false;
     // Small outputs stay on the quad kernel: a cell wave lives for rows + 1 cell rows, and an image of fewer than ~1000 such
     // waves (about 720 x 720 dst pixels) cannot fill the chip with them -- the reference's own example call (158 x 158 dst
@@ -321,12 +311,12 @@ hipError_t launch_cell_scan(const RotLaunch &r, unsigned long long *laneMasks, u
     if (r.dW <= 0 || r.dH <= 0) return hipSuccess;
     const QuadConsts<float> q = make_cell_quad_consts<float>(r.side, r.c, r.s, r.policy);
     const CellConsts<float> z = make_cell_consts<float>(r.side, r.c, r.s);
-    const int rows = 16;
-    const int strips = (r.dW + 62) / 63;                       // the scan walks 64 x 1 tiles
+    const int rows = 4;                                        // per wave: workgroups of 16 dst rows
+    const int strips = (r.dW + 62) / 63;
     const int tilesX = (r.dW + 15) / 16;
-    const int bands = (r.dH + rows - 1) / rows;
+    const int bands = (r.dH + kCellWaves * rows - 1) / (kCellWaves * rows);
     for (int b0 = 0; b0 < bands; b0 += 65535) {                // grid.y carries at most 65535 bands
-        const dim3 grid((strips + 3) / 4, bands - b0 < 65535 ? bands - b0 : 65535, 1);
+        const dim3 grid(strips, bands - b0 < 65535 ? bands - b0 : 65535, 1);
 #define AAI_CELL_SCAN(W)                                                                                                                               \
     case W:                                                                                                                                            \
         if (q.hiPrec) hipLaunchKernelGGL((aai_cell_scan_kernel<W, true>), grid, dim3(kQuadBlock), 0, stream, r, q, z, laneMasks, counter, tilesX, rows, b0); \

@@ -146,7 +146,7 @@ def cpu_baseline(name, budget_s=15.0, procs=0, pool=None):
             rows_src = side
             sample = "unmodified reference (Source.cpp via oracle/_ref) on a %dx%d crop with the same ratio/rotation: %d output pixels, %.1f s" % (side, side, n, t)
         out = {"value": n / t / 1e6, "unit": "Mpixels/s (output)", "cores": 1, "kind": "reference",
-               "sample": sample, "host_cpus": os.cpu_count(), "cpu_model": cpu_model}
+               "sample": sample, "pixels": n, "seconds": t, "host_cpus": os.cpu_count(), "cpu_model": cpu_model}
         if procs > 1 and ang == 0.0 and pool is not None:
             jobs = [(W, rows_src, sr, dr, ang, omode, b + 1) for b in range(procs)]
             t0 = time.perf_counter()
@@ -183,7 +183,7 @@ def cpu_baseline(name, budget_s=15.0, procs=0, pool=None):
     probe = run(mid, mid + 2)
     rows = int(max(2, min(dH - mid, budget_s / max(probe / 2, 1e-6))))
     t = run(mid, mid + rows)
-    return {"value": rows * dW / t / 1e6, "unit": "Mpixels/s (output)", "cores": 1, "kind": "port",
+    return {"value": rows * dW / t / 1e6, "unit": "Mpixels/s (output)", "cores": 1, "kind": "port", "pixels": rows * dW, "seconds": t,
             "sample": "oracle/aai_oracle.c (double precision, 1 thread) on %d of %d output rows of the same "
                       "workload (rows %d..%d), %.1f s" % (rows, dH, mid, mid + rows - 1, t),
             "host_cpus": os.cpu_count(), "cpu_model": cpu_model}
@@ -321,7 +321,18 @@ def measure_traffic(argv_child, steady, timeout_s=240.0):
 
 
 # ---- the other BASELINE configurations, kernel-only ------------------------------------------------------------------------
-def config_block(aai, torch, policy, cfg2_cpu, cpu_procs, cpu_pool, with_cpu):
+def short_kernel(name):
+    """aai_cell_kernel<float, 4, false, false, 64>(...) -> aai_cell_kernel<float,4,false,false,64>"""
+    name = name.split("(")[0].strip()
+    return name.split("::")[-1].replace(" ", "")[:64]
+
+
+def compact_shape(shape):
+    """the plan's "kernel=K rows=R nt=N swap=S flagged=F dense=D" without the kernel (named beside it)"""
+    return " ".join(t for t in shape.split() if not t.startswith("kernel="))[:80]
+
+
+def config_block(aai, torch, policy, cfg2_cpu, cpu_procs, cpu_pool, with_cpu, cpu_scale=1.0):
     """Every BASELINE.json configuration (CONFIG_SET) on this GPU: device-resident synthetic images, `prepare_ms` = wall
     clock of aai_prepare on a geometry this process has not seen (config 2: the headline already built its plan -- its
     cold figure is `plan.first_call_ms` of the headline), then a block of launches between two HIP events on the launch
@@ -363,22 +374,79 @@ def config_block(aai, torch, policy, cfg2_cpu, cpu_procs, cpu_pool, with_cpu):
         torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / n
         alg = B * (4 * W * H + 4 * dW * dH)
-        entry = {"workload": "%s: %s" % (name, desc), "images_per_launch": B, "dst": [dW, dH], "kernel": aai.last_kernel(),
-                 "kernel_ms_per_launch": ms, "launches_timed": n, "value": B * dW * dH / (ms * 1e-3) / 1e6, "unit": "Mpixels/s (output)",
-                 "algorithmic_bytes_per_launch": alg, "achieved_gbps": alg / (ms * 1e-3) / 1e9, "frac": alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
-                 "plan_shape": aai.plan_shape(rq), "prepare_ms": prepare_ms, "prepare": "warm (built by the headline)" if name == "cfg2" else "cold"}
+        # compact on purpose: the driver keeps the last 8 KB of stdout, the whole JSON line has to fit (tests/test_host_logic.py);
+        # the workload's description is WORKLOADS[name], the host CPU is named once at the top level of the line
+        entry = {"name": name, "images": B, "dst": [dW, dH], "kernel": short_kernel(aai.last_kernel()),
+                 "ms": round(ms, 5), "launches": n, "mpix_s": round(B * dW * dH / (ms * 1e-3) / 1e6, 1),
+                 "gbps": round(alg / (ms * 1e-3) / 1e9, 1), "frac": round(alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+                 "prepare_ms": round(prepare_ms, 2), "plan": compact_shape(aai.plan_shape(rq))}
         del src, dst
         torch.cuda.empty_cache()
         if with_cpu and mode in (MODE_AREA, MODE_FAST):
             if name == "cfg2" and cfg2_cpu:
-                cpu = dict(cfg2_cpu)
-                cpu.pop("gpu_over_cpu", None)
+                cpu = cfg2_cpu
             else:
-                cpu = cpu_baseline(name, budget_s=6.0, procs=cpu_procs if name == "cfg4" else 0, pool=cpu_pool)
-            entry["cpu_baseline"] = cpu
-            entry["gpu_over_cpu"] = entry["value"] / cpu["value"]
+                cpu = cpu_baseline(name, budget_s=6.0 * cpu_scale, procs=cpu_procs if name == "cfg4" else 0, pool=cpu_pool)
+            # [Mpixels/s of the unmodified reference on 1 core, output pixels of the sample, seconds] (+ config 4: N processes)
+            entry["cpu"] = [round(cpu["value"], 5), cpu.get("pixels"), round(cpu.get("seconds", 0.0), 2)]
+            if "nproc" in cpu:
+                entry["cpu_nproc"] = [cpu["nproc"]["processes"], round(cpu["nproc"]["value"], 5)]
+            entry["gpu_over_cpu"] = round(B * dW * dH / (ms * 1e-3) / 1e6 / cpu["value"], 0)
+            entry["cpu_kind"] = cpu["kind"]
         out.append(entry)
     return out
+
+
+def cfg4_sharded(aai, torch, dist, D, world, rank, cdev, policy, fence, mock):
+    """BASELINE config 4 as BASELINE.json words it -- a batch of 64 independent 4096x4096 -> 1024x1024 images sharded over the
+    ranks -- on every rank of a multi-rank run: rank r resamples images [r 64/N, (r + 1) 64/N) (seed = global index + 1), one
+    batched launch per step, no data-path collective; kernel-only ms per rank from a HIP event pair, aggregate = all 64 images
+    over the slowest rank's time.  Returns the entry on rank 0 (None elsewhere)."""
+    W, H, sr, dr, ang, mode, desc = WORKLOADS["cfg4"]
+    total = 64
+    first, last = D.shard_bounds(total, rank, world)
+    B = last - first
+    rq = aai.make_request(W, H, sr, dr, isocenter("cfg4", W, H), ang, mode=mode, policy=policy)
+    rc, msg, lay = aai.query(rq)
+    assert rc == 0, msg
+    dW, dH = lay.dst_width, lay.dst_height
+    n = 20
+    if mock:
+        ms = 2.0
+    else:
+        stream = torch.cuda.current_stream().cuda_stream
+        src = torch.empty((max(B, 1), H, W), dtype=torch.float32, device="cuda")
+        dst = torch.empty((max(B, 1), dH, dW), dtype=torch.float32, device="cuda")
+        for b in range(B):
+            aai.synth_device(src[b].data_ptr(), W, H, W, first + b + 1, stream)
+
+        def launch():
+            if B:
+                aai.resample_device(rq, src.data_ptr(), W, dst.data_ptr(), dW, stream, batch=B, src_image_stride=W * H, dst_image_stride=dW * dH)
+
+        launch()
+        launch()
+        fence()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(n):
+            launch()
+        e1.record()
+        fence()
+        ms = e0.elapsed_time(e1) / n
+        del src, dst
+        torch.cuda.empty_cache()
+    mine = torch.tensor([ms], dtype=torch.float64, device=cdev)
+    every = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(every, mine)
+    rank_ms = [round(float(x.item()), 5) for x in every]
+    if rank != 0:
+        return None
+    alg = (total // world) * (4 * W * H + 4 * dW * dH)
+    worst = max(rank_ms)
+    return {"workload": "cfg4: 64 x (%s), %d images per rank" % (desc, total // world), "ms_per_rank": rank_ms, "launches": n,
+            "mpix_s": round(total * dW * dH / (worst * 1e-3) / 1e6, 1), "frac_per_gpu": round(alg / (worst * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+            "note": "kernel-only, every rank's images device-resident, no collective on the data path"}
 
 
 # ---- one rank -----------------------------------------------------------------------------------------------------
@@ -401,6 +469,12 @@ def worker(args):
                                             not mock and not args.traffic_child and args.shard == "batch" and args.src_dtype == "f32")
     cpu_procs = args.cpu_procs if args.cpu_procs >= 0 else (min(16, os.cpu_count() or 1) if (args.workload == "cfg4" or want_configs) else 0)
     cpu_pool = None
+    cpu_note = None
+    if under_profiler() and not args.no_cpu_baseline and not mock:
+        # A profiler's preload has initialised the GPU in THIS process: starting worker interpreters from it (each inheriting the
+        # preload) is the hop spawn_ranks() and measure_traffic() refuse too.  The CPU legs are skipped and the line says so.
+        args.no_cpu_baseline = True
+        cpu_note = "skipped: running under a profiler preload (no child processes from a GPU-initialised process)"
     if cpu_procs > 1 and world == 1 and not args.no_cpu_baseline and not mock:
         from multiprocessing import get_context
         cpu_pool = get_context("spawn").Pool(cpu_procs)
@@ -588,6 +662,14 @@ def worker(args):
         fence()
         gather_ms = (time.perf_counter() - g0) * 1e3
 
+    # BASELINE config 4 (64 images over the ranks) rides along on every multi-rank batch run of the headline
+    cfg4_rank = None
+    if world > 1 and dist.is_initialized() and args.configs != "off" and not rows_mode and args.workload == "cfg2" and 64 % world == 0:
+        if not mock:
+            del src, dst
+            torch.cuda.empty_cache()
+        cfg4_rank = cfg4_sharded(aai, torch, dist, D, world, rank, cdev, policy, fence, mock)
+
     if rank == 0:
         out_pix = total_images * dW * dH * n_timed
         alg_bytes = B * (esz * W * src_rows + 4 * dW * out_rows)              # per launch on this GPU
@@ -628,18 +710,25 @@ def worker(args):
             "distributed": {"backend": backend, "world_size_seen": world_seen, "kernel_ms_per_rank": rank_ms,
                             "value_compute_only": out_pix / elapsed / 1e6},
         }
+        line["host"] = {"cpu_model": _cpu_model(), "host_cpus": os.cpu_count()}
         if mock:
             line["mock"] = True
         if gather_ms is not None:
             line["distributed"]["gather_ms"] = gather_ms
             line["distributed"]["value_with_gather"] = total_images * dW * dH / (elapsed / n_timed + gather_ms * 1e-3) / 1e6
         if world == 1 and not args.no_cpu_baseline and not mock and mode in (MODE_AREA, MODE_FAST):
-            line["cpu_baseline"] = cpu_baseline(args.workload, procs=cpu_procs if args.workload == "cfg4" else 0, pool=cpu_pool)
+            line["cpu_baseline"] = cpu_baseline(args.workload, budget_s=15.0 * args.cpu_scale, procs=cpu_procs if args.workload == "cfg4" else 0, pool=cpu_pool)
             line["cpu_baseline"]["gpu_over_cpu"] = line["value"] / line["cpu_baseline"]["value"]
+        if cpu_note:
+            line["cpu_baseline"] = {"value": None, "unit": "Mpixels/s (output)", "cores": 0, "kind": "reference", "sample": cpu_note}
         if want_configs:
             del src, dst
             torch.cuda.empty_cache()
-            line["configs"] = config_block(aai, torch, policy, line.get("cpu_baseline"), cpu_procs, cpu_pool, not args.no_cpu_baseline)
+            line["configs"] = config_block(aai, torch, policy, line.get("cpu_baseline"), cpu_procs, cpu_pool, not args.no_cpu_baseline, args.cpu_scale)
+            line["configs_note"] = ("per BASELINE configuration, kernel-only: ms per launch, output Mpixels/s, algorithmic GB/s and fraction of the 8 TB/s HBM peak, "
+                                    "cold aai_prepare ms; cpu = [Mpixels/s of the unmodified reference on 1 core of this host, output pixels of its sample, seconds]")
+        if cfg4_rank is not None:
+            line["cfg4"] = cfg4_rank
         if saved_stdout is not None:
             sys.stdout.flush()
             ctypes.CDLL(None).fflush(None)          # whatever C stdio still holds goes to stderr, not after the JSON line
@@ -679,6 +768,7 @@ def main():
     ap.add_argument("--traffic-child", action="store_true", help=argparse.SUPPRESS)     # a counter pass of measure_traffic()
     ap.add_argument("--repeats", type=int, default=0, help="fix the number of repeats of the --steps block (0 = from --min-seconds)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-scale", type=float, default=1.0, help="scale the CPU baseline's time budgets (15 s headline, 6 s per configuration); tests use a small one")
     ap.add_argument("--cpu-procs", type=int, default=-1, help="processes of the extra multi-process CPU baseline (default: min(16, cores) for cfg4, else none)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend; nccl (= RCCL) is the real one, gloo lets two ranks rehearse on one GPU")

@@ -132,6 +132,9 @@ def test_bench_self_launches_two_ranks_and_relays_one_line():
     assert d["timed"]["steps_timed"] == d["timed"]["repeats"] * d["steps"] and d["timed"]["repeats"] >= 1
     assert d["timed"]["step_ms"]["min"] <= d["timed"]["step_ms"]["median"] <= d["timed"]["step_ms"]["max"]
     assert abs(d["ms_per_step"] * d["timed"]["steps_timed"] * 1e-3 - d["timed"]["seconds"]) < 1e-6
+    # BASELINE config 4 (64 images over the ranks) rides along on a multi-rank headline run: 32 images per rank here
+    assert len(d["cfg4"]["ms_per_rank"]) == 2 and "32 images per rank" in d["cfg4"]["workload"] and d["cfg4"]["mpix_s"] > 0
+    assert len(out.strip()) < 8000                                         # the driver keeps an 8 KB tail of stdout
     # row bands of one image: same launch path, strong scaling, half an image per rank
     rc, lines, out, err = _run_bench("--gpus", "2", "--backend", "gloo", "--shard", "rows")
     assert rc == 0 and len(lines) == 1, err[-2000:]
