@@ -8,7 +8,9 @@ import os
 import sys
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libaai_hip.so")
+# (tools/ may point AAI_LIB at the experiments build, `make -C csrc exp` -> libaai_hip_exp.so, whose launch heuristics read the
+# AAI_* environment switches; the product library ignores them)
+LIB_PATH = os.environ.get("AAI_LIB") or os.path.join(_HERE, "libaai_hip.so")
 
 # status codes (include/aai.h)
 OK = 0
@@ -26,6 +28,8 @@ ERR_EMPTY_OUTPUT = 10
 MODE_AREA, MODE_FAST, MODE_BILINEAR, MODE_BICUBIC = 1, 2, 3, 4
 POLICY_REFERENCE, POLICY_EXACT = 0, 1
 POLICY_DOUBLE_PRECISION = 0x100      # OR into a policy: general rotations in double precision throughout (include/aai.h)
+POLICY_PREFER_CELL = 0x200           # OR into a policy: the cell formulation also for small outputs (a hint)
+POLICY_DIAG_NO_FIXUP = 0x400         # OR into a policy: DIAGNOSTIC, the fix-up pass over the plan's listed pixels is not launched
 DTYPE_F32, DTYPE_U8, DTYPE_U16 = 0, 1, 2
 KERNEL_AXIS, KERNEL_ROTATED, KERNEL_FAST, KERNEL_SAMPLE, KERNEL_AXIS_WIDE = 1, 2, 3, 4, 5
 

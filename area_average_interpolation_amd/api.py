@@ -39,6 +39,20 @@ def make_request(width, height, src_resolution, dst_resolution, src_isocenter, r
                      iso[0], iso[1], float(rotation_angle))
 
 
+# Per-request hint / diagnostic bits the debug_* helpers below switch on for every request made through this module (the library
+# itself has no process-wide switches: include/aai.h, AAI_POLICY_PREFER_CELL / AAI_POLICY_DIAG_NO_FIXUP)
+_extra_policy = 0
+
+
+def _ref(request):
+    """ctypes reference to the request as the library should see it: with the module's extra policy bits, if any"""
+    if not _extra_policy:
+        return ctypes.byref(request)
+    rq = L.Request.from_buffer_copy(request)
+    rq.policy |= _extra_policy
+    return ctypes.byref(rq)
+
+
 def last_error():
     return L.load().aai_last_error().decode()
 
@@ -47,7 +61,7 @@ def query(request):
     """aai_query: validate + output layout.  Returns (code, message, Layout-or-None).  Needs no GPU."""
     lib = L.load()
     lay = L.Layout()
-    rc = lib.aai_query(ctypes.byref(request), ctypes.byref(lay))
+    rc = lib.aai_query(_ref(request), ctypes.byref(lay))
     if rc != L.OK:
         return rc, last_error(), None
     return rc, "", lay
@@ -92,7 +106,7 @@ def resample_host(src, src_resolution, dst_resolution, src_isocenter, rotation_a
             return rc, msg, None, None, None
         dst = np.empty((lay.dst_height, lay.dst_width), dtype=np.float32)
         out_lay = L.Layout()
-        rc = lib.aai_resample_host(ctypes.byref(rq), a.ctypes.data, L.DTYPE_U8 if a.dtype == np.uint8 else L.DTYPE_U16, W,
+        rc = lib.aai_resample_host(_ref(rq), a.ctypes.data, L.DTYPE_U8 if a.dtype == np.uint8 else L.DTYPE_U16, W,
                                    dst.ctypes.data, max(lay.dst_width, 1), ctypes.byref(out_lay))
         if rc != L.OK:
             return rc, last_error(), None, None, None
@@ -112,7 +126,7 @@ def resample_host(src, src_resolution, dst_resolution, src_isocenter, rotation_a
     dst = np.empty((lay.dst_height, lay.dst_width), dtype=a.dtype)
     fn = lib.aai_resample_f32 if a.dtype == np.float32 else lib.aai_resample_f64
     out_lay = L.Layout()
-    rc = fn(ctypes.byref(rq), a.ctypes.data, W, dst.ctypes.data, max(lay.dst_width, 1), ctypes.byref(out_lay))
+    rc = fn(_ref(rq), a.ctypes.data, W, dst.ctypes.data, max(lay.dst_width, 1), ctypes.byref(out_lay))
     if rc != L.OK:
         return rc, last_error(), None, None, None
     return rc, "", dst, (out_lay.dst_iso_x, out_lay.dst_iso_y), out_lay
@@ -204,7 +218,7 @@ def resample_batch_host(srcs, src_resolution, dst_resolution, src_isocenter, rot
     if dst.shape != shape or dst.dtype != np.float32 or not dst.flags.c_contiguous:
         raise ValueError("out must be a C-contiguous float32 array of shape %r" % (shape,))
     out_lay = L.Layout()
-    rc = lib.aai_resample_batch_host(ctypes.byref(rq), B, a.ctypes.data, _NP_DTYPES[a.dtype], W, W * H,
+    rc = lib.aai_resample_batch_host(_ref(rq), B, a.ctypes.data, _NP_DTYPES[a.dtype], W, W * H,
                                      dst.ctypes.data, max(lay.dst_width, 1), lay.dst_width * lay.dst_height, ctypes.byref(out_lay))
     if rc != L.OK:
         return rc, last_error(), None, None
@@ -226,7 +240,7 @@ def resample_interleaved_host(src, src_resolution, dst_resolution, src_isocenter
         return rc, msg, None, None
     dst = np.empty((lay.dst_height, lay.dst_width, C), dtype=np.float32)
     out_lay = L.Layout()
-    rc = lib.aai_resample_interleaved_host(ctypes.byref(rq), C, a.ctypes.data, _NP_DTYPES[a.dtype], W * C,
+    rc = lib.aai_resample_interleaved_host(_ref(rq), C, a.ctypes.data, _NP_DTYPES[a.dtype], W * C,
                                            dst.ctypes.data, max(lay.dst_width * C, 1), ctypes.byref(out_lay))
     if rc != L.OK:
         return rc, last_error(), None, None
@@ -237,7 +251,7 @@ def resample_interleaved_device(request, channels, src_ptr, src_stride, dst_ptr,
                                 src_image_stride=0, dst_image_stride=0, src_dtype=L.DTYPE_F32):
     """Device-resident interleaved images (aai_resample_interleaved_device); strides in elements."""
     lib = L.load()
-    rc = lib.aai_resample_interleaved_device(ctypes.byref(request), int(batch), int(channels), src_ptr, int(src_dtype), src_stride,
+    rc = lib.aai_resample_interleaved_device(_ref(request), int(batch), int(channels), src_ptr, int(src_dtype), src_stride,
                                              src_image_stride, dst_ptr, dst_stride, dst_image_stride, stream)
     if rc != L.OK:
         raise AaiError(rc, last_error())
@@ -249,15 +263,15 @@ def resample_device(request, src_ptr, src_stride, dst_ptr, dst_stride, stream=0,
     src_dtype: DTYPE_F32 (default) / DTYPE_U8 / DTYPE_U16 -- strides are in source elements."""
     lib = L.load()
     if src_dtype != L.DTYPE_F32:
-        rc = lib.aai_resample_batch_device(ctypes.byref(request), 1 if batch is None else int(batch), src_ptr, int(src_dtype),
+        rc = lib.aai_resample_batch_device(_ref(request), 1 if batch is None else int(batch), src_ptr, int(src_dtype),
                                            src_stride, src_image_stride, dst_ptr, dst_stride, dst_image_stride, stream)
         if rc != L.OK:
             raise AaiError(rc, last_error())
         return
     if batch is None:
-        rc = lib.aai_resample_device_f32(ctypes.byref(request), src_ptr, src_stride, dst_ptr, dst_stride, stream)
+        rc = lib.aai_resample_device_f32(_ref(request), src_ptr, src_stride, dst_ptr, dst_stride, stream)
     else:
-        rc = lib.aai_resample_batch_device_f32(ctypes.byref(request), int(batch), src_ptr, src_stride, src_image_stride,
+        rc = lib.aai_resample_batch_device_f32(_ref(request), int(batch), src_ptr, src_stride, src_image_stride,
                                                dst_ptr, dst_stride, dst_image_stride, stream)
     if rc != L.OK:
         raise AaiError(rc, last_error())
@@ -272,7 +286,7 @@ def resample_multi_device(request, shards, src_stride, src_image_stride, dst_str
     srcs = (ctypes.c_void_p * n)(*[s[2] for s in shards])
     dsts = (ctypes.c_void_p * n)(*[s[3] for s in shards])
     strs = (ctypes.c_void_p * n)(*[s[4] for s in shards])
-    rc = L.load().aai_resample_batch_multi_device_f32(ctypes.byref(request), n, devs, cnts, srcs, src_stride, src_image_stride,
+    rc = L.load().aai_resample_batch_multi_device_f32(_ref(request), n, devs, cnts, srcs, src_stride, src_image_stride,
                                                      dsts, dst_stride, dst_image_stride, strs)
     if rc != L.OK:
         raise AaiError(rc, last_error())
@@ -281,7 +295,7 @@ def resample_multi_device(request, shards, src_stride, src_image_stride, dst_str
 def band_source_rows(request, dst_row0, dst_row1):
     """aai_band_source_rows: source rows [a, b) that dst rows [dst_row0, dst_row1) read.  Needs no GPU."""
     a, b = ctypes.c_int32(), ctypes.c_int32()
-    rc = L.load().aai_band_source_rows(ctypes.byref(request), int(dst_row0), int(dst_row1), ctypes.byref(a), ctypes.byref(b))
+    rc = L.load().aai_band_source_rows(_ref(request), int(dst_row0), int(dst_row1), ctypes.byref(a), ctypes.byref(b))
     if rc != L.OK:
         raise AaiError(rc, last_error())
     return a.value, b.value
@@ -289,7 +303,7 @@ def band_source_rows(request, dst_row0, dst_row1):
 
 def resample_band_device(request, dst_row0, dst_row1, src_rows_ptr, src_stride, dst_rows_ptr, dst_stride, stream=0):
     """aai_resample_band_device_f32: src_rows_ptr addresses source row band_source_rows(...)[0], dst_rows_ptr output row dst_row0."""
-    rc = L.load().aai_resample_band_device_f32(ctypes.byref(request), int(dst_row0), int(dst_row1), src_rows_ptr, src_stride,
+    rc = L.load().aai_resample_band_device_f32(_ref(request), int(dst_row0), int(dst_row1), src_rows_ptr, src_stride,
                                                dst_rows_ptr, dst_stride, stream)
     if rc != L.OK:
         raise AaiError(rc, last_error())
@@ -299,26 +313,24 @@ def plan_shape(request, channels=1):
     """aai_plan_info: one line describing the cached whole-image plan of this request on the current device ("" if none):
     kernel family, K1 launch shape and its origin, flagged pixels, fp32 formulation, build time."""
     buf = ctypes.create_string_buffer(512)
-    rc = L.load().aai_plan_info(ctypes.byref(request), int(channels), buf, 512)
+    rc = L.load().aai_plan_info(_ref(request), int(channels), buf, 512)
     if rc != L.OK:
         raise AaiError(rc, last_error())
     return buf.value.decode()
 
 
 def debug_cell_min_waves(waves):
-    """tests only: the smallest output (in cell waves of 63 x 8 dst pixels) the cell kernel takes; 0 = all, -1 = the default"""
-    lib = L.load()
-    lib.aai_debug_cell_min_waves.restype = None
-    lib.aai_debug_cell_min_waves.argtypes = [ctypes.c_int]
-    lib.aai_debug_cell_min_waves(int(waves))
+    """tests: 0 = every rotated area request made through this module carries AAI_POLICY_PREFER_CELL (small outputs take the cell
+    kernel too); anything else = the default (outputs below ~720 x 720 pixels stay on the quad kernel)"""
+    global _extra_policy
+    _extra_policy = (_extra_policy | L.POLICY_PREFER_CELL) if int(waves) == 0 else (_extra_policy & ~L.POLICY_PREFER_CELL)
 
 
 def debug_skip_fixup(skip):
-    """tests only: True = the double-precision fix-up pass is not launched, flagged pixels keep the caller's bytes"""
-    lib = L.load()
-    lib.aai_debug_skip_fixup.restype = None
-    lib.aai_debug_skip_fixup.argtypes = [ctypes.c_int]
-    lib.aai_debug_skip_fixup(1 if skip else 0)
+    """tests / timing: True = requests made through this module carry AAI_POLICY_DIAG_NO_FIXUP (the double-precision fix-up pass is
+    not launched, the plan's listed pixels keep the caller's bytes)"""
+    global _extra_policy
+    _extra_policy = (_extra_policy | L.POLICY_DIAG_NO_FIXUP) if skip else (_extra_policy & ~L.POLICY_DIAG_NO_FIXUP)
 
 
 def shutdown():
@@ -329,7 +341,7 @@ def shutdown():
 def prepare(request, channels=1):
     """aai_prepare: build (and cache) the plan of this request on the current device now -- K1 tables, the one-off
     scans of a rotated geometry -- instead of inside the first resampling call, which would then synchronise."""
-    rc = L.load().aai_prepare(ctypes.byref(request), int(channels))
+    rc = L.load().aai_prepare(_ref(request), int(channels))
     if rc != L.OK:
         raise AaiError(rc, last_error())
 

@@ -555,8 +555,8 @@ __global__ __launch_bounds__(256) void aai_axis_wide_kernel(AxisLaunch a, const 
 
 }  // namespace
 
-// Launch-shape overrides for experiments (tools/tune_axis.py): AAI_AXIS_TUNE="nt=1,rows=1,interleave=0,gy=0,swap=0,tile=1" is
-// read once per process; aai_debug_axis_tune() replaces it at run time (not part of the public ABI in include/aai.h).
+// Launch-shape overrides for experiments (tools/tune_axis.py), in the experiments build only (make exp, -DAAI_EXPERIMENTS):
+// AAI_AXIS_TUNE="nt=1,rows=1,interleave=0,gy=0,swap=0,tile=1" is read once per process; aai_debug_axis_tune() replaces it at run time.
 struct AxisTune { int nt = -1, rows = 0, interleave = -1, gy = -1, swap = -1, tile = -1; };
 static AxisTune parse_axis_tune(const char *spec)
 {
@@ -571,7 +571,7 @@ static AxisTune parse_axis_tune(const char *spec)
 }
 static AxisTune &axis_tune()
 {
-    static AxisTune t = parse_axis_tune(getenv("AAI_AXIS_TUNE"));
+    static AxisTune t = parse_axis_tune(experiment_env("AAI_AXIS_TUNE"));
     return t;
 }
 void set_axis_tune(const char *spec) { axis_tune() = parse_axis_tune(spec); }

@@ -300,20 +300,10 @@ int aai_shutdown(void)
     return AAI_OK;
 }
 
-/* experiments only (tools/tune_axis.py); not declared in include/aai.h */
+#if defined(AAI_EXPERIMENTS)
+/* experiments build only (tools/tune_axis.py): the run-time form of AAI_AXIS_TUNE; not declared in include/aai.h */
 void aai_debug_axis_tune(const char *spec) { aai::set_axis_tune(spec); }
-/* tests only: the smallest output (in cell waves) the cell kernel takes; 0 = every output, < 0 = the default */
-void aai_debug_cell_min_waves(int waves) { aai::set_cell_min_waves(waves); }
-/* tests only: != 0: the double-precision fix-up pass is not launched -- the pixels the plan's scans flagged stay as the caller left them */
-void aai_debug_skip_fixup(int skip) { aai::set_skip_fixup(skip != 0); }
-
-const char *aai_debug_plan_shape(const aai_request *req)
-{
-    // kept for tools/ written against round 2: the text of aai_plan_info
-    static thread_local std::string text;
-    text = req ? plan_description(*req, 1) : std::string();
-    return text.c_str();
-}
+#endif
 
 int aai_synth_rows_device_f32(float *d_dst, int32_t width, int32_t height, int32_t row0, int32_t row1, int64_t stride, uint64_t seed, void *stream)
 {

@@ -44,6 +44,46 @@ std::list<PlanRef> &plan_cache()
     static std::list<PlanRef> *cache = new std::list<PlanRef>();      // never destroyed: no HIP calls from static destructors
     return *cache;
 }
+static std::mutex g_poolMutex;
+static std::map<int, DevicePool *> &pools()
+{
+    static std::map<int, DevicePool *> *m = new std::map<int, DevicePool *>();
+    return *m;
+}
+DevicePool &device_pool(int device)
+{
+    std::lock_guard<std::mutex> lock(g_poolMutex);
+    DevicePool *&p = pools()[device];
+    if (!p) p = new DevicePool();
+    return *p;
+}
+// the pool's build stream, created on first use (callers hold no lock)
+static hipError_t pool_build_stream(DevicePool &pool, hipStream_t *out)
+{
+    std::lock_guard<std::mutex> lock(pool.m);
+    if (!pool.build) {
+        const hipError_t e = hipStreamCreateWithFlags(&pool.build, hipStreamNonBlocking);
+        if (e != hipSuccess) return e;
+    }
+    *out = pool.build;
+    return hipSuccess;
+}
+// the side streams and their events; under pool.m.  A failure leaves the pool without them (passes then run in-stream).
+static void pool_create_sides(DevicePool &pool)
+{
+    hipError_t e = hipSuccess;
+    for (int k = 0; k < DevicePool::kSideSlots && e == hipSuccess; ++k) {
+        // (Default priority.  Created with the highest priority -- so that the pass's few hundred short workgroups would go first
+        // -- the mere existence of such streams cost EVERY kernel of the process a third to a half of its rate: config 3 162 ->
+        // 270 us, its fast mode 98 -> 217 us, 8:1 171 -> 329 us: profiles/r04_fixup_beside.txt.)
+        e = hipStreamCreateWithFlags(&pool.side[k], hipStreamNonBlocking);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&pool.fork[k], hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&pool.join[k], hipEventDisableTiming);
+    }
+    if (e == hipSuccess) pool.sideReady = true;
+    else { (void)hipGetLastError(); pool.sideFailed = true; }
+}
+
 void drop_plans()
 {
     std::list<PlanRef> gone;
@@ -52,13 +92,31 @@ void drop_plans()
         gone.swap(plan_cache());
     }
     gone.clear();                     // frees device memory of every plan nobody is launching from
+    // ... and the pools' streams and events (created again on the next need)
+    std::lock_guard<std::mutex> lock(g_poolMutex);
+    int current = -1;
+    (void)hipGetDevice(&current);
+    for (auto &kv : pools()) {
+        DevicePool &pool = *kv.second;
+        std::lock_guard<std::mutex> plock(pool.m);
+        if (hipSetDevice(kv.first) != hipSuccess) { (void)hipGetLastError(); continue; }
+        if (pool.build) { (void)hipStreamSynchronize(pool.build); (void)hipStreamDestroy(pool.build); pool.build = nullptr; }
+        for (int k = 0; k < DevicePool::kSideSlots; ++k) {
+            if (pool.side[k]) { (void)hipStreamSynchronize(pool.side[k]); (void)hipStreamDestroy(pool.side[k]); pool.side[k] = nullptr; }
+            if (pool.fork[k]) { (void)hipEventDestroy(pool.fork[k]); pool.fork[k] = nullptr; }
+            if (pool.join[k]) { (void)hipEventDestroy(pool.join[k]); pool.join[k] = nullptr; }
+        }
+        pool.sideReady = false; pool.sideFailed = false; pool.besideLaunches = 0;
+    }
+    if (current >= 0) (void)hipSetDevice(current);
 }
 constexpr size_t kMaxPlans = 32;       // per device
 constexpr unsigned kMaxListedPixels = 1u << 24;      // beyond 16 M flagged pixels the whole image takes the double-precision pass
 
 bool same_request(const aai_request &a, const aai_request &b)
 {
-    return a.mode == b.mode && a.policy == b.policy && a.src_width == b.src_width && a.src_height == b.src_height &&
+    // (AAI_POLICY_DIAG_NO_FIXUP is a property of a launch, not of the plan: with and without it a request shares one plan)
+    return a.mode == b.mode && (a.policy & ~AAI_POLICY_DIAG_NO_FIXUP) == (b.policy & ~AAI_POLICY_DIAG_NO_FIXUP) && a.src_width == b.src_width && a.src_height == b.src_height &&
            a.src_res_x == b.src_res_x && a.src_res_y == b.src_res_y && a.dst_res_x == b.dst_res_x &&
            a.dst_res_y == b.dst_res_y && a.src_iso_x == b.src_iso_x && a.src_iso_y == b.src_iso_y &&
            a.rotation_deg == b.rotation_deg;
@@ -68,8 +126,9 @@ int check_request(const aai_request *rq)
 {
     if (!rq) return fail(AAI_ERR_BAD_ARGUMENT, "Null request.");
     if (rq->mode < AAI_MODE_AREA || rq->mode > AAI_MODE_BICUBIC) return fail(AAI_ERR_BAD_ARGUMENT, "Unknown interpolation mode.");
-    const int rule = rq->policy & ~AAI_POLICY_DOUBLE_PRECISION;
-    if (rule != AAI_POLICY_REFERENCE && rule != AAI_POLICY_EXACT) return fail(AAI_ERR_BAD_ARGUMENT, "Unknown weight policy.");
+    const int rule = rq->policy & AAI_POLICY_RULE_MASK;
+    const int known = AAI_POLICY_RULE_MASK | AAI_POLICY_DOUBLE_PRECISION | AAI_POLICY_PREFER_CELL | AAI_POLICY_DIAG_NO_FIXUP;
+    if ((rule != AAI_POLICY_REFERENCE && rule != AAI_POLICY_EXACT) || (rq->policy & ~known)) return fail(AAI_ERR_BAD_ARGUMENT, "Unknown weight policy.");
     return AAI_OK;
 }
 
@@ -223,7 +282,7 @@ static void tune_axis_plan(Plan &p, int channels, int band0, hipStream_t stream)
 }
 
 // Everything a fresh plan needs from the device; the caller holds p.build, not the cache's lock.
-static int build_plan(Plan &p)
+static int build_plan(Plan &p, hipStream_t bs)
 {
     const aai_request &rq = p.key;
     const aai::Geometry &g = p.g;
@@ -237,10 +296,10 @@ static int build_plan(Plan &p)
         fprintf(stderr, "[aai plan] %-28s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(now - tick).count());
         tick = now;
     };
-    hipStream_t bs = nullptr;                                        // a private stream: never the caller's, never the NULL stream
-    AAI_HIP(hipStreamCreateWithFlags(&bs, hipStreamNonBlocking));
-    stage("private stream");
-    struct StreamGuard { hipStream_t s; ~StreamGuard() { if (s) { (void)hipStreamSynchronize(s); (void)hipStreamDestroy(s); } } } guard{bs};
+    // (bs: the caller's stream, or the device pool's build stream -- no stream is created or destroyed here; whatever was
+    // enqueued is complete when this returns, also on failure)
+    std::vector<int> spans;                                          // (declared before the guard: alive until the stream is synchronised)
+    struct StreamGuard { hipStream_t s; ~StreamGuard() { (void)hipStreamSynchronize(s); } } guard{bs};
     if (p.kernel == AAI_KERNEL_AXIS) {
         aai::build_axis_tables(g, rq.mode, p.tabs, channels);
         if (band0 >= 0) aai::restrict_axis_tables_to_band(g, p.tabs, band0, band1, p.srcRow0, p.srcRow1, axis_band_margin(rq));
@@ -262,12 +321,11 @@ static int build_plan(Plan &p)
     }
     if (p.kernel == AAI_KERNEL_ROTATED || p.kernel == AAI_KERNEL_FAST || p.kernel == AAI_KERNEL_SAMPLE) {
         // the corners of a rotated canvas hold nothing: which tiles of each tile row can (the whole image's table; bands index it by row)
-        std::vector<int> spans;
         aai::rotated_live_spans(aai::make_rot_launch(g, rq.mode, rq.policy), p.kernel == AAI_KERNEL_SAMPLE, spans);
         if (!spans.empty()) {
+            // (no synchronisation of its own: `spans` lives until the stream has been synchronised at the end of the build)
             hipError_t e = hipMalloc((void **)&p.dLive, spans.size() * sizeof(int));
             if (e == hipSuccess) e = hipMemcpyAsync(p.dLive, spans.data(), spans.size() * sizeof(int), hipMemcpyHostToDevice, bs);
-            if (e == hipSuccess) e = hipStreamSynchronize(bs);
             if (e != hipSuccess) return hip_fail(e, "uploading the live tile spans");
         }
         stage("live tile spans");
@@ -279,8 +337,8 @@ static int build_plan(Plan &p)
     if (p.kernel == AAI_KERNEL_ROTATED || p.kernel == AAI_KERNEL_FAST || verifyAxis) {
         const aai::RotLaunch r = aai::make_rot_launch(g, rq.mode, rq.policy);
         // (AAI_MAX_LISTED_PIXELS: test hook, lowers the threshold so that small geometries exercise the dense form)
-        static const unsigned maxListed = [] { const char *v = getenv("AAI_MAX_LISTED_PIXELS"); return v ? (unsigned)strtoul(v, nullptr, 10) : kMaxListedPixels; }();
-        static const bool classVerify = [] { const char *v = getenv("AAI_AXIS_CLASS_VERIFY"); return !(v && atoi(v) == 0); }();
+        static const unsigned maxListed = [] { const char *v = getenv("AAI_MAX_LISTED_PIXELS"); return v ? (unsigned)strtoul(v, nullptr, 10) : kMaxListedPixels; }();      // documented in include/aai.h
+        static const bool classVerify = [] { const char *v = aai::experiment_env("AAI_AXIS_CLASS_VERIFY"); return !(v && atoi(v) == 0); }();
         std::vector<std::pair<int, int>> hostPixels;
         bool hostDense = false;
         if (verifyAxis && classVerify && aai::axis_verify_by_class(r, hostPixels, hostDense, maxListed)) {
@@ -301,14 +359,20 @@ static int build_plan(Plan &p)
         // one-off scans of this geometry (rotated: aai_knife_scan_kernel, and the scan of the fp32 formulation that serves
         // it; axis-aligned: aai_axis_verify_kernel); keeps the list of flagged pixels only if there are any
         const size_t waves = aai::rotated_flag_words(r);
-        unsigned long long *dMasks = nullptr;
-        unsigned *dCount = nullptr;
         unsigned count = 0;
         hipError_t e = hipSuccess;
         if (waves) {
-            e = hipMalloc((void **)&dMasks, waves * sizeof(unsigned long long));
-            if (e == hipSuccess) e = hipMalloc((void **)&dCount, sizeof(unsigned));
-            if (e == hipSuccess) e = hipMemsetAsync(dCount, 0, sizeof(unsigned), bs);
+            // ONE allocation: lane masks | tile flags (one bit per 16 x 16 tile) | the scans' counter / the list's cursor
+            const unsigned tilesX = (unsigned)((g.dW + 15) / 16), tilesY = (unsigned)((g.dH + 15) / 16);
+            const int tileFlagWords = (int)aai::tile_flag_row_words(tilesX);
+            const size_t maskBytes = waves * sizeof(unsigned long long);
+            const size_t tileBytes = ((size_t)tilesY * (size_t)tileFlagWords * sizeof(unsigned) + 15) & ~(size_t)15;
+            char *block = nullptr;
+            e = hipMalloc((void **)&block, maskBytes + tileBytes + 16);
+            unsigned long long *dMasks = reinterpret_cast<unsigned long long *>(block);
+            unsigned *dTiles = reinterpret_cast<unsigned *>(block + maskBytes), *dCount = reinterpret_cast<unsigned *>(block + maskBytes + tileBytes);
+            // (the scans write every lane-mask word they own; tile flags and the counter start at zero)
+            if (e == hipSuccess) e = hipMemsetAsync(dTiles, 0, tileBytes + 16, bs);
             if (e == hipSuccess) e = verifyAxis ? aai::launch_axis_verify(r, dMasks, dCount, bs) : aai::launch_knife_scan(r, dMasks, dCount, bs);
             if (e == hipSuccess && r.quad) e = form == aai::ROT_FORM_CELL ? aai::launch_cell_scan(r, dMasks, dCount, bs) : aai::launch_quad_scan(r, dMasks, dCount, bs);
             if (e == hipSuccess && r.wide && !verifyAxis) e = aai::launch_wide_scan(r, dMasks, dCount, bs);
@@ -319,31 +383,18 @@ static int build_plan(Plan &p)
             if (e == hipSuccess && count) {
                 e = hipMalloc(&p.dList, (size_t)count * 2 * sizeof(unsigned));
                 if (e == hipSuccess) e = hipMemsetAsync(dCount, 0, sizeof(unsigned), bs);
-                if (e == hipSuccess) e = aai::launch_flag_list(dMasks, waves, (unsigned)((g.dW + 15) / 16), p.dList, dCount, count, bs);
-                if (e == hipSuccess) e = hipStreamSynchronize(bs);
-            }
-            if (dCount) (void)hipFree(dCount);
-            stage("flag list");
-            if (e == hipSuccess && count && (r.quad || r.wide)) {
-                // keep the masks: the fp32 kernel skips the flagged pixels and the fix-up pass runs beside it
-                p.dMasks = dMasks;
-                dMasks = nullptr;
-                // ... and asks for the per-pixel masks only in tiles that hold a flagged pixel: one bit per 16 x 16 tile
-                const unsigned tilesX = (unsigned)((g.dW + 15) / 16), tilesY = (unsigned)((g.dH + 15) / 16);
-                p.tileFlagWords = (int)aai::tile_flag_row_words(tilesX);
-                const size_t bytes = (size_t)tilesY * (size_t)p.tileFlagWords * sizeof(unsigned);
-                e = hipMalloc((void **)&p.dTileFlags, bytes);
-                if (e == hipSuccess) e = hipMemsetAsync(p.dTileFlags, 0, bytes, bs);
-                if (e == hipSuccess) e = aai::launch_tile_flags(p.dMasks, tilesX, tilesY, p.dTileFlags, bs);
-                if (e == hipSuccess) e = hipStreamSynchronize(bs);
-                for (int k = 0; k < Plan::kSideSlots && e == hipSuccess; ++k) {
-                    e = hipStreamCreateWithFlags(&p.side[k], hipStreamNonBlocking);
-                    if (e == hipSuccess) e = hipEventCreateWithFlags(&p.fork[k], hipEventDisableTiming);
-                    if (e == hipSuccess) e = hipEventCreateWithFlags(&p.join[k], hipEventDisableTiming);
+                if (e == hipSuccess) e = aai::launch_flag_list(dMasks, waves, tilesX, p.dList, dCount, count, bs);
+                if (e == hipSuccess && (r.quad || r.wide)) {
+                    // keep the masks: the fp32 kernel skips the flagged pixels (the fix-up pass runs beside it) and asks for the
+                    // per-pixel masks only in tiles that hold a flagged pixel
+                    p.dScan = block; p.dMasks = dMasks; p.dTileFlags = dTiles; p.tileFlagWords = tileFlagWords;
+                    block = nullptr;
+                    e = aai::launch_tile_flags(p.dMasks, tilesX, tilesY, p.dTileFlags, bs);
                 }
+                if (e == hipSuccess) e = hipStreamSynchronize(bs);
             }
-            if (dMasks) (void)hipFree(dMasks);
-            stage("side stream + events");
+            if (block) (void)hipFree(block);
+            stage("flag list + tile flags");
         }
         if (e != hipSuccess) return hip_fail(e, verifyAxis ? "axis model scan" : "knife-edge scan");
         p.flaggedPixels = count;
@@ -359,7 +410,7 @@ int rot_form(const aai_request &rq, const aai::Geometry &g, int channels, int sr
     return aai::cell_can_serve(r, srcType, aai::ImageView{srcStride, 0}) ? aai::ROT_FORM_CELL : aai::ROT_FORM_QUAD;
 }
 
-int acquire_plan(const aai_request &rq, int band0, int band1, int channels, int form, PlanRef *out)
+int acquire_plan(const aai_request &rq, int band0, int band1, int channels, int form, PlanRef *out, bool onCallerStream, hipStream_t stream)
 {
     int dev = -1;
     AAI_HIP(hipGetDevice(&dev));
@@ -405,7 +456,20 @@ int acquire_plan(const aai_request &rq, int band0, int band1, int channels, int 
         std::lock_guard<std::mutex> lock(p->build);
         if (!p->built) {
             const auto t0 = std::chrono::steady_clock::now();
-            p->buildRc = build_plan(*p);
+            // where the build's kernels and copies go: the caller's stream when there is one to use (the resampling entry points;
+            // not while it is being captured into a graph: the build synchronises), else the device pool's build stream
+            hipStream_t bs = stream;
+            bool own = onCallerStream;
+            if (own) {
+                hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+                if (hipStreamIsCapturing(stream, &cap) != hipSuccess) (void)hipGetLastError();
+                if (cap != hipStreamCaptureStatusNone) own = false;
+            }
+            if (!own) {
+                const hipError_t e = pool_build_stream(device_pool(dev), &bs);
+                if (e != hipSuccess) { p->buildRc = hip_fail(e, "creating the build stream"); p->buildError = g_lastError; }
+            }
+            if (p->buildRc == AAI_OK) p->buildRc = build_plan(*p, bs);
             p->buildMs = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
             p->buildError = p->buildRc == AAI_OK ? std::string() : g_lastError;
             p->built = true;
@@ -458,7 +522,7 @@ int enqueue(const aai_request &rq, int batch, const void *dSrc, int srcType, int
         std::string msg;
         rc = aai::make_geometry(rq, g0, msg);
         if (rc != AAI_OK) return fail(rc, msg);
-        rc = acquire_plan(rq, band0, band1, channels, rot_form(rq, g0, channels, srcType, srcStride), &p);
+        rc = acquire_plan(rq, band0, band1, channels, rot_form(rq, g0, channels, srcType, srcStride), &p, /*onCallerStream*/ true, stream);
     }
     if (rc != AAI_OK) return rc;
     // launches only enqueue; the plan's side stream and fork / join events are shared by its callers, hence the plan's lock
@@ -500,8 +564,21 @@ int enqueue(const aai_request &rq, int batch, const void *dSrc, int srcType, int
         const aai::QuadMap qm = aai::make_quad_map(g, srcStride, r.srcRow0, channels, srcType == aai::SRC_U8 ? 1 : srcType == aai::SRC_U16 ? 2 : 4);
         aai::RotFlags flags;
         flags.list = p->dList; flags.count = p->flaggedPixels; flags.dense = p->dense;
-        const unsigned slot = p->nextSide++ % Plan::kSideSlots;      // (under p->launch)
-        flags.masks = p->dMasks; flags.tileFlags = p->dTileFlags; flags.tileFlagWords = p->tileFlagWords; flags.live = p->dLive; flags.side = p->side[slot]; flags.fork = p->fork[slot]; flags.join = p->join[slot]; flags.form = p->form;
+        flags.masks = p->dMasks; flags.tileFlags = p->dTileFlags; flags.tileFlagWords = p->tileFlagWords; flags.live = p->dLive; flags.form = p->form;
+        // A production kernel that skips the plan's listed pixels has the fix-up pass BESIDE it on a side stream of the device's
+        // pool (fork / join events; the pool's lock is held while the launch is enqueued).  The pool's side streams are created by
+        // the second such launch of the process: until then -- for the one call the reference's user makes -- the pass runs behind
+        // the production kernel on the caller's stream, which then computes the listed pixels too and has them overwritten.
+        DevicePool &pool = device_pool(p->device);
+        std::unique_lock<std::mutex> poolLock(pool.m, std::defer_lock);
+        if (p->flaggedPixels && p->dMasks && !p->dense) {
+            poolLock.lock();
+            if (!pool.sideReady && !pool.sideFailed && ++pool.besideLaunches >= 2) pool_create_sides(pool);
+            if (pool.sideReady) {
+                const unsigned slot = pool.nextSide++ % DevicePool::kSideSlots;
+                flags.side = pool.side[slot]; flags.fork = pool.fork[slot]; flags.join = pool.join[slot];
+            } else poolLock.unlock();
+        }
         e = hipSuccess;
         for (int b0 = 0; b0 < batch && e == hipSuccess; b0 += kMaxGridZ)
             e = aai::launch_rotated(r, qm, src_at(dSrc, srcType, (int64_t)b0 * srcImageStride), srcType, sv, dDst + (int64_t)b0 * dstImageStride, dv,

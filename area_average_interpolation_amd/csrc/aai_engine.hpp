@@ -47,34 +47,24 @@ struct Plan {
     void *dList = nullptr;
     unsigned flaggedPixels = 0;
     bool dense = false;
-    // fp32 rotated kernels: the lane masks of the flagged pixels (they skip them) and the side stream the fix-up pass runs on
-    unsigned long long *dMasks = nullptr;
-    unsigned *dTileFlags = nullptr;  // one bit per 16 x 16 tile with a flagged pixel (aai::launch_tile_flags), tileFlagWords words per tile row
+    // fp32 rotated kernels: the lane masks of the flagged pixels (they skip them; the fix-up pass runs beside them on a side stream of
+    // the device's pool)
+    void *dScan = nullptr;           // ONE allocation: lane masks | tile flags | the scans' counter
+    unsigned long long *dMasks = nullptr;      // (into dScan)
+    unsigned *dTileFlags = nullptr;  // (into dScan) one bit per 16 x 16 tile with a flagged pixel (aai::launch_tile_flags), tileFlagWords words per tile row
     int tileFlagWords = 0;
     int *dLive = nullptr;            // per-pixel kernels on a rotated canvas: live tile span per tile row (aai::rotated_live_spans), or none
-    // (kSideSlots of them, dealt round-robin per call under `launch`: the fix-up passes of callers on different streams run beside
-    // each other instead of queueing on one stream)
-    static constexpr int kSideSlots = 4;
-    hipStream_t side[kSideSlots] = {};
-    hipEvent_t fork[kSideSlots] = {}, join[kSideSlots] = {};
-    unsigned nextSide = 0;
     double buildMs = 0.0;            // wall clock of build_plan (tables, scans, launch-shape measurement)
     // Built once, by whoever gets here first, under `build` -- NOT under the cache's lock: other requests, other devices
-    // and other threads are not held up by this plan's scans or launch-shape measurement.  `launch` serialises the use of
-    // the plan's side stream and fork / join events between caller streams.
+    // and other threads are not held up by this plan's scans or launch-shape measurement.  `launch` serialises the launches of a
+    // plan between caller threads.
     std::mutex build, launch;
     bool built = false;
     int buildRc = AAI_OK;
     std::string buildError;
     ~Plan()
     {
-        for (int k = 0; k < kSideSlots; ++k) {
-            if (side[k]) { (void)hipStreamSynchronize(side[k]); (void)hipStreamDestroy(side[k]); }
-            if (fork[k]) (void)hipEventDestroy(fork[k]);
-            if (join[k]) (void)hipEventDestroy(join[k]);
-        }
-        if (dMasks) (void)hipFree(dMasks);
-        if (dTileFlags) (void)hipFree(dTileFlags);
+        if (dScan) (void)hipFree(dScan);
         if (dLive) (void)hipFree(dLive);
         if (dList) (void)hipFree(dList);
         if (dLane) (void)hipFree(dLane);
@@ -83,6 +73,26 @@ struct Plan {
     }
 };
 typedef std::shared_ptr<Plan> PlanRef;
+
+// Streams and events the engine needs beside the callers' own, ONE set per device and process, created on first need: creating a
+// stream costs 2.7 ... 5 ms of host time on this platform (a hardware queue each; profiles/r04_plan_time.txt), which at one private
+// stream and four side streams per PLAN was 16 of the 19 ms a first rotated call took.
+//   build   aai_prepare's stream (the resampling entry points build a missing plan on the CALLER's stream instead)
+//   side[]  the fix-up pass beside a production kernel that skips the plan's listed pixels: dealt round-robin per launch, each with
+//           its fork / join events, so that the passes of callers on different streams run beside each other.  Created by the SECOND
+//           launch that wants them: a process that makes one call (the reference's user, Source.cpp:1565) runs its pass behind the
+//           production kernel (~10 us) and never pays the ~11 ms.
+// `m` guards creation and the slot rotation and is held while a launch with a pass beside it is being enqueued (fork ... join).
+struct DevicePool {
+    static constexpr int kSideSlots = 4;
+    std::mutex m;
+    hipStream_t build = nullptr;
+    hipStream_t side[kSideSlots] = {};
+    hipEvent_t fork[kSideSlots] = {}, join[kSideSlots] = {};
+    bool sideReady = false, sideFailed = false;
+    unsigned besideLaunches = 0, nextSide = 0;
+};
+DevicePool &device_pool(int device);      // (heap, never destroyed; aai_shutdown releases the streams while the runtime is alive)
 
 // The cache (most recently used first) lives on the heap and is never destroyed: a static destructor would call into HIP
 // after the runtime's own teardown.  aai_shutdown() empties it while the runtime is alive.
@@ -99,9 +109,10 @@ void fill_layout(const Geometry &g, int kernel, aai_layout *out);
 int require_device();
 
 // Finds the plan for (request, current device) or inserts a fresh one, then builds it if nobody has (blocking: table
-// uploads, the one-off scans, K1's launch-shape measurement -- on a private stream).
+// uploads, the one-off scans, K1's launch-shape measurement -- on `stream` when the caller has one to give (onCallerStream; a
+// stream that is being captured into a graph is not used), else on the device pool's build stream).
 // form: aai::RotForm of a rotated request's launch (rot_form below); ignored by the other kernels
-int acquire_plan(const aai_request &rq, int band0, int band1, int channels, int form, PlanRef *out);
+int acquire_plan(const aai_request &rq, int band0, int band1, int channels, int form, PlanRef *out, bool onCallerStream = false, hipStream_t stream = nullptr);
 // "kernel=K rows=R nt=N swap=S tune=T flagged=F dense=D form=M build_ms=B" of the cached whole-image plan ("" when there is none)
 std::string plan_description(const aai_request &rq, int channels);
 // which fp32 formulation serves a launch of this request: the cell formulation takes plain images below 4 GiB in area mode

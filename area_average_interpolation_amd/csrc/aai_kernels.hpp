@@ -79,7 +79,6 @@ struct RotFlags {
 };
 enum RotForm { ROT_FORM_QUAD = 0, ROT_FORM_CELL = 1 };
 size_t rotated_flag_words(const RotLaunch &r);      // waves of the tiling = 64-bit words of the mask array
-void set_skip_fixup(bool skip);                      // tests only: leave the flagged pixels unwritten (aai_debug_skip_fixup)
 hipError_t launch_knife_scan(const RotLaunch &r, unsigned long long *laneMasks, unsigned *counter, hipStream_t stream);
 // the double-precision fix-up pass over a list of dst pixels (defined in aai_rotated_strict.hip);
 // pixelList == NULL: the whole image (grid as for the production pass, at most 65535 tile rows)
@@ -109,7 +108,6 @@ hipError_t launch_wide(const RotLaunch &r, const QuadMap &m, const void *src, in
 
 // the cell formulation (aai_rotated_cell.hip): one lane per cell of the dst grid, every (dst, src) pair evaluated once
 bool cell_can_serve(const RotLaunch &r, int srcType, ImageView sv);      // r.chan set; plain images below 4 GiB, area mode
-void set_cell_min_waves(int waves);      // tests / experiments: outputs of fewer cell waves than this stay on the quad kernel (default 1024; < 0 restores it)
 hipError_t launch_cell_scan(const RotLaunch &r, unsigned long long *laneMasks, unsigned *counter, hipStream_t stream);
 hipError_t launch_cell(const RotLaunch &r, const QuadMap &m, const void *src, int srcType, ImageView sv, float *dst, ImageView dv,
                        int batch, const unsigned long long *skipMasks, hipStream_t stream);

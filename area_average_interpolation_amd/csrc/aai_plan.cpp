@@ -131,7 +131,8 @@ RotLaunch make_rot_launch(const Geometry &g, int mode, int policy)
     r.offX = g.offX; r.offY = g.offY; r.sn = g.sn; r.cs = g.cs;
     r.reach = g.side * std::sqrt(2.0) / 2 + 1;
     r.dW = g.dW; r.dH = g.dH; r.mW = g.mW; r.mH = g.mH; r.W = g.W; r.H = g.H;
-    r.scale = g.scale; r.quadrant = g.quadrant; r.mode = mode; r.policy = policy & ~AAI_POLICY_DOUBLE_PRECISION;
+    r.scale = g.scale; r.quadrant = g.quadrant; r.mode = mode; r.policy = policy & AAI_POLICY_RULE_MASK;
+    r.preferCell = (policy & AAI_POLICY_PREFER_CELL) ? 1 : 0; r.noFixup = (policy & AAI_POLICY_DIAG_NO_FIXUP) ? 1 : 0;
     r.dyBase = 0; r.dyEnd = g.dH; r.srcRow0 = 0; r.chan = 1;
     r.invScale = 1.0 / g.scale;
     const double c = g.cs, s = g.sn, h = 0.5 * g.side;
@@ -158,6 +159,9 @@ RotLaunch make_rot_launch(const Geometry &g, int mode, int policy)
               quad_supported(g.side, c, s)) ? 1 : 0;
     // (fast mode's window holds pixel centres only and is two positions narrower: one 8 x 8 window reaches a little further)
     if (mode == AAI_MODE_FAST && !(policy & AAI_POLICY_DOUBLE_PRECISION) && c > 0.0 && s > 0.0 && quad_fast_parts(g.side, c, s) == 1) r.quad = 1;
+    // (the window kernels map a replicated lattice back to source pixels with fp32 quotients, exact below 2^22 pixels a side:
+    // QuadSrc::issue; a wider replicated lattice -- a source of 700,000 pixels a side and more -- stays in double precision)
+    if (g.scale > 1 && (g.mW >= (1 << 22) || g.mH >= (1 << 22))) r.quad = 0;
     // (Fast mode with replication used to stay on the fp64 line-walking kernel: the 4 x 4 ... 5 x 5 area-mode window fetched
     // too much.  With the centre-only window of round 3 -- 3 x 3 at x4 up-sampling -- the window kernel wins everywhere
     // measured: x4 at 45 degrees 2.75 -> 2.67 ms, x2 at 30 0.68 -> 0.59, 1:1 at 61 0.212 -> 0.204, x3 at 17.5 0.37 -> 0.29:
@@ -212,6 +216,16 @@ QuadMap make_quad_map(const Geometry &g, int64_t rowStride, int srcRow0, int cha
     const int64_t bytes = ((int64_t)(g.H - 1) * rowStride + (int64_t)g.W * channels) * elementBytes;      // of the whole image
     m.lastLoad4 = (uint32_t)std::max<int64_t>(0, std::min<int64_t>(bytes - 4, 0xffffffffll));
     m.lastLoad8 = (uint32_t)std::max<int64_t>(0, std::min<int64_t>(bytes - 8, 0xffffffffll));
+    if (g.scale == 1 && channels == 1 && elementBytes == 4 && g.mW < (1 << 23) && g.mH < (1 << 23)) {
+        const uint32_t sxb = (uint32_t)m.strideX * 4u, syb = (uint32_t)m.strideY * 4u;
+        m.fastOk = 1;
+        m.fastAlongX = m.strideX == 1 ? 1 : 0;
+        m.fastSX = m.flipX ? 0u - sxb : sxb;
+        m.fastSY = m.flipY ? 0u - syb : syb;
+        m.fastC0 = (m.flipX ? (uint32_t)(m.nX - 1) * sxb : 0u) + (m.flipY ? (uint32_t)(m.nY - 1) * syb : 0u);
+        m.fastLine = m.fastAlongX ? m.fastSY : m.fastSX;
+        m.fastRev4 = (m.fastAlongX ? m.flipX : m.flipY) ? 4u : 0u;
+    }
     return m;
 }
 

@@ -76,6 +76,13 @@ struct QuadMap {
     // a wave of the cell kernel asks for the per-pixel masks only where there is something to find; NULL = no summary
     const unsigned *tileFlags;
     int tileFlagWords;
+    // Plain fp32 images without replication, a window wholly inside the lattice (QuadSrc::issue's common case): the byte offset of
+    // the first element of the window's first line IN MEMORY ORDER is fastC0 + X fastSX + Y fastSY - (WIN - 1) fastRev4 (mod 2^32,
+    // (X, Y) = virtual pixel of window position (0, 0)), its lines follow fastLine bytes apart.  fastOk: the fields are valid (lattice
+    // below 2^23 pixels a side, so that a 24-bit multiply serves the contiguous axis).
+    // (last in the struct: kernels that never read them do not pull them into scalar registers with their neighbours)
+    uint32_t fastC0, fastSX, fastSY, fastLine, fastRev4;
+    int fastAlongX, fastOk;      // fastAlongX: the contiguous axis is virtual X (quadrants 0 / 2)
 };
 QuadMap make_quad_map(const Geometry &g, int64_t rowStride, int srcRow0, int channels = 1, int elementBytes = 4);      // channels: elements per pixel (interleaved)
 

@@ -52,24 +52,21 @@ struct QuadSrc {
         unsigned colOff[WIN], rowOff[WIN];            // source indices along virtual X / Y first, byte offsets below
         const unsigned sxb = (unsigned)m->strideX * (unsigned)sizeof(T), syb = (unsigned)m->strideY * (unsigned)sizeof(T);
         arranged = 0;
-        if (!SCALED && STAGED && allInside && sizeof(T) == 4 && m->anchorRows == 0) {
+        if (!SCALED && STAGED && allInside && sizeof(T) == 4 && m->anchorRows == 0 && m->fastOk) {
             // The common case of the staged kernels, spelt out: every window of the wave inside the lattice, so no clamps, and the
             // WIN lines (the window axis that is contiguous in memory: virtual X in quadrants 0 / 2, virtual Y in 1 / 3) start a
-            // wave-uniform number of bytes apart -- ONE per-lane byte offset (a multiply and a shift-add) and WIN wave-uniform base
-            // pointers (scalar, loop-invariant) instead of 2 WIN offsets, multiplies and adds per lane
-            const bool alongX = sxb == (unsigned)sizeof(T);
-            const bool rev = alongX ? m->flipX != 0 : m->flipY != 0;      // the window axis runs against memory
-            const int bx = m->flipX ? m->nX - 1 - xg0 : xg0, by = m->flipY ? m->nY - 1 - yg0 : yg0;      // source indices of position (0, 0)
-            const int along = alongX ? bx : by, across = alongX ? by : bx;
-            const unsigned acrossStride = alongX ? syb : sxb;
-            const int acrossDir = alongX ? (m->flipY ? -1 : 1) : (m->flipX ? -1 : 1);
-            const unsigned base = (unsigned)across * acrossStride + (unsigned)(rev ? along - (WIN - 1) : along) * (unsigned)sizeof(T);
-            const int64_t lineStep = (int64_t)acrossDir * (int64_t)acrossStride;                          // wave-uniform
-            arranged = 1 + (alongX ? 0 : 2) + (rev ? 1 : 0);
+            // wave-uniform number of bytes apart -- ONE per-lane byte offset from the host-composed coefficients of the map
+            // (QuadMap::fastC0 ...: a multiply along the strided axis, a 24-bit multiply-add along the contiguous one) and one add per
+            // further line, instead of 2 WIN clamped indices, flips, multiplies and adds per lane
+            const uint32_t across = (uint32_t)(m->fastAlongX ? yg0 : xg0) * (m->fastAlongX ? m->fastSY : m->fastSX);
+            const int alongStep = (int)(m->fastAlongX ? m->fastSX : m->fastSY);                            // +4 or -4
+            uint32_t line = (uint32_t)(__mul24(m->fastAlongX ? xg0 : yg0, alongStep) + (int)(across + (m->fastC0 - (uint32_t)(WIN - 1) * m->fastRev4)));
+            arranged = 1 + (m->fastAlongX ? 0 : 2) + (m->fastRev4 ? 1 : 0);
 #pragma unroll
             for (int k = 0; k < WIN; ++k) {
                 float seg[WIN];
-                load_line<WIN>(reinterpret_cast<const float *>(img + (int64_t)k * lineStep + base), seg);
+                load_line<WIN>(reinterpret_cast<const float *>(img + line), seg);
+                line += m->fastLine;
 #pragma unroll
                 for (int e = 0; e < WIN; ++e) v[k * WIN + e] = (T)seg[e];
             }
@@ -78,16 +75,17 @@ struct QuadSrc {
         if (SCALED && allInside && WIN - 1 <= m->scale && m->anchorRows == 0) {
             // Replicated pixels, window no wider than a source pixel plus one: it spans at most two source columns and two
             // source rows -- four loads, and every position selects its value by which side of the split it lies on
-            // (x >= 0 here, so (x + 0.5) / scale is at least 0.5 / scale away from an integer: the floor is exact -- in fp32 too
-            // while the lattice is narrower than 2^22: the quotient's rounding error, 2^-24 x, stays below 0.5 / scale; wave-uniform)
+            // (x >= 0 here, so (x + 0.5) / scale is at least 0.5 / scale away from an integer: the floor is exact -- in fp32 too,
+            // because the planner sends replicated lattices of 2^22 pixels a side and more to the double-precision kernels
+            // (make_rot_launch): the quotient's rounding error, 2^-23 x / scale, stays below 0.5 / scale)
             const int scale = m->scale;
-            const bool f32ok = mW < (1 << 22) && mH < (1 << 22);
-            const int qx0 = f32ok ? (int)(((float)xg0 + 0.5f) * m->invScale) : (int)(((double)xg0 + 0.5) * m->invScaleD);
-            const int qy0 = f32ok ? (int)(((float)yg0 + 0.5f) * m->invScale) : (int)(((double)yg0 + 0.5) * m->invScaleD);
-            const int splitX = scale - (xg0 - qx0 * scale), splitY = scale - (yg0 - qy0 * scale);      // in [1, scale]: first column / row of the second source pixel
-            const int qx1 = splitX < WIN ? qx0 + 1 : qx0, qy1 = splitY < WIN ? qy0 + 1 : qy0;          // (never fetched from outside the image)
-            const unsigned c0 = (unsigned)(m->flipX ? m->nX - 1 - qx0 : qx0) * sxb, c1 = (unsigned)(m->flipX ? m->nX - 1 - qx1 : qx1) * sxb;
-            const unsigned r0 = (unsigned)(m->flipY ? m->nY - 1 - qy0 : qy0) * syb, r1 = (unsigned)(m->flipY ? m->nY - 1 - qy1 : qy1) * syb;
+            const int qx0 = (int)(((float)xg0 + 0.5f) * m->invScale), qy0 = (int)(((float)yg0 + 0.5f) * m->invScale);
+            const int splitX = scale - (xg0 - __mul24(qx0, scale)), splitY = scale - (yg0 - __mul24(qy0, scale));      // in [1, scale]: first column / row of the second source pixel
+            const int ux0 = m->flipX ? m->nX - 1 - qx0 : qx0, uy0 = m->flipY ? m->nY - 1 - qy0 : qy0;
+            const unsigned c0 = (unsigned)ux0 * sxb, r0 = (unsigned)uy0 * syb;
+            // the second source pixel, where the window reaches it, is one step along the (possibly flipped) axis (never fetched from
+            // outside the image)
+            const unsigned c1 = splitX < WIN ? (m->flipX ? c0 - sxb : c0 + sxb) : c0, r1 = splitY < WIN ? (m->flipY ? r0 - syb : r0 + syb) : r0;
             const T v00 = *reinterpret_cast<const T *>(img + (c0 + r0)), v10 = *reinterpret_cast<const T *>(img + (c1 + r0));
             const T v01 = *reinterpret_cast<const T *>(img + (c0 + r1)), v11 = *reinterpret_cast<const T *>(img + (c1 + r1));
             T top[WIN], bottom[WIN];

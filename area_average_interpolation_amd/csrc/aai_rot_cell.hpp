@@ -102,6 +102,32 @@ AAI_HD void cell_cut_small(const QuadConsts<F> &q, F tp, F &exact, F &ref)
     ref = tri ? (q.ref != 0 ? triRef : triExact) : trap;
 }
 
+// The pixel that holds G: the four rays from G (along +a = (c, -s), +b = (s, c), -a, -b in lattice axes, y down) cut it into the
+// parts of the four dst pixels around G.  Area of a part = half the sum over the pixel's sides of (distance of G from the side) x
+// (length of the side inside the part) -- quad_vertex_area's formula, but every side is split ONCE: side x = 1/2 is met by the
+// rays +a and +b and belongs to N above the first crossing, W below the second, O in between; side y = -1/2 (rays -b, +a): NW | N |
+// O; side x = -1/2 (rays -b, -a): N | NW | W; side y = 1/2 (rays -a, +b): NW | W | O.  Eight crossings, eight clamps at 0 and twelve
+// multiply-adds instead of four independent evaluations (types 7-9 of Source.cpp:1276-1401 for all four dst pixels at once).
+// (fx, fy) = G relative to the pixel centre, both in [-1/2, 1/2]; area[CellTarget].
+template <typename F>
+AAI_HD void cell_vertex_areas(F m1, F im1, F fx, F fy, F (&area)[4])
+{
+    auto sat = [](F x) -> F { return qmax(x, F(0)); };      // (every crossing lies on the far side of G: the lengths never exceed 1)
+    const F dR = F(0.5) - fx, dL = F(0.5) + fx, dT = F(0.5) + fy, dB = F(0.5) - fy;
+    // side x = 1/2, from y = -1/2 down: ray +a crosses it at fy - dR m1, ray +b at fy + dR im1
+    const F rN = sat(qfma(-dR, m1, fy) + F(0.5)), rW = sat(F(0.5) - qfma(dR, im1, fy)), rO = (F(1) - rN) - rW;
+    // side y = -1/2, from x = -1/2 rightwards: ray -b crosses it at fx - dT m1, ray +a at fx + dT im1
+    const F tNW = sat(qfma(-dT, m1, fx) + F(0.5)), tO = sat(F(0.5) - qfma(dT, im1, fx)), tN = (F(1) - tNW) - tO;
+    // side x = -1/2, from y = -1/2 down: ray -b crosses it at fy - dL im1, ray -a at fy + dL m1
+    const F lN = sat(qfma(-dL, im1, fy) + F(0.5)), lW = sat(F(0.5) - qfma(dL, m1, fy)), lNW = (F(1) - lN) - lW;
+    // side y = 1/2, from x = -1/2 rightwards: ray -a crosses it at fx - dB im1, ray +b at fx + dB m1
+    const F bNW = sat(qfma(-dB, im1, fx) + F(0.5)), bO = sat(F(0.5) - qfma(dB, m1, fx)), bW = (F(1) - bNW) - bO;
+    area[CELL_O] = F(0.5) * qfma(dR, rO, qfma(dT, tO, dB * bO));
+    area[CELL_W] = F(0.5) * qfma(dR, rW, qfma(dL, lW, dB * bW));
+    area[CELL_N] = F(0.5) * qfma(dR, rN, qfma(dT, tN, dL * lN));
+    area[CELL_NW] = F(0.5) * qfma(dT, tNW, qfma(dL, lNW, dB * bNW));
+}
+
 // One cell.  (Zx, Zy) = the lattice point nearest the zone's centre, (dfx, dfy) = zone centre - (Zx, Zy), both in
 // [-1/2, 1/2].  Source protocol as in quad_pixel (issue / commit / at).  sA[t], sVA[t] = sums of areas and of area x value
 // this cell contributes to target t (CellTarget).  SCAN: src is never touched, every value counts as 1, and the return
@@ -123,10 +149,12 @@ AAI_HD bool cell_eval(const QuadConsts<F> &q, const CellConsts<F> &z, int Zx, in
         src.at(slot, vals);
         return vals[0];
     };
-    // (a pixel that does not reach a target contributes area 0 there -- and must then contribute nothing, whatever its value:
-    // 0 x NaN would put a source pixel's NaN into a dst pixel it does not overlap)
+    // A pixel that does not reach a target contributes area 0 there -- and must then contribute nothing, whatever its value: 0 x NaN
+    // would put a source pixel's NaN into a dst pixel it does not overlap.  Only the vertex zone's two-ray pixels have such targets
+    // (`add`, behind a vote on the value).  Everywhere else the areas are positive: an interior pixel has area 1; a pixel cut by one
+    // grid line gives both sides a positive part and the pixel that holds G four positive wedges unless a zone decision or G sits
+    // within the scan's margin of its threshold -- and then the scan has left every dst pixel this cell feeds to the fix-up pass.
     auto add = [&](int target, F area, F v) { sA[target] += area; sVA[target] = qfma(area, area != F(0) ? v : F(0), sVA[target]); };
-    // ... which only matters for values that are not finite: where every lane's value is (one vote per pixel), 0 x v is 0
     auto addf = [&](int target, F area, F v) { sA[target] += area; sVA[target] = qfma(area, v, sVA[target]); };
     auto finite = [&](F v) -> bool { return AAI_WAVE_ALL(qabs(v) <= F(3.0e38)); };
 
@@ -218,60 +246,62 @@ AAI_HD bool cell_eval(const QuadConsts<F> &q, const CellConsts<F> &z, int Zx, in
                 F area[4];
                 if (HP) {
                     const double fxD = (dfx + z.gx) - (double)rx, fyD = (dfy + z.gy) - (double)ry;
+                    if (q.steep) {
+                        double areaD[4];
+                        cell_vertex_areas<double>(q.m1D, q.im1D, fxD, fyD, areaD);
 #pragma unroll
-                    for (int t = 0; t < 4; ++t)
-                        area[t] = q.steep ? (F)quad_vertex_area<double>(q.m1D, q.im1D, fxD, fyD, t) : quad_vertex_area(q, (F)fxD, (F)fyD, t);
-                } else {
-#pragma unroll
-                    for (int t = 0; t < 4; ++t) area[t] = quad_vertex_area(q, fx, fy, t);
-                }
+                        for (int t = 0; t < 4; ++t) area[t] = (F)areaD[t];
+                    } else cell_vertex_areas<F>(q.m1, q.im1, (F)fxD, (F)fyD, area);
+                } else cell_vertex_areas<F>(q.m1, q.im1, fx, fy, area);
                 // G is vertex 0 (left/top) of the cell's own dst pixel, vertex 1 (right/top) of its left neighbour,
                 // vertex 2 (left/bottom) of the one above, vertex 3 of the one above left
 #pragma unroll
-                for (int t = 0; t < 4; ++t) add(t, area[t], v);
+                for (int t = 0; t < 4; ++t) addf(t, area[t], v);
             }
         }
     }
 
     if (upOnly) { mIn = 0; mLeft = 0; }
+    // coordinates of window position (i, j) relative to G: those of position (0, 0) plus i (c, s) + j (-s, c)
+    const F a00 = qfma(fi0, q.c, qfma(-fj0, q.s, ac)) + q.hmk, b00 = qfma(fi0, q.s, qfma(fj0, q.c, bc)) + q.hmk;
     // ---- interior: area 1 to the cell's own dst pixel --------------------------------------------------------------------
     while (mIn) {
         const int slot = quad_ctz(mIn);
         mIn &= mIn - 1;
-        add(CELL_O, F(1), value(slot));
+        addf(CELL_O, F(1), value(slot));
     }
     // ---- left-edge zone: the vertical grid line alone (the reference's corner rule applies on both sides) -----------------
     while (mLeft) {
         const int slot = quad_ctz(mLeft);
         mLeft &= mLeft - 1;
         const int j = slot / WIN, i = slot - j * WIN;
-        const F fj = fj0 + (F)j, fi = fi0 + (F)i;
-        const F a1 = qfma(fi, q.c, qfma(-fj, q.s, ac)) + q.hmk;
+        const F a1 = qfma((F)i, q.c, qfma(-(F)j, q.s, a00));
         bool flip;
         F tp = plain_tp(a1, flip);
-        if (HP) tp = precise_tp(fi, fj, true, flip);
+        if (HP) tp = precise_tp(fi0 + (F)i, fj0 + (F)j, true, flip);
         if (SCAN && q.ref != 0 && qabs(tp - q.lo) < (HP ? q.marginT : q.margin)) uncertain = true;
         F sE, sR;
         cell_cut_small(q, tp, sE, sR);
         const F v = value(slot);
-        add(CELL_O, flip ? F(1) - sR : sR, v);               // flip: the E side holds the larger part
-        add(CELL_W, flip ? sR : F(1) - sR, v);
+        const F big = F(1) - sR;
+        addf(CELL_O, flip ? big : sR, v);                  // flip: the E side holds the larger part
+        addf(CELL_W, flip ? sR : big, v);
     }
     // ---- top-edge zone: the horizontal grid line alone (exact under both policies) ------------------------------------------
     while (mTop) {
         const int slot = quad_ctz(mTop);
         mTop &= mTop - 1;
         const int j = slot / WIN, i = slot - j * WIN;
-        const F fj = fj0 + (F)j, fi = fi0 + (F)i;
-        const F b1 = qfma(fi, q.s, qfma(fj, q.c, bc)) + q.hmk;
+        const F b1 = qfma((F)i, q.s, qfma((F)j, q.c, b00));
         bool flip;
         F tp = plain_tp(b1, flip);
-        if (HP) tp = precise_tp(fi, fj, false, flip);
+        if (HP) tp = precise_tp(fi0 + (F)i, fj0 + (F)j, false, flip);
         F sS, unused;
         cell_cut_small(q, tp, sS, unused);
         const F v = value(slot);
-        add(CELL_O, flip ? F(1) - sS : sS, v);
-        add(CELL_N, flip ? sS : F(1) - sS, v);
+        const F big = F(1) - sS;
+        addf(CELL_O, flip ? big : sS, v);
+        addf(CELL_N, flip ? sS : big, v);
     }
     // ---- vertex zone, G outside the pixel: one vertical and one horizontal ray from G cross it --------------------------------
     while (mVtx) {
@@ -279,7 +309,7 @@ AAI_HD bool cell_eval(const QuadConsts<F> &q, const CellConsts<F> &z, int Zx, in
         mVtx &= mVtx - 1;
         const int j = slot / WIN, i = slot - j * WIN;
         const F fj = fj0 + (F)j, fi = fi0 + (F)i;
-        const F a1 = qfma(fi, q.c, qfma(-fj, q.s, ac)) + q.hmk, b1 = qfma(fi, q.s, qfma(fj, q.c, bc)) + q.hmk;
+        const F a1 = qfma((F)i, q.c, qfma(-(F)j, q.s, a00)), b1 = qfma((F)i, q.s, qfma((F)j, q.c, b00));
         bool flipA, flipB;
         F tpA = plain_tp(a1, flipA), tpB = plain_tp(b1, flipB);
         if (HP) { tpA = precise_tp(fi, fj, true, flipA); tpB = precise_tp(fi, fj, false, flipB); }
@@ -346,25 +376,35 @@ AAI_HD bool cell_anchor(const RotLaunch &r, const CellColumn &col, int dy, int &
 // positive coefficients L cos, L sin (reduced angle), so each of the four lattice bounds limits dy from one side at one end of
 // the column range.  Conservative (a superset, with a margin of one row): rows outside [lo, hi] contribute nothing to any dst
 // pixel and the kernel does not even compute their anchors -- the corners of a rotated canvas are 36 % of config 3's cells and
-// 50 % of config 5's.  lo > hi: none.
+// 50 % of config 5's.  lo > hi: none.  The four bounds are lines in the column index whose coefficients the host composes once
+// (make_cell_live: the divisions); a wave evaluates four multiply-adds.
+struct CellLive {
+    double loX0, loXk, hiX0, hiXk;     // from the lattice's X extent: dy >= loX0 + xb loXk, dy <= hiX0 + xa hiXk (useX)
+    double loY0, loYk, hiY0, hiYk;     // from its Y extent: dy >= loY0 + xa loYk, dy <= hiY0 + xb hiYk (useY)
+    int useX, useY;
+};
 template <typename F>
-AAI_HD void cell_live_rows(const RotLaunch &r, const CellConsts<F> &z, int xa, int xb, int &lo, int &hi)
+AAI_HD CellLive make_cell_live(const RotLaunch &r, const CellConsts<F> &z)
 {
+    CellLive cl;
     const double reach = (double)z.hbz + 17.0;                     // the window's half extent, the anchor's slack of 16, rounding
     const double Lc = r.side * r.cs, Ls = r.side * r.sn;
     // zone centre of cell (dx, dy): (A0 + dx Lc + dy Ls, B0 - dx Ls + dy Lc)
     const double u0 = r.fracX * r.side - r.isoX + r.offX, v0 = r.fracY * r.side - r.isoY + r.offY;
     const double A0 = u0 * r.cs + v0 * r.sn + r.isoX + z.zx, B0 = -u0 * r.sn + v0 * r.cs + r.isoY + z.zy;
+    cl.useX = Ls > 0.0 ? 1 : 0; cl.useY = Lc > 0.0 ? 1 : 0;
+    cl.loX0 = cl.useX ? (-reach - A0) / Ls : 0.0; cl.loXk = cl.useX ? -Lc / Ls : 0.0;
+    cl.hiX0 = cl.useX ? ((double)r.mW - 1.0 + reach - A0) / Ls : 0.0; cl.hiXk = cl.loXk;
+    cl.loY0 = cl.useY ? (-reach - B0) / Lc : 0.0; cl.loYk = cl.useY ? Ls / Lc : 0.0;
+    cl.hiY0 = cl.useY ? ((double)r.mH - 1.0 + reach - B0) / Lc : 0.0; cl.hiYk = cl.loYk;
+    return cl;
+}
+AAI_HD void cell_live_rows(const CellLive &cl, int xa, int xb, int &lo, int &hi)
+{
     double a = -1e300, b = 1e300;
-    if (Ls > 0.0) {
-        a = fmax(a, (-reach - A0 - xb * Lc) / Ls);
-        b = fmin(b, ((double)r.mW - 1.0 + reach - A0 - xa * Lc) / Ls);
-    }
-    if (Lc > 0.0) {
-        a = fmax(a, (-reach - B0 + xa * Ls) / Lc);
-        b = fmin(b, ((double)r.mH - 1.0 + reach - B0 + xb * Ls) / Lc);
-    }
-    a = floor(a) - 1.0; b = ceil(b) + 1.0;
+    if (cl.useX) { a = fmax(a, qfma((double)xb, cl.loXk, cl.loX0)); b = fmin(b, qfma((double)xa, cl.hiXk, cl.hiX0)); }
+    if (cl.useY) { a = fmax(a, qfma((double)xa, cl.loYk, cl.loY0)); b = fmin(b, qfma((double)xb, cl.hiYk, cl.hiY0)); }
+    a = floor(a) - 2.0; b = ceil(b) + 2.0;                         // (one row of margin, one for the composed coefficients' rounding)
     lo = a < -2147483000.0 ? -2147483000 : (a > 2147483000.0 ? 2147483000 : (int)a);
     hi = b < -2147483000.0 ? -2147483000 : (b > 2147483000.0 ? 2147483000 : (int)b);
 }

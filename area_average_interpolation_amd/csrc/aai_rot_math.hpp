@@ -58,6 +58,8 @@ struct RotLaunch {
     // the fp32 window kernels (aai_rotated_quad.hip): the dst pixel centre in virtual-lattice coordinates as two fused
     // multiply-adds per coordinate, X = cXa dx + cXb dy + cX0, Y alike (quad_centre)
     double cXa, cXb, cX0, cYa, cYb, cY0;
+    // request hints (include/aai.h): AAI_POLICY_PREFER_CELL, AAI_POLICY_DIAG_NO_FIXUP
+    int preferCell, noFixup;
 };
 
 // Decisions closer than this (in virtual-source pixels) to their threshold are "knife edges": the fast

@@ -189,8 +189,12 @@ AAI_HD QuadConsts<F> make_quad_consts(double side, double c, double s, int polic
     return q;
 }
 
-template <typename F> AAI_HD F qmin(F a, F b) { return a < b ? a : b; }
-template <typename F> AAI_HD F qmax(F a, F b) { return a < b ? b : a; }
+// minimum / maximum of two numbers that are never NaN (coordinates, areas): ONE instruction on the GPU (v_min_f32 / v_max_f32),
+// where "a < b ? a : b" is a compare and a select because it must hand a NaN through
+AAI_HD float qmin(float a, float b) { return __builtin_fminf(a, b); }
+AAI_HD float qmax(float a, float b) { return __builtin_fmaxf(a, b); }
+AAI_HD double qmin(double a, double b) { return __builtin_fmin(a, b); }
+AAI_HD double qmax(double a, double b) { return __builtin_fmax(a, b); }
 AAI_HD float qabs(float a) { return __builtin_fabsf(a); }       // a source modifier on the GPU, not an instruction
 AAI_HD double qabs(double a) { return __builtin_fabs(a); }
 // Every multiply-add of this header is an EXPLICIT fused multiply-add and its translation units are compiled without

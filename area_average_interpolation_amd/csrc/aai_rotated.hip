@@ -413,13 +413,13 @@ hipError_t launch_knife_scan(const RotLaunch &r, unsigned long long *laneMasks, 
     return hipSuccess;
 }
 
-// experiments only: AAI_ROT_TUNE="runs=0|1 quad=0|1", read once per process
+// experiments build only (make exp): AAI_ROT_TUNE="runs=0|1 quad=0|1", read once per process
 struct RotTune { int runs = -1, quad = -1; };
 static const RotTune &rot_tune()
 {
     static const RotTune t = [] {
         RotTune v;
-        if (const char *env = getenv("AAI_ROT_TUNE")) {
+        if (const char *env = experiment_env("AAI_ROT_TUNE")) {
             if (const char *p = strstr(env, "runs=")) v.runs = atoi(p + 5) != 0;
             if (const char *p = strstr(env, "quad=")) v.quad = atoi(p + 5) != 0;
         }
@@ -515,11 +515,6 @@ static hipError_t launch_rotated_band(const RotLaunch &r, const QuadMap &m, cons
     return hipGetLastError();
 }
 
-// tests only (aai_debug_skip_fixup): the double-precision pass over the flagged pixels is not launched, so a dst buffer filled with a
-// sentinel shows exactly which pixels the production kernels leave alone
-static bool g_skipFixup = false;
-void set_skip_fixup(bool skip) { g_skipFixup = skip; }
-
 template <typename T>
 static hipError_t launch_rotated_typed(const RotLaunch &r, const QuadMap &m, const T *src, int srcType, ImageView sv, float *dst, ImageView dv,
                                        int batch, const RotFlags &flags, hipStream_t stream, const char **kernelName)
@@ -556,7 +551,7 @@ static hipError_t launch_rotated_typed(const RotLaunch &r, const QuadMap &m, con
         e = hipEventRecord(flags.fork, stream);
         if (e == hipSuccess) e = hipStreamWaitEvent(flags.side, flags.fork, 0);
         if (e != hipSuccess) return e;
-        if (!g_skipFixup) launch_rotated_fixup(r, batch, src, srcType, sv, dst, dv, static_cast<const uint2 *>(flags.list), flags.count, flags.side);
+        if (!r.noFixup) launch_rotated_fixup(r, batch, src, srcType, sv, dst, dv, static_cast<const uint2 *>(flags.list), flags.count, flags.side);      // (AAI_POLICY_DIAG_NO_FIXUP)
         e = hipEventRecord(flags.join, flags.side);
         if (e != hipSuccess) return e;           // (nothing was enqueued on the side stream after the fork that the caller could race with)
     }
@@ -577,7 +572,7 @@ static hipError_t launch_rotated_typed(const RotLaunch &r, const QuadMap &m, con
         return e != hipSuccess ? e : j;
     }
     if (e != hipSuccess) return e;
-    if (fixup && !g_skipFixup) launch_rotated_fixup(r, batch, src, srcType, sv, dst, dv, static_cast<const uint2 *>(flags.list), flags.count, stream);
+    if (fixup && !r.noFixup) launch_rotated_fixup(r, batch, src, srcType, sv, dst, dv, static_cast<const uint2 *>(flags.list), flags.count, stream);
     return hipGetLastError();
 }
 

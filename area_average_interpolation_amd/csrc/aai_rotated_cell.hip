@@ -31,14 +31,19 @@
 
 namespace aai {
 
-// dst rows a wave walks.  A workgroup of 4 waves pays 4 R + 1 cell rows for 4 R dst rows, so taller is cheaper -- as long as the
-// launch still has several waves for every SIMD of the chip (1024 SIMDs x ~6 wave slots)
-static int cell_rows_per_wave(int dW, int rows, int batch)
+// dst rows a wave walks.  A workgroup of 4 waves pays 4 R + 1 cell rows for 4 R dst rows, so taller is cheaper in instructions --
+// but the four segments of a workgroup share a CU, and what they fetch.  Measured (8192^2 sources, one image; profiles/
+// r04_cell_kernel.txt), best R of 4 / 8 / 16 / 32 by a margin of 9 ... 35 %: 3:1 and 4:1 -> 4; 2:1 and 1.5:1 -> 8; 1:1 -> 16; x2 and
+// x4 up-sampling -> 16 ... 32: the workgroup's footprint, 4 R dst rows of `srcRowsPerDstRow` source rows each, wants to be about 50
+// source rows (a CU's cache holds them while its waves walk).  Never so tall that the launch has fewer than several waves for every
+// SIMD of the chip (1024 SIMDs x ~6 wave slots).
+static int cell_rows_per_wave(int dW, int rows, int batch, double srcRowsPerDstRow)
 {
     const char *e = experiment_env("AAI_CELL_ROWS");
     if (e && atoi(e) > 0) return atoi(e);
     const int64_t strips = ((int64_t)dW + 62) / 63 * batch;
-    int R = 32;
+    const double want = 14.0 / (srcRowsPerDstRow > 0.05 ? srcRowsPerDstRow : 0.05);
+    int R = want < 5.7 ? 4 : (want < 11.4 ? 8 : (want < 22.7 ? 16 : 32));      // the nearest power of two
     while (R > 4 && strips * ((rows + R - 1) / R) < 24576) R >>= 1;
     while ((rows + 4 * R - 1) / (4 * R) > 65535) R <<= 1;       // grid.y
     return R;
@@ -131,7 +136,7 @@ __device__ __forceinline__ void cell_segment(int blockY0, int blockY1, int rowsP
 
 template <typename T, int WIN, bool SCALED, bool HP>
 __global__ __launch_bounds__(kQuadBlock, cell_min_waves(WIN)) void aai_cell_kernel(
-    RotLaunch r, QuadConsts<float> q, CellConsts<float> z, QuadMap m, const T *__restrict__ src, ImageView sv, float *__restrict__ dst, ImageView dv,
+    RotLaunch r, QuadConsts<float> q, CellConsts<float> z, CellLive live, QuadMap m, const T *__restrict__ src, ImageView sv, float *__restrict__ dst, ImageView dv,
     const unsigned long long *__restrict__ skipMasks, int tilesX, int rowsPerWave, int bigBlocks, int tailRows)
 {
     __shared__ float window[WIN * WIN][kQuadBlock];
@@ -153,7 +158,7 @@ __global__ __launch_bounds__(kQuadBlock, cell_min_waves(WIN)) void aai_cell_kern
     const char *img = reinterpret_cast<const char *>(src + (int64_t)blockIdx.z * sv.imageStride + m.base);
     const CellColumn col = cell_column(r, z, x0 + lane);
     int liveLo, liveHi;
-    cell_live_rows(r, z, x0, x0 + 63, liveLo, liveHi);         // wave-uniform
+    cell_live_rows(live, x0, x0 + 63, liveLo, liveHi);         // wave-uniform
     // per-pixel masks only where a 16 x 16 tile this segment touches holds a flagged pixel (QuadMap::tileFlags; wave-uniform, scalar loads)
     const unsigned long long *masks = skipMasks;
     if (masks && m.tileFlags) {
@@ -187,7 +192,7 @@ __global__ __launch_bounds__(kQuadBlock, cell_min_waves(WIN)) void aai_cell_kern
 // decision too close to its threshold, or whose total area is too small for fp32 weights (QuadConsts::minArea), in the
 // lane masks of the 16 x 16 tiling (on top of the knife-edge scan's bits) and counts the newly set bits in counter[0].
 template <int WIN, bool HP>
-__global__ __launch_bounds__(kQuadBlock) void aai_cell_scan_kernel(RotLaunch r, QuadConsts<float> q, CellConsts<float> z, unsigned long long *__restrict__ laneMasks,
+__global__ __launch_bounds__(kQuadBlock) void aai_cell_scan_kernel(RotLaunch r, QuadConsts<float> q, CellConsts<float> z, CellLive live, unsigned long long *__restrict__ laneMasks,
                                                                   unsigned *__restrict__ counter, int tilesX, int rowsPerWave, int band0)
 {
     __shared__ CellHandoff hand;
@@ -202,7 +207,7 @@ __global__ __launch_bounds__(kQuadBlock) void aai_cell_scan_kernel(RotLaunch r, 
     cell_segment(blockY0, blockY1, rowsPerWave, wave, y0, y1, ownsBottom);
     const CellColumn col = cell_column(r, z, x0 + lane);
     int liveLo, liveHi;
-    cell_live_rows(r, z, x0, x0 + 63, liveLo, liveHi);
+    cell_live_rows(live, x0, x0 + 63, liveLo, liveHi);
     cell_walk(r.dW, x0, y0, y1, ownsBottom, wave, hand, liveLo, liveHi, lane,
         [&](int, int, bool) -> int { return 0; },
         [&](int cx, int cy, float (&sA)[4], float (&sVA)[4], bool) -> bool {
@@ -221,17 +226,19 @@ __global__ __launch_bounds__(kQuadBlock) void aai_cell_scan_kernel(RotLaunch r, 
         });
 }
 
-template <typename T, int WIN>
+// HPSEL: which precision variants this translation unit holds: 0 = plain fp32 only, 1 = hiPrec only, 2 = both
+template <typename T, int WIN, int HPSEL>
 hipError_t launch_cell_tile(const RotLaunch &r, const QuadConsts<float> &q, const CellConsts<float> &z, const QuadMap &m, const T *src, ImageView sv,
                             float *dst, ImageView dv, int batch, const unsigned long long *skipMasks, hipStream_t stream)
 {
     const int rows = r.dyEnd - r.dyBase;
-    const int rowsPerWave = cell_rows_per_wave(r.dW, rows, batch);
+    const int rowsPerWave = cell_rows_per_wave(r.dW, rows, batch, r.side / (m.scale > 0 ? m.scale : 1));
     const int strips = (r.dW + 62) / 63;
     const int blockRows = kCellWaves * rowsPerWave;
-    // A launch with few waves spends part of its time draining: its last rows go in segments of half the height, whose waves
-    // live half as long.  Experiments (-DAAI_EXPERIMENTS): AAI_CELL_TAIL="<percent of the rows>,<rows per wave in the tail>".
-    int tailPct = rowsPerWave == 4 ? 10 : 0, tailR = 2;
+    // (Shorter segments for the last rows of a launch -- waves that live half as long, so that the chip drains sooner -- paid with
+    // 8-row strips per wave; with four waves per strip segment they measure nothing: config 3 160.7 us without, 161.0 ... 166.3 with.
+    // Experiments (-DAAI_EXPERIMENTS): AAI_CELL_TAIL="<percent of the rows>,<rows per wave in the tail>".)
+    int tailPct = 0, tailR = 2;
     {
         const char *e = experiment_env("AAI_CELL_TAIL");
         if (e) { tailPct = atoi(e); const char *c = strchr(e, ','); tailR = c ? atoi(c + 1) : 2; }
@@ -245,41 +252,79 @@ hipError_t launch_cell_tile(const RotLaunch &r, const QuadConsts<float> &q, cons
     }
     const dim3 grid(strips, bigBlocks + tailBlocks, batch);
     const int tilesX = (r.dW + 15) / 16;
+    const CellLive live = make_cell_live(r, z);
 #define AAI_CELL_LAUNCH(SCALED, HP) \
-    hipLaunchKernelGGL((aai_cell_kernel<T, WIN, SCALED, HP>), grid, dim3(kQuadBlock), 0, stream, r, q, z, m, src, sv, dst, dv, skipMasks, tilesX, rowsPerWave, bigBlocks, tailRows)
+    hipLaunchKernelGGL((aai_cell_kernel<T, WIN, SCALED, HP>), grid, dim3(kQuadBlock), 0, stream, r, q, z, live, m, src, sv, dst, dv, skipMasks, tilesX, rowsPerWave, bigBlocks, tailRows)
+    if ((q.hiPrec != 0) != (HPSEL == 1) && HPSEL != 2) return hipErrorInvalidValue;       // (the dispatcher picks the unit that holds the variant)
     if (m.scale > 1) {
-        if (q.hiPrec) AAI_CELL_LAUNCH(true, true); else AAI_CELL_LAUNCH(true, false);
+        if (HPSEL != 0 && q.hiPrec) AAI_CELL_LAUNCH(true, true);
+        if (HPSEL != 1 && !q.hiPrec) AAI_CELL_LAUNCH(true, false);
     } else {
-        if (q.hiPrec) AAI_CELL_LAUNCH(false, true); else AAI_CELL_LAUNCH(false, false);
+        if (HPSEL != 0 && q.hiPrec) AAI_CELL_LAUNCH(false, true);
+        if (HPSEL != 1 && !q.hiPrec) AAI_CELL_LAUNCH(false, false);
     }
 #undef AAI_CELL_LAUNCH
     return hipGetLastError();
 }
 
-template <typename T>
+template <typename T, int HPSEL>
 hipError_t launch_cell_typed(const RotLaunch &r, const QuadMap &m, const T *src, ImageView sv, float *dst, ImageView dv, int batch,
                              const unsigned long long *skipMasks, hipStream_t stream)
 {
     const QuadConsts<float> q = make_cell_quad_consts<float>(r.side, r.c, r.s, r.policy);
     const CellConsts<float> z = make_cell_consts<float>(r.side, r.c, r.s);
     switch (z.win) {
-    case 2: return launch_cell_tile<T, 2>(r, q, z, m, src, sv, dst, dv, batch, skipMasks, stream);
-    case 3: return launch_cell_tile<T, 3>(r, q, z, m, src, sv, dst, dv, batch, skipMasks, stream);
-    case 4: return launch_cell_tile<T, 4>(r, q, z, m, src, sv, dst, dv, batch, skipMasks, stream);
-    case 5: return launch_cell_tile<T, 5>(r, q, z, m, src, sv, dst, dv, batch, skipMasks, stream);
-    case 6: return launch_cell_tile<T, 6>(r, q, z, m, src, sv, dst, dv, batch, skipMasks, stream);
-    case 7: return launch_cell_tile<T, 7>(r, q, z, m, src, sv, dst, dv, batch, skipMasks, stream);
-    case 8: return launch_cell_tile<T, 8>(r, q, z, m, src, sv, dst, dv, batch, skipMasks, stream);
+    case 2: return launch_cell_tile<T, 2, HPSEL>(r, q, z, m, src, sv, dst, dv, batch, skipMasks, stream);
+    case 3: return launch_cell_tile<T, 3, HPSEL>(r, q, z, m, src, sv, dst, dv, batch, skipMasks, stream);
+    case 4: return launch_cell_tile<T, 4, HPSEL>(r, q, z, m, src, sv, dst, dv, batch, skipMasks, stream);
+    case 5: return launch_cell_tile<T, 5, HPSEL>(r, q, z, m, src, sv, dst, dv, batch, skipMasks, stream);
+    case 6: return launch_cell_tile<T, 6, HPSEL>(r, q, z, m, src, sv, dst, dv, batch, skipMasks, stream);
+    case 7: return launch_cell_tile<T, 7, HPSEL>(r, q, z, m, src, sv, dst, dv, batch, skipMasks, stream);
+    case 8: return launch_cell_tile<T, 8, HPSEL>(r, q, z, m, src, sv, dst, dv, batch, skipMasks, stream);
     default: return hipErrorInvalidValue;
     }
 }
 
 }  // namespace
 
-// (tests: aai_debug_cell_min_waves(0) sends small images to the cell kernel too)
-static int g_cellMinWaves = 1024;
-void set_cell_min_waves(int waves) { g_cellMinWaves = waves < 0 ? 1024 : waves; }
+// ---- translation units ----------------------------------------------------------------------------------------------------------
+// The runtime loads a translation unit's code object when one of its kernels is first launched -- ~1 ms per 100 KB of code, once per
+// process, and the first call of a process is the only one the reference's user makes (Source.cpp:1565).  All 84 instantiations of
+// aai_cell_kernel in one unit made that 14 ms (profiles/r03_plan_time.txt: config 3's plan 15.4 ms cold, 0.8 ms with the unit loaded).
+// The Makefile therefore compiles this file once per AAI_CELL_PART: 1 = dispatch + scan kernels, 2 = fp32 sources, 3 = fp32 sources
+// with hiPrec (rotations within a few degrees of an axis), 4 = 8-bit, 5 = 16-bit sources; a process pays for the unit it uses.
+// (AAI_CELL_PART undefined = everything in one unit.)
+hipError_t launch_cell_f32(const RotLaunch &r, const QuadMap &m, const float *src, ImageView sv, float *dst, ImageView dv, int batch, const unsigned long long *skipMasks, hipStream_t stream);
+hipError_t launch_cell_f32_hp(const RotLaunch &r, const QuadMap &m, const float *src, ImageView sv, float *dst, ImageView dv, int batch, const unsigned long long *skipMasks, hipStream_t stream);
+hipError_t launch_cell_u8(const RotLaunch &r, const QuadMap &m, const unsigned char *src, ImageView sv, float *dst, ImageView dv, int batch, const unsigned long long *skipMasks, hipStream_t stream);
+hipError_t launch_cell_u16(const RotLaunch &r, const QuadMap &m, const unsigned short *src, ImageView sv, float *dst, ImageView dv, int batch, const unsigned long long *skipMasks, hipStream_t stream);
 
+#if !defined(AAI_CELL_PART) || AAI_CELL_PART == 2
+hipError_t launch_cell_f32(const RotLaunch &r, const QuadMap &m, const float *src, ImageView sv, float *dst, ImageView dv, int batch, const unsigned long long *skipMasks, hipStream_t stream)
+{
+    return launch_cell_typed<float, 0>(r, m, src, sv, dst, dv, batch, skipMasks, stream);
+}
+#endif
+#if !defined(AAI_CELL_PART) || AAI_CELL_PART == 3
+hipError_t launch_cell_f32_hp(const RotLaunch &r, const QuadMap &m, const float *src, ImageView sv, float *dst, ImageView dv, int batch, const unsigned long long *skipMasks, hipStream_t stream)
+{
+    return launch_cell_typed<float, 1>(r, m, src, sv, dst, dv, batch, skipMasks, stream);
+}
+#endif
+#if !defined(AAI_CELL_PART) || AAI_CELL_PART == 4
+hipError_t launch_cell_u8(const RotLaunch &r, const QuadMap &m, const unsigned char *src, ImageView sv, float *dst, ImageView dv, int batch, const unsigned long long *skipMasks, hipStream_t stream)
+{
+    return launch_cell_typed<unsigned char, 2>(r, m, src, sv, dst, dv, batch, skipMasks, stream);
+}
+#endif
+#if !defined(AAI_CELL_PART) || AAI_CELL_PART == 5
+hipError_t launch_cell_u16(const RotLaunch &r, const QuadMap &m, const unsigned short *src, ImageView sv, float *dst, ImageView dv, int batch, const unsigned long long *skipMasks, hipStream_t stream)
+{
+    return launch_cell_typed<unsigned short, 2>(r, m, src, sv, dst, dv, batch, skipMasks, stream);
+}
+#endif
+
+#if !defined(AAI_CELL_PART) || AAI_CELL_PART == 1
 bool cell_can_serve(const RotLaunch &r, int srcType, ImageView sv)
 {
     // plain images below 4 GiB (lanes address their pixels with unsigned 32-bit byte offsets from the image's first element)
@@ -288,7 +333,8 @@ bool cell_can_serve(const RotLaunch &r, int srcType, ImageView sv)
     // Small outputs stay on the quad kernel: a cell wave lives for rows + 1 cell rows, and an image of fewer than ~1000 such
     // waves (about 720 x 720 dst pixels) cannot fill the chip with them -- the reference's own example call (158 x 158 dst
     // pixels at 5.9 : 1) takes 71 us on 60 cell waves and 36 us on 390 one-shot quad waves.
-    if ((int64_t)((r.dW + 62) / 63) * ((r.dH + 7) / 8) < g_cellMinWaves) return false;
+    // (AAI_POLICY_PREFER_CELL asks for the cell kernel all the same)
+    if (!r.preferCell && (int64_t)((r.dW + 62) / 63) * ((r.dH + 7) / 8) < 1024) return false;
     const int64_t esz = srcType == SRC_U8 ? 1 : srcType == SRC_U16 ? 2 : 4;
     return (int64_t)r.H * sv.rowStride * esz < ((int64_t)1 << 32);
 }
@@ -300,9 +346,11 @@ hipError_t launch_cell(const RotLaunch &r, const QuadMap &map, const void *src, 
     QuadMap m = map;
     m.anchorRows = 0;
     switch (srcType) {
-    case SRC_U8: return launch_cell_typed(r, m, static_cast<const unsigned char *>(src), sv, dst, dv, batch, skipMasks, stream);
-    case SRC_U16: return launch_cell_typed(r, m, static_cast<const unsigned short *>(src), sv, dst, dv, batch, skipMasks, stream);
-    default: return launch_cell_typed(r, m, static_cast<const float *>(src), sv, dst, dv, batch, skipMasks, stream);
+    case SRC_U8: return launch_cell_u8(r, m, static_cast<const unsigned char *>(src), sv, dst, dv, batch, skipMasks, stream);
+    case SRC_U16: return launch_cell_u16(r, m, static_cast<const unsigned short *>(src), sv, dst, dv, batch, skipMasks, stream);
+    default:
+        if (make_cell_quad_consts<float>(r.side, r.c, r.s, r.policy).hiPrec) return launch_cell_f32_hp(r, m, static_cast<const float *>(src), sv, dst, dv, batch, skipMasks, stream);
+        return launch_cell_f32(r, m, static_cast<const float *>(src), sv, dst, dv, batch, skipMasks, stream);
     }
 }
 
@@ -311,6 +359,7 @@ hipError_t launch_cell_scan(const RotLaunch &r, unsigned long long *laneMasks, u
     if (r.dW <= 0 || r.dH <= 0) return hipSuccess;
     const QuadConsts<float> q = make_cell_quad_consts<float>(r.side, r.c, r.s, r.policy);
     const CellConsts<float> z = make_cell_consts<float>(r.side, r.c, r.s);
+    const CellLive live = make_cell_live(r, z);
     const int rows = 4;                                        // per wave: workgroups of 16 dst rows
     const int strips = (r.dW + 62) / 63;
     const int tilesX = (r.dW + 15) / 16;
@@ -319,8 +368,8 @@ hipError_t launch_cell_scan(const RotLaunch &r, unsigned long long *laneMasks, u
         const dim3 grid(strips, bands - b0 < 65535 ? bands - b0 : 65535, 1);
 #define AAI_CELL_SCAN(W)                                                                                                                               \
     case W:                                                                                                                                            \
-        if (q.hiPrec) hipLaunchKernelGGL((aai_cell_scan_kernel<W, true>), grid, dim3(kQuadBlock), 0, stream, r, q, z, laneMasks, counter, tilesX, rows, b0); \
-        else hipLaunchKernelGGL((aai_cell_scan_kernel<W, false>), grid, dim3(kQuadBlock), 0, stream, r, q, z, laneMasks, counter, tilesX, rows, b0);    \
+        if (q.hiPrec) hipLaunchKernelGGL((aai_cell_scan_kernel<W, true>), grid, dim3(kQuadBlock), 0, stream, r, q, z, live, laneMasks, counter, tilesX, rows, b0); \
+        else hipLaunchKernelGGL((aai_cell_scan_kernel<W, false>), grid, dim3(kQuadBlock), 0, stream, r, q, z, live, laneMasks, counter, tilesX, rows, b0);    \
         break;
         switch (z.win) {
             AAI_CELL_SCAN(2) AAI_CELL_SCAN(3) AAI_CELL_SCAN(4) AAI_CELL_SCAN(5) AAI_CELL_SCAN(6) AAI_CELL_SCAN(7) AAI_CELL_SCAN(8)
@@ -332,5 +381,7 @@ hipError_t launch_cell_scan(const RotLaunch &r, unsigned long long *laneMasks, u
 #undef AAI_CELL_SCAN
     return hipGetLastError();
 }
+
+#endif      // AAI_CELL_PART 1
 
 }  // namespace aai

@@ -234,7 +234,9 @@ __global__ __launch_bounds__(kQuadBlock) void aai_quad_fast_kernel(RotLaunch r, 
 // store, written around the caches), and walks the four rows its wave of the 16 x 16 tile owns -- so the skip masks, the
 // live tile spans and the fix-up list keep their tiling.  Per-pixel arithmetic is untouched: results are identical.
 template <typename T, int WIN, bool SCALED>
-__global__ __launch_bounds__(kQuadBlock) void aai_quad_fast_rows_kernel(RotLaunch r, QuadConsts<float> q, QuadMap m, const T *__restrict__ src, ImageView sv,
+// (at most 96 scalar registers: with 97 ... 112 a CU admits six 256-lane workgroups instead of seven -- MI355X_MICROARCH.md, Residency --
+// and this store-bound kernel loses a tenth of its rate: config 5 fast 1.50 -> 1.66 ms when a change of the source map took it to 99)
+__global__ __launch_bounds__(kQuadBlock) __attribute__((amdgpu_num_sgpr(96))) void aai_quad_fast_rows_kernel(RotLaunch r, QuadConsts<float> q, QuadMap m, const T *__restrict__ src, ImageView sv,
                                                                        float *__restrict__ dst, ImageView dv, const unsigned long long *__restrict__ skipMasks,
                                                                        const int *__restrict__ live, int tilesX)
 {
@@ -348,6 +350,7 @@ __global__ __launch_bounds__(kQuadBlock) void aai_quad_scan_kernel(RotLaunch r, 
     }
 }
 
+#if !defined(AAI_QUAD_PART) || AAI_QUAD_PART == 1
 // flagged dst pixels as a list of (dy << 32 | dx)... kept as two 32-bit words per pixel; any order (the fix-up pass
 // writes each listed pixel once)
 __global__ __launch_bounds__(256) void aai_flag_list_kernel(const unsigned long long *__restrict__ laneMasks, size_t waves, unsigned tilesX,
@@ -368,13 +371,17 @@ __global__ __launch_bounds__(256) void aai_flag_list_kernel(const unsigned long 
     }
 }
 
-// AAI_FAST_ROWS (A/B switch of tools/): 0 = always the 16 x 4 wave, 1 = row-shaped wave under replication and at ratios up to
-// 1.6 (default), 2 = row-shaped wave for every plain image below 4 GiB
+#endif
+
+// AAI_FAST_ROWS (A/B switch of tools/, experiments build only): 0 = always the 16 x 4 wave, 1 = row-shaped wave under replication and
+// at ratios up to 1.6 (default), 2 = row-shaped wave for every plain image below 4 GiB
 static int quad_fast_rows_mode()
 {
-    static const int mode = [] { const char *e = getenv("AAI_FAST_ROWS"); return e && e[0] >= '0' && e[0] <= '2' ? e[0] - '0' : 1; }();
+    static const int mode = [] { const char *e = experiment_env("AAI_FAST_ROWS"); return e && e[0] >= '0' && e[0] <= '2' ? e[0] - '0' : 1; }();
     return mode;
 }
+
+#if !defined(AAI_QUAD_PART) || AAI_QUAD_PART == 1
 
 // summary of the lane masks: one bit per 16 x 16 tile that holds a flagged pixel (QuadMap::tileFlags)
 __global__ __launch_bounds__(256) void aai_tile_flags_kernel(const unsigned long long *__restrict__ laneMasks, unsigned tilesX, unsigned tilesY, unsigned rowWords,
@@ -388,13 +395,16 @@ __global__ __launch_bounds__(256) void aai_tile_flags_kernel(const unsigned long
         }
     }
 }
+#endif
 
-template <typename T, int WIN>
+template <typename T, int WIN, int FAMILIES>
 hipError_t launch_quad_win(const RotLaunch &r, const QuadConsts<float> &q, const QuadMap &m, const T *src, ImageView sv, float *dst, ImageView dv,
                            int batch, const unsigned long long *skipMasks, hipStream_t stream, const int *live)
 {
     const dim3 grid((r.dW + 15) / 16, (r.dyEnd - r.dyBase + 15) / 16, batch);      // at most 65535 tile rows: the caller bands taller outputs
     if (r.mode == AAI_MODE_FAST) {
+      if constexpr ((FAMILIES & 2) == 0) return hipErrorInvalidValue;
+      else {
         // ... and without replication while a dst pixel is at most 1.6 source pixels wide (1.5:1 at 17.5 degrees 237 -> 189 us, 1:1 at
         // 45 degrees 480 -> 426; from 2:1 on the slanted line of source pixels a row-shaped wave reads costs more than its stores
         // save: 2:1 at 45 degrees 148 -> 206 us, 3:1 at 17.5 degrees 100 -> 158) -- profiles/r03_store_paths.txt
@@ -407,8 +417,10 @@ hipError_t launch_quad_win(const RotLaunch &r, const QuadConsts<float> &q, const
         } else if (m.scale > 1) hipLaunchKernelGGL((aai_quad_fast_kernel<T, WIN, true>), grid, dim3(kQuadBlock), 0, stream, r, q, m, src, sv, dst, dv, skipMasks, live);
         else hipLaunchKernelGGL((aai_quad_fast_kernel<T, WIN, false>), grid, dim3(kQuadBlock), 0, stream, r, q, m, src, sv, dst, dv, skipMasks, live);
         return hipGetLastError();
+      }
     }
-    if (m.scale > 1) {
+    if constexpr ((FAMILIES & 1) == 0) return hipErrorInvalidValue;
+    else if (m.scale > 1) {
         if (q.hiPrec) hipLaunchKernelGGL((aai_quad_kernel<T, WIN, true, true>), grid, dim3(kQuadBlock), 0, stream, r, q, m, src, sv, dst, dv, skipMasks, live);
         else hipLaunchKernelGGL((aai_quad_kernel<T, WIN, true, false>), grid, dim3(kQuadBlock), 0, stream, r, q, m, src, sv, dst, dv, skipMasks, live);
     } else {
@@ -456,13 +468,16 @@ hipError_t launch_quad_multi_win(const RotLaunch &r, const QuadConsts<float> &q,
     return launch_quad_multi_words<T, WIN, (sizeof(T) == 4 && WIN * WIN * 4 <= 80 ? 4 : 1)>(r, q, m, src, sv, dst, dv, batch, skipMasks, stream);
 }
 
-template <typename T>
+// FAMILIES: which kernel families this translation unit holds (see "translation units" below): 1 = area mode, plain images;
+// 2 = fast mode; 4 = interleaved channels
+template <typename T, int FAMILIES>
 hipError_t launch_quad_typed(const RotLaunch &r, const QuadMap &m, const T *src, ImageView sv, float *dst, ImageView dv, int batch,
                              const unsigned long long *skipMasks, hipStream_t stream, const int *live)
 {
     const QuadConsts<float> q = make_quad_consts<float>(r.side, r.c, r.s, r.policy, r.scale);
     if (r.chan > 1) {
-        switch (q.win) {
+        if constexpr ((FAMILIES & 4) == 0) return hipErrorInvalidValue;
+        else switch (q.win) {
         case 3: return launch_quad_multi_win<T, 3>(r, q, m, src, sv, dst, dv, batch, skipMasks, stream);
         case 4: return launch_quad_multi_win<T, 4>(r, q, m, src, sv, dst, dv, batch, skipMasks, stream);
         case 5: return launch_quad_multi_win<T, 5>(r, q, m, src, sv, dst, dv, batch, skipMasks, stream);
@@ -471,19 +486,50 @@ hipError_t launch_quad_typed(const RotLaunch &r, const QuadMap &m, const T *src,
         default: return launch_quad_multi_win<T, 8>(r, q, m, src, sv, dst, dv, batch, skipMasks, stream);
         }
     }
-    switch (r.mode == AAI_MODE_FAST ? q.winFast : q.win) {
-    case 2: return launch_quad_win<T, 2>(r, q, m, src, sv, dst, dv, batch, skipMasks, stream, live);
-    case 3: return launch_quad_win<T, 3>(r, q, m, src, sv, dst, dv, batch, skipMasks, stream, live);
-    case 4: return launch_quad_win<T, 4>(r, q, m, src, sv, dst, dv, batch, skipMasks, stream, live);
-    case 5: return launch_quad_win<T, 5>(r, q, m, src, sv, dst, dv, batch, skipMasks, stream, live);
-    case 6: return launch_quad_win<T, 6>(r, q, m, src, sv, dst, dv, batch, skipMasks, stream, live);
-    case 7: return launch_quad_win<T, 7>(r, q, m, src, sv, dst, dv, batch, skipMasks, stream, live);
-    default: return launch_quad_win<T, 8>(r, q, m, src, sv, dst, dv, batch, skipMasks, stream, live);
+    if constexpr ((FAMILIES & 3) == 0) return hipErrorInvalidValue;
+    else switch (r.mode == AAI_MODE_FAST ? q.winFast : q.win) {
+    case 2: return launch_quad_win<T, 2, FAMILIES>(r, q, m, src, sv, dst, dv, batch, skipMasks, stream, live);
+    case 3: return launch_quad_win<T, 3, FAMILIES>(r, q, m, src, sv, dst, dv, batch, skipMasks, stream, live);
+    case 4: return launch_quad_win<T, 4, FAMILIES>(r, q, m, src, sv, dst, dv, batch, skipMasks, stream, live);
+    case 5: return launch_quad_win<T, 5, FAMILIES>(r, q, m, src, sv, dst, dv, batch, skipMasks, stream, live);
+    case 6: return launch_quad_win<T, 6, FAMILIES>(r, q, m, src, sv, dst, dv, batch, skipMasks, stream, live);
+    case 7: return launch_quad_win<T, 7, FAMILIES>(r, q, m, src, sv, dst, dv, batch, skipMasks, stream, live);
+    default: return launch_quad_win<T, 8, FAMILIES>(r, q, m, src, sv, dst, dv, batch, skipMasks, stream, live);
     }
 }
 
 }  // namespace
 
+// ---- translation units ----------------------------------------------------------------------------------------------------------
+// As in aai_rotated_cell.hip: the runtime loads a translation unit's code object on the first launch of one of its kernels, so the
+// Makefile compiles this file once per AAI_QUAD_PART and a process pays for the kernels it uses: 1 = dispatch, scans, list / tile
+// flag kernels; 2 = fp32 plain images, area mode; 3 = fp32, fast mode (the reference's default mode); 4 = fp32 interleaved
+// channels; 5 = 8-bit, 6 = 16-bit sources (all families).  (AAI_QUAD_PART undefined = everything in one unit.)
+#define AAI_QUAD_ENTRY(name, T) \
+    hipError_t name(const RotLaunch &r, const QuadMap &m, const T *src, ImageView sv, float *dst, ImageView dv, int batch, const unsigned long long *skipMasks, hipStream_t stream, const int *live)
+AAI_QUAD_ENTRY(launch_quad_f32_area, float);
+AAI_QUAD_ENTRY(launch_quad_f32_fast, float);
+AAI_QUAD_ENTRY(launch_quad_f32_multi, float);
+AAI_QUAD_ENTRY(launch_quad_u8, unsigned char);
+AAI_QUAD_ENTRY(launch_quad_u16, unsigned short);
+#if !defined(AAI_QUAD_PART) || AAI_QUAD_PART == 2
+AAI_QUAD_ENTRY(launch_quad_f32_area, float) { return launch_quad_typed<float, 1>(r, m, src, sv, dst, dv, batch, skipMasks, stream, live); }
+#endif
+#if !defined(AAI_QUAD_PART) || AAI_QUAD_PART == 3
+AAI_QUAD_ENTRY(launch_quad_f32_fast, float) { return launch_quad_typed<float, 2>(r, m, src, sv, dst, dv, batch, skipMasks, stream, live); }
+#endif
+#if !defined(AAI_QUAD_PART) || AAI_QUAD_PART == 4
+AAI_QUAD_ENTRY(launch_quad_f32_multi, float) { return launch_quad_typed<float, 4>(r, m, src, sv, dst, dv, batch, skipMasks, stream, live); }
+#endif
+#if !defined(AAI_QUAD_PART) || AAI_QUAD_PART == 5
+AAI_QUAD_ENTRY(launch_quad_u8, unsigned char) { return launch_quad_typed<unsigned char, 7>(r, m, src, sv, dst, dv, batch, skipMasks, stream, live); }
+#endif
+#if !defined(AAI_QUAD_PART) || AAI_QUAD_PART == 6
+AAI_QUAD_ENTRY(launch_quad_u16, unsigned short) { return launch_quad_typed<unsigned short, 7>(r, m, src, sv, dst, dv, batch, skipMasks, stream, live); }
+#endif
+#undef AAI_QUAD_ENTRY
+
+#if !defined(AAI_QUAD_PART) || AAI_QUAD_PART == 1
 // How many source rows apart two lanes of one wave (a 16 x 4 dst tile) can read: their centres differ by at most
 // 15.6 dst pixel sides, each reaches half a window further, plus slack for rounding and clamping.
 int quad_anchor_rows(const RotLaunch &r)
@@ -520,9 +566,12 @@ hipError_t launch_quad(const RotLaunch &r, const QuadMap &map, const void *src, 
     const int64_t esz = srcType == SRC_U8 ? 1 : srcType == SRC_U16 ? 2 : 4;
     m.anchorRows = (int64_t)r.H * sv.rowStride * esz >= ((int64_t)1 << 32) ? quad_anchor_rows(r) : 0;
     switch (srcType) {
-    case SRC_U8: return launch_quad_typed(r, m, static_cast<const unsigned char *>(src), sv, dst, dv, batch, skipMasks, stream, live);
-    case SRC_U16: return launch_quad_typed(r, m, static_cast<const unsigned short *>(src), sv, dst, dv, batch, skipMasks, stream, live);
-    default: return launch_quad_typed(r, m, static_cast<const float *>(src), sv, dst, dv, batch, skipMasks, stream, live);
+    case SRC_U8: return launch_quad_u8(r, m, static_cast<const unsigned char *>(src), sv, dst, dv, batch, skipMasks, stream, live);
+    case SRC_U16: return launch_quad_u16(r, m, static_cast<const unsigned short *>(src), sv, dst, dv, batch, skipMasks, stream, live);
+    default:
+        if (r.chan > 1) return launch_quad_f32_multi(r, m, static_cast<const float *>(src), sv, dst, dv, batch, skipMasks, stream, live);
+        if (r.mode == AAI_MODE_FAST) return launch_quad_f32_fast(r, m, static_cast<const float *>(src), sv, dst, dv, batch, skipMasks, stream, live);
+        return launch_quad_f32_area(r, m, static_cast<const float *>(src), sv, dst, dv, batch, skipMasks, stream, live);
     }
 }
 
@@ -567,5 +616,7 @@ hipError_t launch_flag_list(const unsigned long long *laneMasks, size_t waves, u
                        static_cast<uint2 *>(list), cursor, capacity);
     return hipGetLastError();
 }
+
+#endif      // AAI_QUAD_PART 1
 
 }  // namespace aai

@@ -179,43 +179,50 @@ __global__ __launch_bounds__(kQuadBlock) void aai_wide_fast_scan_kernel(RotLaunc
     }
 }
 
-template <typename T, int WIN, int PARTS>
+// FAMILIES: 1 = area mode, 2 = fast mode (which kernels this translation unit holds: "translation units" below)
+template <typename T, int WIN, int PARTS, int FAMILIES>
 hipError_t launch_wide_win(const RotLaunch &r, const QuadConsts<float> &q, const QuadMap &m, const T *src, ImageView sv, float *dst, ImageView dv,
                            int batch, const unsigned long long *skipMasks, hipStream_t stream)
 {
     const int tilesX = (r.dW + 15) / 16;
     const dim3 grid(tilesX * (PARTS == 2 ? 4 : 16), (r.dyEnd - r.dyBase + 15) / 16, batch);      // at most 65535 tile rows: the caller bands taller outputs
     if (r.mode == AAI_MODE_FAST) {
-        hipLaunchKernelGGL((aai_wide_fast_kernel<T, WIN, PARTS>), grid, dim3(kQuadBlock), 0, stream, r, q, m, src, sv, dst, dv, skipMasks);
+        if constexpr ((FAMILIES & 2) == 0) return hipErrorInvalidValue;
+        else {
+            hipLaunchKernelGGL((aai_wide_fast_kernel<T, WIN, PARTS>), grid, dim3(kQuadBlock), 0, stream, r, q, m, src, sv, dst, dv, skipMasks);
+            return hipGetLastError();
+        }
+    }
+    if constexpr ((FAMILIES & 1) == 0) return hipErrorInvalidValue;
+    else {
+        if (q.hiPrec) hipLaunchKernelGGL((aai_wide_kernel<T, WIN, true, PARTS>), grid, dim3(kQuadBlock), 0, stream, r, q, m, src, sv, dst, dv, skipMasks);
+        else hipLaunchKernelGGL((aai_wide_kernel<T, WIN, false, PARTS>), grid, dim3(kQuadBlock), 0, stream, r, q, m, src, sv, dst, dv, skipMasks);
         return hipGetLastError();
     }
-    if (q.hiPrec) hipLaunchKernelGGL((aai_wide_kernel<T, WIN, true, PARTS>), grid, dim3(kQuadBlock), 0, stream, r, q, m, src, sv, dst, dv, skipMasks);
-    else hipLaunchKernelGGL((aai_wide_kernel<T, WIN, false, PARTS>), grid, dim3(kQuadBlock), 0, stream, r, q, m, src, sv, dst, dv, skipMasks);
-    return hipGetLastError();
 }
 
-template <typename T, int PARTS>
+template <typename T, int PARTS, int FAMILIES>
 hipError_t launch_wide_parts(const RotLaunch &r, const QuadConsts<float> &q, const QuadMap &m, const T *src, ImageView sv, float *dst, ImageView dv,
                              int batch, const unsigned long long *skipMasks, hipStream_t stream)
 {
     switch (r.mode == AAI_MODE_FAST ? q.winFast : q.win) {
-    case 5: return launch_wide_win<T, 5, PARTS>(r, q, m, src, sv, dst, dv, batch, skipMasks, stream);
-    case 6: return launch_wide_win<T, 6, PARTS>(r, q, m, src, sv, dst, dv, batch, skipMasks, stream);
-    case 7: return launch_wide_win<T, 7, PARTS>(r, q, m, src, sv, dst, dv, batch, skipMasks, stream);
-    case 8: return launch_wide_win<T, 8, PARTS>(r, q, m, src, sv, dst, dv, batch, skipMasks, stream);
+    case 5: return launch_wide_win<T, 5, PARTS, FAMILIES>(r, q, m, src, sv, dst, dv, batch, skipMasks, stream);
+    case 6: return launch_wide_win<T, 6, PARTS, FAMILIES>(r, q, m, src, sv, dst, dv, batch, skipMasks, stream);
+    case 7: return launch_wide_win<T, 7, PARTS, FAMILIES>(r, q, m, src, sv, dst, dv, batch, skipMasks, stream);
+    case 8: return launch_wide_win<T, 8, PARTS, FAMILIES>(r, q, m, src, sv, dst, dv, batch, skipMasks, stream);
     default: return hipErrorInvalidValue;
     }
 }
 
-template <typename T>
+template <typename T, int FAMILIES>
 hipError_t launch_wide_typed(const RotLaunch &r, const QuadMap &m, const T *src, ImageView sv, float *dst, ImageView dv, int batch,
                              const unsigned long long *skipMasks, hipStream_t stream)
 {
     const QuadConsts<float> q = make_quad_consts<float>(r.side, r.c, r.s, r.policy, r.scale);
     const int parts = r.mode == AAI_MODE_FAST ? q.partsFast : q.parts;
     if (parts != r.wide) return hipErrorInvalidValue;
-    if (parts == 2) return launch_wide_parts<T, 2>(r, q, m, src, sv, dst, dv, batch, skipMasks, stream);
-    return launch_wide_parts<T, 4>(r, q, m, src, sv, dst, dv, batch, skipMasks, stream);
+    if (parts == 2) return launch_wide_parts<T, 2, FAMILIES>(r, q, m, src, sv, dst, dv, batch, skipMasks, stream);
+    return launch_wide_parts<T, 4, FAMILIES>(r, q, m, src, sv, dst, dv, batch, skipMasks, stream);
 }
 
 template <int PARTS>
@@ -243,9 +250,32 @@ hipError_t launch_wide_scan_parts(const RotLaunch &r, const QuadConsts<float> &q
 
 }  // namespace
 
+// ---- translation units (as in aai_rotated_cell.hip: a process loads the code object of the kernels it uses) ------------------------
+// AAI_WIDE_PART: 1 = dispatch + scan kernels, 2 = fp32 area mode, 3 = fp32 fast mode, 4 = 8-bit, 5 = 16-bit sources; undefined = all
+#define AAI_WIDE_ENTRY(name, T) \
+    hipError_t name(const RotLaunch &r, const QuadMap &m, const T *src, ImageView sv, float *dst, ImageView dv, int batch, const unsigned long long *skipMasks, hipStream_t stream)
+AAI_WIDE_ENTRY(launch_wide_f32_area, float);
+AAI_WIDE_ENTRY(launch_wide_f32_fast, float);
+AAI_WIDE_ENTRY(launch_wide_u8, unsigned char);
+AAI_WIDE_ENTRY(launch_wide_u16, unsigned short);
+#if !defined(AAI_WIDE_PART) || AAI_WIDE_PART == 2
+AAI_WIDE_ENTRY(launch_wide_f32_area, float) { return launch_wide_typed<float, 1>(r, m, src, sv, dst, dv, batch, skipMasks, stream); }
+#endif
+#if !defined(AAI_WIDE_PART) || AAI_WIDE_PART == 3
+AAI_WIDE_ENTRY(launch_wide_f32_fast, float) { return launch_wide_typed<float, 2>(r, m, src, sv, dst, dv, batch, skipMasks, stream); }
+#endif
+#if !defined(AAI_WIDE_PART) || AAI_WIDE_PART == 4
+AAI_WIDE_ENTRY(launch_wide_u8, unsigned char) { return launch_wide_typed<unsigned char, 3>(r, m, src, sv, dst, dv, batch, skipMasks, stream); }
+#endif
+#if !defined(AAI_WIDE_PART) || AAI_WIDE_PART == 5
+AAI_WIDE_ENTRY(launch_wide_u16, unsigned short) { return launch_wide_typed<unsigned short, 3>(r, m, src, sv, dst, dv, batch, skipMasks, stream); }
+#endif
+#undef AAI_WIDE_ENTRY
+
+#if !defined(AAI_WIDE_PART) || AAI_WIDE_PART == 1
 bool wide_can_serve(const RotLaunch &r, int srcType, ImageView sv)
 {
-    static const bool off = [] { const char *e = getenv("AAI_WIDE"); return e && atoi(e) == 0; }();      // experiments: AAI_WIDE=0 keeps the runs kernel
+    static const bool off = [] { const char *e = experiment_env("AAI_WIDE"); return e && atoi(e) == 0; }();      // experiments: AAI_WIDE=0 keeps the runs kernel
     if (off || !r.wide || (r.mode != AAI_MODE_AREA && r.mode != AAI_MODE_FAST) || r.chan != 1 || r.scale != 1 || (r.dyBase & 15) != 0) return false;
     // (tilesX * 16 blocks along grid.x)
     if ((int64_t)((r.dW + 15) / 16) * 16 > 2147483647ll) return false;
@@ -260,9 +290,11 @@ hipError_t launch_wide(const RotLaunch &r, const QuadMap &map, const void *src, 
     const int64_t esz = srcType == SRC_U8 ? 1 : srcType == SRC_U16 ? 2 : 4;
     m.anchorRows = (int64_t)r.H * sv.rowStride * esz >= ((int64_t)1 << 32) ? quad_anchor_rows(r) : 0;
     switch (srcType) {
-    case SRC_U8: return launch_wide_typed(r, m, static_cast<const unsigned char *>(src), sv, dst, dv, batch, skipMasks, stream);
-    case SRC_U16: return launch_wide_typed(r, m, static_cast<const unsigned short *>(src), sv, dst, dv, batch, skipMasks, stream);
-    default: return launch_wide_typed(r, m, static_cast<const float *>(src), sv, dst, dv, batch, skipMasks, stream);
+    case SRC_U8: return launch_wide_u8(r, m, static_cast<const unsigned char *>(src), sv, dst, dv, batch, skipMasks, stream);
+    case SRC_U16: return launch_wide_u16(r, m, static_cast<const unsigned short *>(src), sv, dst, dv, batch, skipMasks, stream);
+    default:
+        if (r.mode == AAI_MODE_FAST) return launch_wide_f32_fast(r, m, static_cast<const float *>(src), sv, dst, dv, batch, skipMasks, stream);
+        return launch_wide_f32_area(r, m, static_cast<const float *>(src), sv, dst, dv, batch, skipMasks, stream);
     }
 }
 
@@ -274,5 +306,7 @@ hipError_t launch_wide_scan(const RotLaunch &r, unsigned long long *laneMasks, u
     if (parts != r.wide) return hipErrorInvalidValue;
     return parts == 2 ? launch_wide_scan_parts<2>(r, q, laneMasks, counter, stream) : launch_wide_scan_parts<4>(r, q, laneMasks, counter, stream);
 }
+
+#endif      // AAI_WIDE_PART 1
 
 }  // namespace aai

@@ -70,7 +70,18 @@ enum {
      * dst value is not hundreds of times smaller than those neighbours (fuzz of round 2: worst 1-3e-6 of
      * max(|value|, 1e-3) per 3,000 random cases).  Images
      * whose neighbouring values span many orders of magnitude can ask for double precision here. */
-    AAI_POLICY_DOUBLE_PRECISION = 0x100
+    AAI_POLICY_DOUBLE_PRECISION = 0x100,
+    /* OR into either policy -- a hint: general rotations in area mode take the "cell" formulation (every (dst, src) pair evaluated
+     * once and shared between the dst pixels it feeds) also for outputs below ~720 x 720 pixels, which by default stay on the
+     * one-lane-per-pixel kernel because the cell kernel's long-lived waves cannot fill the chip there.  Same results to ~1e-6
+     * (both are pinned to the reference); tests use it to run every fixture through both formulations. */
+    AAI_POLICY_PREFER_CELL = 0x200,
+    /* OR into either policy -- a DIAGNOSTIC, per request (there is no process-wide switch): the double-precision pass over the
+     * dst pixels the plan lists (aai_plan_info: flagged=) is not launched, so those pixels keep the bytes the caller's buffer
+     * held.  The output of such a request is NOT the reference's answer in the listed pixels.  For tests (which pixels do the
+     * fp32 kernels leave alone?) and timing (what does the pass cost beside the production kernel?). */
+    AAI_POLICY_DIAG_NO_FIXUP = 0x400,
+    AAI_POLICY_RULE_MASK = 0xff   /* the weight policy proper: AAI_POLICY_REFERENCE or AAI_POLICY_EXACT */
 };
 
 /* Source element types of the typed entry points (real images are rarely double).
@@ -160,6 +171,14 @@ int aai_prepare(const aai_request *req, int32_t channels /* 1 for plain images; 
  *   - rotated area / fast requests: one or two scan kernels over the output (pixels left to the double-precision pass).
  * All of it runs on a private stream and blocks only the calling thread: plans of other requests, devices and threads are
  * built and launched from concurrently.
+ *
+ * Environment variables the shipping library reads (all of them; launch-heuristic overrides exist only in the experiments build,
+ * `make -C area_average_interpolation_amd/csrc exp`):
+ *   AAI_AXIS_AUTOTUNE=0      no launch-shape measurement for K1 (built-in shape), see above
+ *   AAI_MAX_LISTED_PIXELS=n  a plan whose scans list more than n pixels (default 16 M) hands the WHOLE image to the double-precision
+ *                            pass instead of keeping the list (`dense` in aai_plan_info); results are the same either way, only the
+ *                            time differs -- tests lower it to exercise that form on small images
+ *   AAI_TRACE_PLAN=1         stage timings of every plan build on stderr
  *
  * aai_plan_info writes a one-line description of the cached whole-image plan of `req` on the current device into `text`
  * ("" when there is none yet): "kernel=K rows=R nt=N swap=S tune=measured|cached|default flagged=F dense=D form=cell|quad|-

@@ -58,6 +58,13 @@ int aai_oracle_rows(int mode, int policy, const void *src, int srcIsF32, int W, 
                     double isoX, double isoY, double angleDeg,
                     int row0, int row1, double *out, char *err, int errLen);
 
+/* A list of n dst pixels (xs[k], ys[k]) -> out[k]: unbiased samples of images too large for a full CPU run.  Each is evaluated
+ * right after its predecessor in the reference's loop order, so the loop's persistent state is what the reference would hold. */
+int aai_oracle_pixels(int mode, int policy, const void *src, int srcIsF32, int W, int H,
+                      double srcResX, double srcResY, double dstResX, double dstResY,
+                      double isoX, double isoY, double angleDeg,
+                      int n, const int *xs, const int *ys, double *out, char *err, int errLen);
+
 void aai_oracle_free(void *p);
 
 /* Per-pair areas of one dst pixel over the reference's search window (test / debug aid). */

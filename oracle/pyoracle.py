@@ -159,6 +159,27 @@ def oracle_rows(mode, src_f32, src_res, dst_res, iso, angle, row0, row1, dst_wid
     return out
 
 
+def oracle_pixels(mode, src_f32, src_res, dst_res, iso, angle, xs, ys, policy=POLICY_REFERENCE):
+    """A list of dst pixels (aai_oracle_pixels): unbiased samples of images too large for a full CPU run (~80 us per pixel at
+    3:1).  src_f32 is an [H, W] float32 array; returns float64 values, one per (xs[k], ys[k])."""
+    lib = _load_oracle()
+    lib.aai_oracle_pixels.restype = ctypes.c_int
+    lib.aai_oracle_pixels.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int] + \
+        [ctypes.c_double] * 7 + [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int]
+    a = np.ascontiguousarray(src_f32, dtype=np.float32)
+    H, W = a.shape
+    x = np.ascontiguousarray(xs, dtype=np.int32)
+    y = np.ascontiguousarray(ys, dtype=np.int32)
+    assert x.shape == y.shape and x.ndim == 1
+    out = np.empty(x.shape[0], np.float64)
+    err = ctypes.create_string_buffer(256)
+    ok = lib.aai_oracle_pixels(int(mode), int(policy), a.ctypes.data, 1, W, H, float(src_res), float(src_res), float(dst_res), float(dst_res),
+                               float(iso[0]), float(iso[1]), float(angle), int(x.shape[0]), x.ctypes.data, y.ctypes.data, out.ctypes.data, err, 256)
+    if not ok:
+        raise RuntimeError(err.value.decode())
+    return out
+
+
 def synth_image(W, H, seed=1):
     """SURVEY.md Appendix C.1 generator, vectorised numpy (uint64 wraparound arithmetic)."""
     with np.errstate(over="ignore"):

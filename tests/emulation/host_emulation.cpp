@@ -880,7 +880,7 @@ long aai_emu_cell_live_rows_check(const aai_request *rq)
     long bad = 0;
     for (int x0 = 0; x0 <= r.dW; x0 += 63) {
         int lo, hi;
-        cell_live_rows(r, z, x0, x0 + 63, lo, hi);
+        cell_live_rows(make_cell_live(r, z), x0, x0 + 63, lo, hi);
         for (int y = 0; y <= r.dH; ++y)
             for (int x = x0; x <= std::min(x0 + 63, r.dW); ++x) {
                 const size_t at = (size_t)y * cells.W1 + x;

@@ -106,6 +106,60 @@ def test_baseline_configs_against_reference_known_answers(gpu, name):
         del dst
 
 
+def _ring(dW, dH):
+    """every pixel of the canvas border ring"""
+    xs = np.concatenate([np.arange(dW), np.arange(dW), np.zeros(dH - 2, int), np.full(dH - 2, dW - 1)])
+    ys = np.concatenate([np.zeros(dW, int), np.full(dW, dH - 1), np.arange(1, dH - 1), np.arange(1, dH - 1)])
+    return xs, ys
+
+
+@pytest.mark.parametrize("name,image,samples,ring", [("cfg2", "noise", 4000, True), ("cfg3", "noise", 4000, True), ("cfg5s", "noise", 4000, True),
+                                                      ("cfg5", "noise", 500, True), ("cfg3", "dose", 4000, False)])
+def test_full_size_configs_at_random_pixels_and_on_the_canvas_border(gpu, po, name, image, samples, ring):
+    """The known-answer test above looks at a fixed strided grid and seven rows -- always the same ~26 k pixels, never the canvas
+    border as a whole.  Here: seeded-random dst pixels (4,000; 500 at the full config 5) plus EVERY pixel of the canvas border ring,
+    both modes, against the CPU oracle evaluated pixel by pixel (aai_oracle_pixels: each pixel right after its predecessor in the
+    reference's loop order) on the same image -- 1e-5 relative with an absolute floor of 1e-6 (not the 1e-3 of the fixture tests),
+    exact zeros exact.  "dose": config 3's ratio and rotation on a 2048 x 2048 dose-like image (flat field, penumbrae, tails at 1e-4 of
+    the maximum)."""
+    import torch
+    z, meta = load_full(name)
+    W, H = meta["W"], meta["H"]
+    if image == "dose":
+        # (a quarter of the linear size: the dose image is synthesised on the host, ~6 s at 2048^2; same ratio, same rotation, still
+        # large enough for the cell kernel)
+        W, H = W // 4, H // 4
+        meta = dict(meta, iso=[(W - 1) / 2, (H - 1) / 2])
+        host = po.dose_image(W, H, 1)
+        src = torch.from_numpy(host).cuda()
+    else:
+        host = po.synth_image(W, H, 1)
+        src = torch.empty((H, W), dtype=torch.float32, device="cuda")
+        gpu.synth_device(src.data_ptr(), W, H, W, 1)
+        assert torch.equal(src[:4].cpu(), torch.from_numpy(host[:4]))
+    rng = np.random.default_rng({"cfg2": 2, "cfg3": 3, "cfg5s": 55, "cfg5": 5}[name] + (100 if image == "dose" else 0))
+    for tag, mode, omode in (("exact", 1, po.MODE_EXACT), ("fast", 2, po.MODE_FAST)):
+        rq = gpu.make_request(W, H, meta["src_res"], meta["dst_res"], meta["iso"], meta["angle"], mode=mode)
+        rc, msg, lay = gpu.query(rq)
+        assert rc == 0, msg
+        dW, dH = lay.dst_width, lay.dst_height
+        dst = torch.full((dH, dW), -1.0, dtype=torch.float32, device="cuda")
+        gpu.resample_device(rq, src.data_ptr(), W, dst.data_ptr(), dW, torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        xs, ys = rng.integers(0, dW, samples), rng.integers(0, dH, samples)
+        if ring:
+            rx, ry = _ring(dW, dH)
+            xs, ys = np.concatenate([xs, rx]), np.concatenate([ys, ry])
+        gold = po.oracle_pixels(omode, host, meta["src_res"], meta["dst_res"], meta["iso"], meta["angle"], xs, ys)
+        got = dst[torch.from_numpy(ys).cuda(), torch.from_numpy(xs).cuda()].cpu().numpy()
+        err = rel_err(got, gold, floor=1e-6)
+        worst = int(err.argmax())
+        assert err.max() <= TOL, (name, image, tag, gpu.last_kernel(), int(xs[worst]), int(ys[worst]), float(got[worst]), float(gold[worst]))
+        assert np.array_equal(got == 0, gold == 0), (name, image, tag)
+        assert (gold[:samples] != 0).sum() > samples // 4            # (the random pixels are not all in the canvas's empty corners)
+        del dst
+
+
 # ---- (b) oracle on the same seeded inputs -------------------------------------------------------------------
 def test_reference_default_call_on_a_dose_like_image(gpu, formulation, po, refdefault_golden):
     """The reference's own example call (Source.cpp:1528-1534: a 911 x 911 film at 150 dpi to 25.4 dpi about (455, 455), rotated

@@ -230,3 +230,24 @@ def test_bicubic_restatement_equals_the_published_keys_kernel(po):
                 ref += wy * keys_kernel(sx - (fx + kx)) * x64[iy, ix]
         assert float((gold - ref)[inside].abs().max()) <= 1e-13
         assert not (~inside).any() or float(gold[~inside].abs().max()) == 0.0
+
+
+def test_pixel_list_equals_the_full_run(po, small_golden):
+    """aai_oracle_pixels (the unbiased samples of the full-size GPU tests) against aai_oracle_run, pixel for pixel and bit for bit:
+    random geometries and the golden knife-edge cases, where the reference's loop state that persists from pixel to pixel
+    (dstVertex[], r[], s[]; Source.cpp:1014-1021) can decide a pair -- hence every listed pixel is evaluated right after its
+    predecessor in the loop order."""
+    z, manifest = small_golden
+    rng = np.random.default_rng(4)
+    cases = [manifest[i] for i in (48, 49, 73, 105, 108, 109, 131, 132)] + [manifest[int(i)] for i in rng.integers(0, len(manifest), 12)]
+    for c in cases:
+        src = po.synth_image(c["W"], c["H"], c["seed"])
+        for mode in (po.MODE_EXACT, po.MODE_FAST):
+            full = po.oracle_run(mode, src.astype(np.float64), c["src_res"], c["dst_res"], c["iso"], c["angle"])
+            assert full.ok
+            dH, dW = full.dst.shape
+            if dH * dW == 0:
+                continue
+            ys, xs = np.divmod(rng.permutation(dH * dW)[:400], dW)
+            got = po.oracle_pixels(mode, src, c["src_res"], c["dst_res"], c["iso"], c["angle"], xs, ys)
+            assert np.array_equal(got, full.dst[ys, xs]), (c, mode)

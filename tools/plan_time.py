@@ -26,12 +26,20 @@ def prep(name, W, H, sr, dr, ang, mode, iso=None):
 
 # first touch: the runtime loads each translation unit's code object on its first launch (~5-20 ms per unit, once per process)
 t0 = time.perf_counter()
-for (sr, ang, mode) in ((2.0, 0.0, 1), (2.0, 90.0, 1), (3.0, 17.5, 1), (3.0, 17.5, 2), (1.0, 33.0, 3), (8.0, 12.0, 1)):
+aai.debug_cell_min_waves(0)          # small images take the cell kernel too: its translation units are among the first touches
+for (sr, ang, mode) in ((2.0, 0.0, 1), (2.0, 90.0, 1), (3.0, 17.5, 1), (3.0, 17.5, 2), (1.0, 33.0, 3), (8.0, 12.0, 1), (8.0, 12.0, 2)):
     img = torch.rand((96, 96), dtype=torch.float32, device="cuda")
     rq = aai.make_request(96, 96, sr, 1.0, (47.5, 47.5), ang, mode=mode)
     rc, msg, lay = aai.query(rq)
     out = torch.empty((lay.dst_height, lay.dst_width), dtype=torch.float32, device="cuda")
     aai.resample_device(rq, img.data_ptr(), 96, out.data_ptr(), lay.dst_width, torch.cuda.current_stream().cuda_stream)
+    if mode == 1 and ang == 17.5:
+        aai.debug_cell_min_waves(-1)     # ... and once more on the quad kernel
+        rq2 = aai.make_request(96, 96, 2.5, 1.0, (47.5, 47.5), ang, mode=mode)
+        rc, msg, lay2 = aai.query(rq2)
+        out2 = torch.empty((lay2.dst_height, lay2.dst_width), dtype=torch.float32, device="cuda")
+        aai.resample_device(rq2, img.data_ptr(), 96, out2.data_ptr(), lay2.dst_width, torch.cuda.current_stream().cuda_stream)
+aai.debug_cell_min_waves(-1)
 torch.cuda.synchronize()
 print("first touch of every kernel family (code objects loaded): %.1f ms" % (1e3 * (time.perf_counter() - t0)))
 print("AAI_AXIS_AUTOTUNE=%s AAI_AXIS_CLASS_VERIFY=%s" % (os.environ.get("AAI_AXIS_AUTOTUNE", "1"), os.environ.get("AAI_AXIS_CLASS_VERIFY", "1")))

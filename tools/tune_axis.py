@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Sweep the launch knobs of the axis-aligned kernel on the cfg2 workload (through the library's experiment hook
 aai_debug_axis_tune, the run-time form of AAI_AXIS_TUNE).  Variants are interleaved in ONE process, several rounds each;
-reports median and min per variant, then what the plan's own autotune picked on this box (aai_debug_plan_shape)."""
+reports median and min per variant, then what the plan's own autotune picked on this box (aai_plan_info).
+Needs the experiments build: make -C area_average_interpolation_amd/csrc exp; AAI_LIB=area_average_interpolation_amd/libaai_hip_exp.so"""
 import itertools
 import os
 import sys
@@ -16,8 +17,6 @@ from area_average_interpolation_amd import _lib as L
 lib = L.load()
 lib.aai_debug_axis_tune.restype = None
 lib.aai_debug_axis_tune.argtypes = [ctypes.c_char_p]
-lib.aai_debug_plan_shape.restype = ctypes.c_char_p
-lib.aai_debug_plan_shape.argtypes = [ctypes.POINTER(L.Request)]
 
 W = H = int(os.environ.get("TUNE_SIZE", "8192"))
 B = int(os.environ.get("TUNE_BATCH", "4"))
@@ -73,7 +72,7 @@ for v in best:
     print("%-46s median %.1f us (%.0f GB/s, %.1f%% of 8 TB/s)  min %.1f us (%.0f GB/s)" % (
         v, med * 1e3, alg / med / 1e6, alg / med / 1e6 / 80, mn * 1e3, alg / mn / 1e6))
 lib.aai_debug_axis_tune(b"")
-print("plan autotune on this box:", lib.aai_debug_plan_shape(ctypes.byref(rq)).decode())
+print("plan autotune on this box:", aai.plan_shape(rq))
 t = []
 for r in range(ROUNDS):
     run()
