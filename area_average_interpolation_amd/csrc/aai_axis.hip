@@ -425,6 +425,9 @@ template <bool NT, typename T, int NR, int kDepth, typename Finish>
 __device__ __forceinline__ void tile_columns(const T *__restrict__ img, int64_t rowStride, int colc, const AxisEntry *__restrict__ rowTab, int kb0, int nCols,
                                              Finish &&finish_column)
 {
+    // (the trailing waves of the last cooperative workgroup have no output rows: row kb0 then lies past the table's end and must
+    // not even be looked at; their caller still meets the other waves at its barrier)
+    if (nCols <= 0) return;
     RowsN<T, NR> ring[kDepth];
     Win wring[kDepth];
     bool tall = false;

@@ -54,9 +54,8 @@ AAI_HD bool axis_pixel_differs(const RotLaunch &r, int dx, int dy)
     double px, py;
     pixel_centre(r, dx, dy, px, py);
     if (!pixel_on_knife_edge(r, px, py, true)) return false;       // generic pixels: the closed forms ARE the products
-    const double hb = r.h * (r.c + r.s);
-    const int x0 = (int)fmax(0.0, floor(px - hb + 0.5 - AAI_KNIFE_GUARD)), x1 = (int)fmin((double)(r.mW - 1), ceil(px + hb - 0.5 + AAI_KNIFE_GUARD));
-    const int y0 = (int)fmax(0.0, floor(py - hb + 0.5 - AAI_KNIFE_GUARD)), y1 = (int)fmin((double)(r.mH - 1), ceil(py + hb - 0.5 + AAI_KNIFE_GUARD));
+    int x0, x1, y0, y1;
+    rot_window(r, px, py, x0, x1, y0, y1);
     SVec sv4[4];
     bool haveVertices = false;
     double sumStrict = 0.0, sumProduct = 0.0;
@@ -98,9 +97,8 @@ AAI_HD bool axis_pixel_differs_fast(const RotLaunch &r, int dx, int dy)
     double lox, hix, loy, hiy;
     axis_pixel_edges(r, dx, dy, lox, hix, loy, hiy);
     const bool span = hix > lox && hiy > loy;
-    const double hb = r.h * (r.c + r.s);
-    const int x0 = (int)fmax(0.0, floor(px - hb + 0.5 - AAI_KNIFE_GUARD)), x1 = (int)fmin((double)(r.mW - 1), ceil(px + hb - 0.5 + AAI_KNIFE_GUARD));
-    const int y0 = (int)fmax(0.0, floor(py - hb + 0.5 - AAI_KNIFE_GUARD)), y1 = (int)fmin((double)(r.mH - 1), ceil(py + hb - 0.5 + AAI_KNIFE_GUARD));
+    int x0, x1, y0, y1;
+    rot_window(r, px, py, x0, x1, y0, y1);
     const double lim = r.h + DBL_EPSILON * r.side;
     SVec sv4[4];
     bool haveVertices = false;

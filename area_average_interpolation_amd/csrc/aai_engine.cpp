@@ -542,7 +542,7 @@ int enqueue(const aai_request &rq, int batch, const void *dSrc, int srcType, int
     if (band0 >= 0) {
         int srcRow0 = p->srcRow0, srcRow1 = p->srcRow1;
         if (!axisKernel) aai::rotated_band_source_rows(g, band0, band1, p->kernel == AAI_KERNEL_SAMPLE, srcRow0, srcRow1);
-        r.dyBase = band0; r.dyEnd = band1; r.srcRow0 = srcRow0;
+        r.dyBase = band0; r.dyEnd = band1; r.srcRow0 = srcRow0; r.srcRow1 = srcRow1;
     }
     r.chan = channels;
     if (axisKernel && !p->dense) {

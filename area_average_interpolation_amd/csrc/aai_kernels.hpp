@@ -95,6 +95,9 @@ hipError_t launch_flag_list(const unsigned long long *laneMasks, size_t waves, u
 hipError_t launch_rotated(const RotLaunch &r, const QuadMap &m, const void *src, int srcType, ImageView sv, float *dst, ImageView dv,
                           int batch, const RotFlags &flags, hipStream_t stream, const char **kernelName);
 bool quad_can_address(const RotLaunch &r, int srcType, ImageView sv);
+// (which form of the kernel family a launch_quad call took, where it has several: a static string, or NULL; per thread)
+void set_quad_kernel_note(const char *note);
+const char *quad_kernel_note();
 hipError_t launch_quad(const RotLaunch &r, const QuadMap &m, const void *src, int srcType, ImageView sv, float *dst, ImageView dv,
                        int batch, const unsigned long long *skipMasks, hipStream_t stream, const int *live = nullptr);
 

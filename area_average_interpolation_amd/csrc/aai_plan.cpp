@@ -133,7 +133,7 @@ RotLaunch make_rot_launch(const Geometry &g, int mode, int policy)
     r.dW = g.dW; r.dH = g.dH; r.mW = g.mW; r.mH = g.mH; r.W = g.W; r.H = g.H;
     r.scale = g.scale; r.quadrant = g.quadrant; r.mode = mode; r.policy = policy & AAI_POLICY_RULE_MASK;
     r.preferCell = (policy & AAI_POLICY_PREFER_CELL) ? 1 : 0; r.noFixup = (policy & AAI_POLICY_DIAG_NO_FIXUP) ? 1 : 0;
-    r.dyBase = 0; r.dyEnd = g.dH; r.srcRow0 = 0; r.chan = 1;
+    r.dyBase = 0; r.dyEnd = g.dH; r.srcRow0 = 0; r.srcRow1 = g.H; r.chan = 1;
     r.invScale = 1.0 / g.scale;
     const double c = g.cs, s = g.sn, h = 0.5 * g.side;
     r.c = c; r.s = s; r.h = h;
@@ -231,13 +231,24 @@ QuadMap make_quad_map(const Geometry &g, int64_t rowStride, int srcRow0, int cha
 
 void rotated_band_source_rows(const Geometry &g, int row0, int row1, bool sampler, int &srcRow0, int &srcRow1)
 {
-    // virtual-lattice bounding box of the band: centres are affine in (dx,dy), so its four corner pixels bound it
-    // area / fast kernels reach half a rotated dst pixel (+1); the samplers' taps reach 2 original pixels.
-    // The cell kernel (aai_rot_cell.hpp) also evaluates the cells of dst row `row1` and dst column dW (their N / W parts
-    // belong to the band's last row / column) and fetches whole lattice windows around ZONE centres, which sit up to
-    // (c + s) / 2 < 0.71 beside the pixel centre: the box therefore spans cells [0, dW] x [row0, row1] and reaches one more pixel.
-    // The wide-footprint kernel (aai_rotated_wide.hip) splits its window into parts that may overhang it by up to 3 positions.
-    const double hb = 0.5 * g.side * (std::fabs(g.cs) + std::fabs(g.sn)) + 2.0 + (sampler ? 3.0 * g.scale : 0.0) + (!sampler && g.side > 5.0 ? 3.0 : 0.0);
+    // virtual-lattice bounding box of the band: centres are affine in (dx,dy), so its four corner pixels bound it, and every kernel
+    // family that may serve the request reaches a known distance beyond a pixel's centre -- the constants come from the headers
+    // that hold the windows' formulas (rot_window_reach, quad_window_reach, quad_fast_window_reach, cell_window_reach), not from
+    // prose; tests/emulation replays the windows of every family against the rows reported here (aai_emu_band_cover).
+    // The cell kernel also evaluates the cells of dst row `row1` and dst column dW (their N / W parts belong to the band's last row /
+    // column): the box spans cells [0, dW] x [row0, row1].  The samplers' taps reach 2 ORIGINAL pixels from the sample point.
+    const double c = std::fabs(g.cs), s = std::fabs(g.sn);
+    double hb = rot_window_reach(0.5 * g.side, c, s);                      // the double-precision kernels and the fix-up pass: always possible
+    if (sampler) hb = 3.0 * g.scale;
+    else if (c > 0.0 && s > 0.0) {
+        if (quad_supported(g.side, c, s) || quad_wide_parts(g.side, c, s) || quad_fast_parts(g.side, c, s)) {
+            const QuadConsts<float> q = make_quad_consts<float>(g.side, c, s, AAI_POLICY_REFERENCE, g.scale);
+            if (quad_supported(g.side, c, s) || quad_wide_parts(g.side, c, s)) hb = std::max(hb, quad_window_reach(q));
+            if (quad_fast_parts(g.side, c, s)) hb = std::max(hb, quad_fast_window_reach(q));
+        }
+        if (cell_supported(g.side, c, s)) hb = std::max(hb, cell_window_reach(make_cell_consts<float>(g.side, c, s)));
+    }
+    hb += 0.5;                                                             // (slack for the centres' own rounding)
     double minX = 1e300, maxX = -1e300, minY = 1e300, maxY = -1e300;
     for (int c = 0; c < 4; ++c) {
         double px, py;

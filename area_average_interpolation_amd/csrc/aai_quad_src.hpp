@@ -9,6 +9,37 @@ namespace aai {
 
 constexpr int kQuadBlock = 256;      // lanes per workgroup: the LDS window is [slot][kQuadBlock], one column per lane
 
+// ---- XCD-aware workgroup order ---------------------------------------------------------------------------------------------------
+// Workgroups are dealt round-robin over the 8 XCDs (workgroup b of a launch runs on XCD b % 8: MI355X_MICROARCH.md), each with an L2 of
+// its own.  In launch order horizontally adjacent tiles of a rotated request -- whose slanted footprints share 128-byte lines -- sit
+// behind different L2s and every shared line crosses the fabric once per L2 that wants it: config 3's fast mode asked the fabric for
+// 1.75 x its source and was bound by exactly that traffic (profiles/r04_fast_xcd.txt).  With `band` > 0 the linear workgroup index is
+// re-read so that XCD x owns the tile rows [band (8 n + x), band (8 n + x + 1)) of every group of 8 band tile rows and walks them column
+// by column: its neighbours in x (and, inside a band, in y) are its own predecessors, and the 8 XCDs advance in step over rows of
+// (nearly) equal length, so none runs out of work early (the contiguous bands and cyclic super-tiles of rounds 2-3 lost to that).
+// gridDim.y must be a multiple of 8 band (xcd_grid_rows); rows beyond the real ones are the caller's to skip.
+__device__ __forceinline__ void xcd_tile(int band, int &tx, int &ty)
+{
+    if (band <= 0) return;
+    const unsigned b = blockIdx.y * gridDim.x + blockIdx.x, group = gridDim.x * 8u * (unsigned)band;
+    const unsigned super = b / group, within = b - super * group, j = within >> 3;
+    tx = (int)(j / (unsigned)band);
+    ty = (int)((super * 8u + (within & 7u)) * (unsigned)band + j % (unsigned)band);
+}
+// the band height a launcher uses: its default, or AAI_XCD_ROWS in the experiments build
+inline int xcd_band(int dflt)
+{
+    static const int env = [] { const char *e = experiment_env("AAI_XCD_ROWS"); return e ? atoi(e) : -1; }();
+    return env >= 0 ? env : dflt;
+}
+// gridDim.y for `rows` tile rows under xcd_tile; 0: the order cannot be used (more than 65535 rows)
+inline int xcd_grid_rows(int rows, int band)
+{
+    if (band <= 0) return rows;
+    const int64_t padded = ((int64_t)rows + 8 * band - 1) / (8 * band) * (8 * band);
+    return padded <= 65535 ? (int)padded : 0;
+}
+
 // N consecutive fp32 elements from an element-aligned address in as few load instructions as possible
 template <int N>
 __device__ __forceinline__ void load_line(const float *p, float (&seg)[N])
@@ -36,7 +67,12 @@ __device__ __forceinline__ bool tiles_flagged(const unsigned *__restrict__ tileF
 // strides), one table per axis; positions outside the lattice are clamped onto it -- their values are fetched but
 // never read (quad_pixel only reads slots whose valid bit is set).
 // STAGED: the caller reads values through commit() / at() only (not reg()): vector-loaded lines may stay in memory order
-template <typename T, int WIN, bool SCALED, bool STAGED = false>
+// ARR (kernels that read through reg(), plain fp32 images without replication, QuadMap::fastOk): 0 ... 3 = the arrangement of the
+// window in memory -- bit 1: its lines are window COLUMNS (the contiguous axis is virtual Y), bit 0: the lines run against memory -- as a
+// compile-time constant: v[] then stays in MEMORY order (line k, element e at v[k WIN + e]) and reg(slot) is a fixed register, where a
+// run-time arrangement sent every element of the window through a chain of selects (~70 of the ~440 vector instructions of config
+// 3's fast mode).  The kernel picks the instantiation with one wave-uniform switch (quad_arrangement).  -1: slot order, any map.
+template <typename T, int WIN, bool SCALED, bool STAGED = false, int ARR = -1>
 struct QuadSrc {
     const char *img;                 // first element of this image (band offset included)
     const QuadMap *m;
@@ -46,12 +82,50 @@ struct QuadSrc {
     T v[WIN * WIN];
     int arranged;                    // STAGED: 0 = v[] is in slot order; else 1 + arrangement of the vector-loaded lines (commit)
 
+    // index of window position (i, j) in v[] under arrangement ARR
+    static __device__ __forceinline__ constexpr int mem_index(int j, int i)
+    {
+        return ARR == 0 ? j * WIN + i : (ARR == 1 ? j * WIN + (WIN - 1 - i) : (ARR == 2 ? i * WIN + j : (ARR == 3 ? i * WIN + (WIN - 1 - j) : j * WIN + i)));
+    }
     // allInside: the caller has established (by a wave vote) that every lane's window lies inside the lattice
     __device__ __forceinline__ void issue(int xg0, int yg0, unsigned long long, bool allInside = false)
     {
         unsigned colOff[WIN], rowOff[WIN];            // source indices along virtual X / Y first, byte offsets below
         const unsigned sxb = (unsigned)m->strideX * (unsigned)sizeof(T), syb = (unsigned)m->strideY * (unsigned)sizeof(T);
         arranged = 0;
+        if (ARR >= 0) {
+            // (the caller guarantees: no replication, fp32, QuadMap::fastOk, below 4 GiB)
+            if (allInside) {
+                const uint32_t across = (uint32_t)(m->fastAlongX ? yg0 : xg0) * (m->fastAlongX ? m->fastSY : m->fastSX);
+                const int alongStep = (int)(m->fastAlongX ? m->fastSX : m->fastSY);                        // +4 or -4
+                uint32_t line = (uint32_t)(__mul24(m->fastAlongX ? xg0 : yg0, alongStep) + (int)(across + (m->fastC0 - (uint32_t)(WIN - 1) * m->fastRev4)));
+#pragma unroll
+                for (int k = 0; k < WIN; ++k) {
+                    float seg[WIN];
+                    load_line<WIN>(reinterpret_cast<const float *>(img + line), seg);
+                    line += m->fastLine;
+#pragma unroll
+                    for (int e = 0; e < WIN; ++e) v[k * WIN + e] = (T)seg[e];
+                }
+                return;
+            }
+            // at the lattice's border: every position by itself, clamped onto the lattice, into its place in memory order
+#pragma unroll
+            for (int i = 0; i < WIN; ++i) {
+                const int X = min(max(xg0 + i, 0), mW - 1), Y = min(max(yg0 + i, 0), mH - 1);
+                colOff[i] = (unsigned)(m->flipX ? m->nX - 1 - X : X) * sxb;
+                rowOff[i] = (unsigned)(m->flipY ? m->nY - 1 - Y : Y) * syb;
+            }
+#pragma unroll
+            for (int k = 0; k < WIN; ++k)
+#pragma unroll
+                for (int e = 0; e < WIN; ++e) {
+                    // (line k, element e in memory order) is window position (i, j):
+                    const int i = ARR == 0 ? e : (ARR == 1 ? WIN - 1 - e : k), j = ARR == 0 || ARR == 1 ? k : (ARR == 2 ? e : WIN - 1 - e);
+                    v[k * WIN + e] = *reinterpret_cast<const T *>(img + (colOff[i] + rowOff[j]));
+                }
+            return;
+        }
         if (!SCALED && STAGED && allInside && sizeof(T) == 4 && m->anchorRows == 0 && m->fastOk) {
             // The common case of the staged kernels, spelt out: every window of the wave inside the lattice, so no clamps, and the
             // WIN lines (the window axis that is contiguous in memory: virtual X in quadrants 0 / 2, virtual Y in 1 / 3) start a
@@ -221,8 +295,51 @@ struct QuadSrc {
         for (int k = 0; k < WIN * WIN; ++k) lds[k][tid] = (float)v[k];
     }
     __device__ __forceinline__ void at(int slot, float (&vals)[1]) const { vals[0] = lds[slot][tid]; }
-    __device__ __forceinline__ float reg(int slot) const { return (float)v[slot]; }
+    __device__ __forceinline__ float reg(int slot) const { return (float)v[ARR >= 0 ? mem_index(slot / WIN, slot % WIN) : slot]; }
 };
+
+// the arrangement of a plain fp32 window in memory (QuadSrc's ARR), or -1 where the register-window kernels keep slot order
+template <typename T, bool SCALED>
+__device__ __forceinline__ int quad_arrangement(const QuadMap &m)
+{
+    if (SCALED || sizeof(T) != 4 || !m.fastOk || m.anchorRows != 0) return -1;
+    return (m.fastAlongX ? 0 : 2) + (m.fastRev4 ? 1 : 0);
+}
+
+// One dst pixel (or one part of a wide window) of fast mode through the register window: the window's arrangement in memory picks
+// the instantiation (one wave-uniform switch), so that every window value is read from a fixed register (QuadSrc's ARR).
+template <typename T, int WIN, bool SCALED, int ARR>
+__device__ __forceinline__ void fast_window_sum_arr(const RotLaunch &r, const QuadConsts<float> &q, const QuadMap &m, const char *img, int Xc, int Yc,
+                                                    double dfx, double dfy, int tid, int partI, int partJ, float &sum, int &count)
+{
+    QuadSrc<T, WIN, SCALED, false, ARR> s;
+    s.img = img; s.m = &m; s.mW = r.mW; s.mH = r.mH; s.lds = nullptr; s.tid = tid;
+    quad_fast_pixel<float, WIN, false>(q, Xc, Yc, dfx, dfy, r.mW, r.mH, s, sum, count, partI, partJ);
+}
+template <typename T, int WIN, bool SCALED>
+__device__ __forceinline__ void fast_window_sum(const RotLaunch &r, const QuadConsts<float> &q, const QuadMap &m, const char *img, int Xc, int Yc,
+                                                double dfx, double dfy, int tid, int partI, int partJ, float &sum, int &count)
+{
+    if constexpr (!SCALED && sizeof(T) == 4) {
+        switch (quad_arrangement<T, SCALED>(m)) {                     // (wave-uniform: a scalar branch)
+        case 0: return fast_window_sum_arr<T, WIN, SCALED, 0>(r, q, m, img, Xc, Yc, dfx, dfy, tid, partI, partJ, sum, count);
+        case 1: return fast_window_sum_arr<T, WIN, SCALED, 1>(r, q, m, img, Xc, Yc, dfx, dfy, tid, partI, partJ, sum, count);
+        case 2: return fast_window_sum_arr<T, WIN, SCALED, 2>(r, q, m, img, Xc, Yc, dfx, dfy, tid, partI, partJ, sum, count);
+        case 3: return fast_window_sum_arr<T, WIN, SCALED, 3>(r, q, m, img, Xc, Yc, dfx, dfy, tid, partI, partJ, sum, count);
+        default: break;
+        }
+    }
+    fast_window_sum_arr<T, WIN, SCALED, -1>(r, q, m, img, Xc, Yc, dfx, dfy, tid, partI, partJ, sum, count);
+}
+template <typename T, int WIN, bool SCALED>
+__device__ __forceinline__ float fast_window_value(const RotLaunch &r, const QuadConsts<float> &q, const QuadMap &m, const char *img, int Xc, int Yc,
+                                                   double dfx, double dfy, int tid)
+{
+    float sum;
+    int count;
+    fast_window_sum<T, WIN, SCALED>(r, q, m, img, Xc, Yc, dfx, dfy, tid, 0, 0, sum, count);
+    return count > 0 ? sum / (float)count : 0.f;                      // Source.cpp:905
+}
 
 struct NoSrc {
     __device__ __forceinline__ float reg(int) const { return 1.f; }

@@ -69,6 +69,17 @@ AAI_HD CellConsts<F> make_cell_consts(double side, double c, double s)
     return z;
 }
 
+// How far from a dst pixel's centre the cell kernel fetches at most, along either lattice axis: the window starts at Z + ceil(f - hbz)
+// around the ZONE's centre, which sits (zx, zy) beside the pixel's, and holds `win` positions (rotated_band_source_rows; the cells
+// of a band are those of its pixels plus one more column and row: the caller spans cells [0, dW] x [row0, row1]).
+template <typename F>
+AAI_HD double cell_window_reach(const CellConsts<F> &z)
+{
+    const double off = fabs(z.zx) > fabs(z.zy) ? fabs(z.zx) : fabs(z.zy);
+    const double lo = (double)z.hbz, hi = (double)z.win - (double)z.hbz;
+    return off + (lo > hi ? lo : hi) + 1e-3;
+}
+
 // The quad constants as the cell formulation uses them.  hiPrec (edge parameters and vertex positions from double precision) stays
 // for rotations close to an axis (QuadConsts::steep), but NOT for replicated source pixels: the quad formulation needed it there
 // (8-bit noise, a 1 beside a 255: 7-8.5e-6 in plain fp32), the cell formulation does not -- every side of a cut takes its small

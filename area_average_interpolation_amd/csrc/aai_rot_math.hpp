@@ -60,6 +60,7 @@ struct RotLaunch {
     double cXa, cXb, cX0, cYa, cYb, cY0;
     // request hints (include/aai.h): AAI_POLICY_PREFER_CELL, AAI_POLICY_DIAG_NO_FIXUP
     int preferCell, noFixup;
+    int srcRow1;         // ... and the buffer ends before source row srcRow1 (the image height unless a row band)
 };
 
 // Decisions closer than this (in virtual-source pixels) to their threshold are "knife edges": the fast
@@ -267,6 +268,21 @@ AAI_HD void pixel_centre(const RotLaunch &r, int dx, int dy, double &px, double 
     px = u * r.cs + v * r.sn + r.isoX;
     py = -u * r.sn + v * r.cs + r.isoY;
 }
+
+// The window of virtual pixels the double-precision kernels (aai_rotated_kernel, aai_rotated_runs_kernel, the strict fix-up pass,
+// K1's model check) visit for a dst pixel centred at (px, py): the tight bounding box of its square, clipped to the lattice
+// (the reference searches a wider window, Source.cpp:426-429, whose extra pixels all classify as "not included").  Everything
+// those kernels FETCH lies in these rows and columns (their 16-byte segment loads stay inside a source row).
+AAI_HD void rot_window(const RotLaunch &r, double px, double py, int &x0, int &x1, int &y0, int &y1)
+{
+    const double hb = r.h * (r.c + r.s);
+    const double ax = floor(px - hb + 0.5 - AAI_KNIFE_GUARD), bx = ceil(px + hb - 0.5 + AAI_KNIFE_GUARD);
+    const double ay = floor(py - hb + 0.5 - AAI_KNIFE_GUARD), by = ceil(py + hb - 0.5 + AAI_KNIFE_GUARD);
+    x0 = (int)(ax > 0.0 ? ax : 0.0); x1 = (int)(bx < (double)(r.mW - 1) ? bx : (double)(r.mW - 1));
+    y0 = (int)(ay > 0.0 ? ay : 0.0); y1 = (int)(by < (double)(r.mH - 1) ? by : (double)(r.mH - 1));
+}
+// ... and how far from the pixel's centre, along either lattice axis, that window reaches at most (rotated_band_source_rows)
+AAI_HD double rot_window_reach(double h, double c, double s) { return h * (c + s) + 0.5 + 1e-6; }
 
 // The same centre from host-composed coefficients: 4 fused multiply-adds instead of 14 additions and 6 products in double precision
 // (a sixth of the fast-mode window kernel's issue time at config 5).  It differs from pixel_centre -- the reference's own operation

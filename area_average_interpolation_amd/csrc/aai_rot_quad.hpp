@@ -189,6 +189,57 @@ AAI_HD QuadConsts<F> make_quad_consts(double side, double c, double s, int polic
     return q;
 }
 
+// How far from a dst pixel's centre, along either lattice axis, the window kernels fetch at most (rotated_band_source_rows sizes a
+// row band's source rows from these; tests/emulation replays the windows themselves against the rows it reports).  The window of
+// quad_pixel starts at Xc + floor(fpx - hbm) with Xc the lattice point nearest the centre and fpx = centre - Xc, and holds parts x
+// win positions (a wide footprint's parts may overhang winFull); quad_fast_pixel's starts at Xc + ceil(fpx - hbf).
+template <typename F>
+AAI_HD double quad_window_reach(const QuadConsts<F> &q)
+{
+    const double lo = (double)q.hbm + 1.0, hi = (double)(q.parts * q.win) - 1.0 - (double)q.hbm;
+    return (lo > hi ? lo : hi) + 1e-3;
+}
+template <typename F>
+AAI_HD double quad_fast_window_reach(const QuadConsts<F> &q)
+{
+    const double lo = (double)q.hbf, hi = (double)(q.partsFast * q.winFast) - (double)q.hbf;
+    return (lo > hi ? lo : hi) + 1e-3;
+}
+
+// ---- the source footprint of a 16 x 16 dst tile (aai_quad_fast_lds_kernel stages it through LDS) ------------------------------------
+// Pixel centres are affine in (dx, dy) (quad_centre) and every window reaches quad_fast_window_reach beyond its pixel's centre, so the
+// windows of a tile lie in a box whose corners sit at fixed offsets from the centre of the tile's first pixel.
+struct FastTile {
+    double x0off, x1off, y0off, y1off;       // the box relative to the centre of the tile's first pixel, virtual frame
+    int maxSide;                              // upper bound of the box's side (lattice points): bounds the LDS pitch
+};
+constexpr int kFastLdsBytes = 64 * 1024;
+// false: the box does not fit the LDS budget (or a side exceeds two elements per lane of a wave)
+template <typename F>
+AAI_HD bool make_fast_tile(const RotLaunch &r, const QuadConsts<F> &q, FastTile &ft)
+{
+    const double reach = quad_fast_window_reach(q) + 0.01;
+    const double xa = 15.0 * r.cXa, xb = 15.0 * r.cXb, ya = 15.0 * r.cYa, yb = 15.0 * r.cYb;
+    ft.x0off = (xa < 0.0 ? xa : 0.0) + (xb < 0.0 ? xb : 0.0) - reach; ft.x1off = (xa > 0.0 ? xa : 0.0) + (xb > 0.0 ? xb : 0.0) + reach;
+    ft.y0off = (ya < 0.0 ? ya : 0.0) + (yb < 0.0 ? yb : 0.0) - reach; ft.y1off = (ya > 0.0 ? ya : 0.0) + (yb > 0.0 ? yb : 0.0) + reach;
+    const double sx = ft.x1off - ft.x0off, sy = ft.y1off - ft.y0off, side = sx > sy ? sx : sy;
+    if (!(side < 126.0)) return false;
+    ft.maxSide = (int)ceil(side) + 2;
+    return (size_t)(ft.maxSide | 1) * (size_t)ft.maxSide * sizeof(float) <= (size_t)kFastLdsBytes;
+}
+// the box [X0, X1] x [Y0, Y1] of the tile whose first pixel is (dx0, dy0), clipped to the lattice; false: it misses the lattice
+AAI_HD bool fast_tile_box(const RotLaunch &r, const FastTile &ft, int dx0, int dy0, int &X0, int &X1, int &Y0, int &Y1)
+{
+    double px0, py0;
+    quad_centre(r, dx0, dy0, px0, py0);
+    const double bx0 = floor(px0 + ft.x0off), bx1 = ceil(px0 + ft.x1off), by0 = floor(py0 + ft.y0off), by1 = ceil(py0 + ft.y1off);
+    const double wMax = (double)(r.mW - 1), hMax = (double)(r.mH - 1);
+    if (!(bx0 <= wMax && bx1 >= 0.0 && by0 <= hMax && by1 >= 0.0)) return false;
+    X0 = (int)(bx0 > 0.0 ? bx0 : 0.0); X1 = (int)(bx1 < wMax ? bx1 : wMax);
+    Y0 = (int)(by0 > 0.0 ? by0 : 0.0); Y1 = (int)(by1 < hMax ? by1 : hMax);
+    return true;
+}
+
 // minimum / maximum of two numbers that are never NaN (coordinates, areas): ONE instruction on the GPU (v_min_f32 / v_max_f32),
 // where "a < b ? a : b" is a compare and a select because it must hand a NaN through
 AAI_HD float qmin(float a, float b) { return __builtin_fminf(a, b); }

@@ -87,9 +87,8 @@ __global__ __launch_bounds__(kRotBlock) void aai_rotated_runs_kernel(RotLaunch r
 
     double px, py;
     pixel_centre(r, dx, dy, px, py);
-    const double hb = r.h * (r.c + r.s);
-    const int x0 = max(0, (int)floor(px - hb + 0.5 - AAI_KNIFE_GUARD)), x1 = min(r.mW - 1, (int)ceil(px + hb - 0.5 + AAI_KNIFE_GUARD));
-    const int y0 = max(0, (int)floor(py - hb + 0.5 - AAI_KNIFE_GUARD)), y1 = min(r.mH - 1, (int)ceil(py + hb - 0.5 + AAI_KNIFE_GUARD));
+    int x0, x1, y0, y1;
+    rot_window(r, px, py, x0, x1, y0, y1);
 
     double sumA = 0.0;
     double sumVA[NC] = {};
@@ -494,7 +493,9 @@ static hipError_t launch_rotated_band(const RotLaunch &r, const QuadMap &m, cons
     } else if (r.mode == AAI_MODE_FAST && quad) {
         // centres in the dst square, fp32 in the dst frame; flagged pixels belong to the fix-up pass as in area mode
         if (kernelName) *kernelName = "aai_quad_fast_kernel";
-        return launch_quad(r, m, src, srcType, sv, dst, dv, batch, flags.count ? flags.masks : nullptr, stream, flags.live);
+        const hipError_t e = launch_quad(r, m, src, srcType, sv, dst, dv, batch, flags.count ? flags.masks : nullptr, stream, flags.live);
+        if (kernelName && quad_kernel_note()) *kernelName = quad_kernel_note();      // (the LDS-staged form)
+        return e;
     } else if (r.mode == AAI_MODE_FAST) {
         if (kernelName) *kernelName = "aai_rotated_kernel<fast>";
         hipLaunchKernelGGL((aai_rotated_kernel<AAI_MODE_FAST, false, T>), grid, dim3(kRotBlock), 0, stream, r, src, sv, dst, dv, nullptr, 0u);

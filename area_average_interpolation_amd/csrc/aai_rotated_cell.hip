@@ -68,6 +68,7 @@ constexpr int cell_min_waves(int win) { return win <= 4 ? 6 : (cell_waves_per_si
 __device__ __forceinline__ size_t flag_word(int dx, int dy, int tilesX) { return ((size_t)(dy >> 4) * tilesX + (dx >> 4)) * 4 + ((dy & 15) >> 2); }
 __device__ __forceinline__ int flag_bit(int dx, int dy) { return ((dy & 3) << 4) | (dx & 15); }
 
+constexpr int kCellXcdRowsDefault = 2;      // row blocks per XCD band without replication (profiles/r04_fast_xcd.txt)
 constexpr int kCellWaves = kQuadBlock / 64;          // waves of a workgroup: consecutive row segments of ONE strip of 63 dst columns
 
 // What the waves of a workgroup hand to the wave above them: the N / NW parts of their first cell row (which finish the last
@@ -94,9 +95,11 @@ __device__ __forceinline__ void cell_walk(int dW, int x0, int y0, int y1, bool o
     float ownA = 0.f, ownVA = 0.f, belowA = 0.f, belowVA = 0.f;
     int rowU = 0;
     // one cell row: own + W of this row (own*), N + NW for the row above (below*)
+    bool rowLive = false, aboveLive = false;                     // wave-uniform: this cell row / the one above can touch the image
     auto row = [&](int cy, bool upOnly) {
         ownA = 0.f; ownVA = 0.f; belowA = 0.f; belowVA = 0.f; rowU = 0;
-        if (cy > liveHi || cy < liveLo) return;                  // wave-uniform: every cell of this row misses the image
+        rowLive = !(cy > liveHi || cy < liveLo);
+        if (!rowLive) return;                                    // wave-uniform: every cell of this row misses the image
         float sA[4] = {0.f, 0.f, 0.f, 0.f}, sVA[4] = {0.f, 0.f, 0.f, 0.f};
         int unc = 0;
         if (cx <= dW) unc = eval(cx, cy, sA, sVA, upOnly) ? 1 : 0;
@@ -114,14 +117,19 @@ __device__ __forceinline__ void cell_walk(int dW, int x0, int y0, int y1, bool o
         decltype(look(cx, cy, false)) seen = {};
         if (!first) seen = look(cx, cy - 1, column);
         if (active && (!last || ownsBottom)) row(cy, last);
-        else if (active) { belowA = hand.a[wave + 1][lane]; belowVA = hand.va[wave + 1][lane]; rowU = hand.u[wave + 1][lane]; }
+        else if (active) { belowA = hand.a[wave + 1][lane]; belowVA = hand.va[wave + 1][lane]; rowU = hand.u[wave + 1][lane]; rowLive = true; }
         if (first) {
             if (active) { hand.a[wave][lane] = belowA; hand.va[wave][lane] = belowVA; hand.u[wave][lane] = rowU; }
             __syncthreads();
             if (!active) break;
-        } else if (column) emit(cx, cy - 1, carryA + belowA, carryVA + belowVA, carryU | rowU, seen);
+        } else if (column) {
+            // (a pixel row between two cell rows that miss the image -- the corners of a rotated canvas, half of config 5's rows --
+            // has no area: its zeros go out without the sums and the division; the knife scan may still have listed such a pixel)
+            if (!rowLive && !aboveLive) emit(cx, cy - 1, 0.f, 0.f, 0, seen);
+            else emit(cx, cy - 1, carryA + belowA, carryVA + belowVA, carryU | rowU, seen);
+        }
         if (last) break;
-        carryA = ownA; carryVA = ownVA; carryU = rowU;
+        carryA = ownA; carryVA = ownVA; carryU = rowU; aboveLive = rowLive;
     }
 }
 
@@ -137,17 +145,21 @@ __device__ __forceinline__ void cell_segment(int blockY0, int blockY1, int rowsP
 template <typename T, int WIN, bool SCALED, bool HP>
 __global__ __launch_bounds__(kQuadBlock, cell_min_waves(WIN)) void aai_cell_kernel(
     RotLaunch r, QuadConsts<float> q, CellConsts<float> z, CellLive live, QuadMap m, const T *__restrict__ src, ImageView sv, float *__restrict__ dst, ImageView dv,
-    const unsigned long long *__restrict__ skipMasks, int tilesX, int rowsPerWave, int bigBlocks, int tailRows)
+    const unsigned long long *__restrict__ skipMasks, int tilesX, int rowsPerWave, int bigBlocks, int tailRows, int xcdRows, int rowBlocks)
 {
     __shared__ float window[WIN * WIN][kQuadBlock];
     __shared__ CellHandoff hand;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int x0 = blockIdx.x * 63;                            // (block-uniform: every wave reaches the walk's barrier)
+    int bx = blockIdx.x, by = blockIdx.y;
+    // XCD-aware order (xcd_tile, aai_quad_src.hpp): XCD x owns bands of `xcdRows` row blocks and walks them strip by strip, so that the
+    // source lines neighbouring strips share are fetched through one L2
+    xcd_tile(xcdRows, bx, by);
+    if (by >= rowBlocks) return;                               // (block-uniform; rows the padded grid adds)
+    const int x0 = bx * 63;                                    // (block-uniform: every wave reaches the walk's barrier)
     // the last workgroups of a launch are shorter (tailRows rows per wave instead of rowsPerWave): the waves that finish it live a
     // fraction as long, and the chip drains in a fraction of the time
-    const int by = blockIdx.y;
     const int rpw = by < bigBlocks ? rowsPerWave : tailRows;
     const int blockY0 = r.dyBase + (by < bigBlocks ? by * (kCellWaves * rowsPerWave) : bigBlocks * (kCellWaves * rowsPerWave) + (by - bigBlocks) * (kCellWaves * tailRows));
     const int blockY1 = min(blockY0 + kCellWaves * rpw, r.dyEnd);
@@ -250,11 +262,19 @@ hipError_t launch_cell_tile(const RotLaunch &r, const QuadConsts<float> &q, cons
         tailBlocks = (rows - bigBlocks * blockRows + kCellWaves * tailRows - 1) / (kCellWaves * tailRows);
         if (bigBlocks + tailBlocks > 65535) { bigBlocks = (rows + blockRows - 1) / blockRows; tailRows = rowsPerWave; tailBlocks = 0; }      // grid.y
     }
-    const dim3 grid(strips, bigBlocks + tailBlocks, batch);
+    const int rowBlocks = bigBlocks + tailBlocks;
+    // XCD-aware workgroup order: config 3 is bound by instruction issue and does not move (170.0 us at 0 / 1 / 2 / 4 row blocks per
+    // band), but geometries whose waves wait for memory do: 2:1 at 45 degrees 312 -> 275 / 260 / 257 us, 4:1 at 30 degrees 275 -> 270;
+    // replicated sources (config 5: one source row feeds four dst rows) lose 1-4 % beyond one block and gain nothing: off there.
+    // (profiles/r04_fast_xcd.txt; experiments build: AAI_XCD_ROWS.)
+    const int band = xcd_band(m.scale > 1 ? 0 : kCellXcdRowsDefault);
+    const int gy = xcd_grid_rows(rowBlocks, band);
+    const int xcdRows = gy ? band : 0;
+    const dim3 grid(strips, gy ? gy : rowBlocks, batch);
     const int tilesX = (r.dW + 15) / 16;
     const CellLive live = make_cell_live(r, z);
 #define AAI_CELL_LAUNCH(SCALED, HP) \
-    hipLaunchKernelGGL((aai_cell_kernel<T, WIN, SCALED, HP>), grid, dim3(kQuadBlock), 0, stream, r, q, z, live, m, src, sv, dst, dv, skipMasks, tilesX, rowsPerWave, bigBlocks, tailRows)
+    hipLaunchKernelGGL((aai_cell_kernel<T, WIN, SCALED, HP>), grid, dim3(kQuadBlock), 0, stream, r, q, z, live, m, src, sv, dst, dv, skipMasks, tilesX, rowsPerWave, bigBlocks, tailRows, xcdRows, rowBlocks)
     if ((q.hiPrec != 0) != (HPSEL == 1) && HPSEL != 2) return hipErrorInvalidValue;       // (the dispatcher picks the unit that holds the variant)
     if (m.scale > 1) {
         if (HPSEL != 0 && q.hiPrec) AAI_CELL_LAUNCH(true, true);

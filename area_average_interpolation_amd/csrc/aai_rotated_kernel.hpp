@@ -116,9 +116,8 @@ __global__ __launch_bounds__(kRotBlock) void aai_rotated_kernel(RotLaunch r, con
 
         // tight bounding box of the square; nothing outside it can overlap (the reference searches a wider
         // window, Source.cpp:426-429, whose extra pixels all classify as "not included")
-        const double hb = r.h * (r.c + r.s);
-        const int x0 = max(0, (int)floor(px - hb + 0.5 - AAI_KNIFE_GUARD)), x1 = min(r.mW - 1, (int)ceil(px + hb - 0.5 + AAI_KNIFE_GUARD));
-        const int y0 = max(0, (int)floor(py - hb + 0.5 - AAI_KNIFE_GUARD)), y1 = min(r.mH - 1, (int)ceil(py + hb - 0.5 + AAI_KNIFE_GUARD));
+        int x0, x1, y0, y1;
+        rot_window(r, px, py, x0, x1, y0, y1);
 
         SVec sv4[4];                                 // the reference's vertices, fetched lazily (STRICT only)
         bool haveVertices = false;

@@ -27,6 +27,8 @@
 #include "aai_rot_quad.hpp"
 #include "aai_quad_src.hpp"
 
+#include <type_traits>
+
 namespace aai {
 
 namespace {
@@ -151,11 +153,12 @@ constexpr int quad_waves_per_simd(int win) { return 160 / (win * win) >= 8 ? 8 :
 template <typename T, int WIN, bool SCALED, bool HP>
 __global__ __launch_bounds__(kQuadBlock, quad_waves_per_simd(WIN) - (HP && quad_waves_per_simd(WIN) > 2 ? 1 : 0)) void aai_quad_kernel(RotLaunch r, QuadConsts<float> q, QuadMap m, const T *__restrict__ src,
                                                              ImageView sv, float *__restrict__ dst, ImageView dv,
-                                                             const unsigned long long *__restrict__ skipMasks, const int *__restrict__ live)
+                                                             const unsigned long long *__restrict__ skipMasks, const int *__restrict__ live, int xcdRows)
 {
     __shared__ float window[WIN * WIN][kQuadBlock];
     const int tid = threadIdx.x;
-    const int tx = blockIdx.x, ty = blockIdx.y;
+    int tx = blockIdx.x, ty = blockIdx.y;
+    xcd_tile(xcdRows, tx, ty);
     const int dx = tx * 16 + (tid & 15);
     const int dy = r.dyBase + ty * 16 + (tid >> 4);
     if (!(dx < r.dW && dy < r.dyEnd)) return;
@@ -188,15 +191,18 @@ __global__ __launch_bounds__(kQuadBlock, quad_waves_per_simd(WIN) - (HP && quad_
     *out = value;
 }
 
+constexpr int kFastXcdRowsDefault = 1;       // tile rows per XCD band of the 16 x 4-wave kernels (profiles/r04_fast_xcd.txt)
+
 // K3 in the same frame: fast mode (Source.cpp:868-907), the mean of the virtual pixels whose centres lie in the dst
 // square.  The window stays in the registers it was fetched into; no LDS.
 template <typename T, int WIN, bool SCALED>
 __global__ __launch_bounds__(kQuadBlock) void aai_quad_fast_kernel(RotLaunch r, QuadConsts<float> q, QuadMap m, const T *__restrict__ src, ImageView sv,
                                                                   float *__restrict__ dst, ImageView dv, const unsigned long long *__restrict__ skipMasks,
-                                                                  const int *__restrict__ live)
+                                                                  const int *__restrict__ live, int xcdRows)
 {
     const int tid = threadIdx.x;
-    const int tx = blockIdx.x, ty = blockIdx.y;
+    int tx = blockIdx.x, ty = blockIdx.y;
+    xcd_tile(xcdRows, tx, ty);                                 // XCD-aware tile order (aai_quad_src.hpp); rows beyond the image leave below
     const int dx = tx * 16 + (tid & 15);
     const int dy = r.dyBase + ty * 16 + (tid >> 4);
     if (!(dx < r.dW && dy < r.dyEnd)) return;
@@ -217,13 +223,8 @@ __global__ __launch_bounds__(kQuadBlock) void aai_quad_fast_kernel(RotLaunch r, 
     const double cx = floor(px + 0.5), cy = floor(py + 0.5);
     float value = 0.f;
     if (cx > -16.0 && cx < (double)r.mW + 16.0 && cy > -16.0 && cy < (double)r.mH + 16.0) {
-        QuadSrc<T, WIN, SCALED> s;
-        s.img = reinterpret_cast<const char *>(src + (int64_t)blockIdx.z * sv.imageStride + m.base);
-        s.m = &m; s.mW = r.mW; s.mH = r.mH; s.lds = nullptr; s.tid = tid;
-        float sum;
-        int count;
-        quad_fast_pixel<float, WIN, false>(q, (int)cx, (int)cy, px - cx, py - cy, r.mW, r.mH, s, sum, count);
-        value = count > 0 ? sum / (float)count : 0.f;                 // Source.cpp:905
+        const char *img = reinterpret_cast<const char *>(src + (int64_t)blockIdx.z * sv.imageStride + m.base);
+        value = fast_window_value<T, WIN, SCALED>(r, q, m, img, (int)cx, (int)cy, px - cx, py - cy, tid);
     }
     *out = value;
 }
@@ -265,17 +266,147 @@ __global__ __launch_bounds__(kQuadBlock) __attribute__((amdgpu_num_sgpr(96))) vo
         const double cx = floor(px + 0.5), cy = floor(py + 0.5);
         float value = 0.f;
         if (cx > -16.0 && cx < (double)r.mW + 16.0 && cy > -16.0 && cy < (double)r.mH + 16.0) {
-            QuadSrc<T, WIN, SCALED> s;
-            s.img = reinterpret_cast<const char *>(src + (int64_t)blockIdx.z * sv.imageStride + m.base);
-            s.m = &m; s.mW = r.mW; s.mH = r.mH; s.lds = nullptr; s.tid = tid;
-            float sum;
-            int count;
-            quad_fast_pixel<float, WIN, false>(q, (int)cx, (int)cy, px - cx, py - cy, r.mW, r.mH, s, sum, count);
-            value = count > 0 ? sum / (float)count : 0.f;                 // Source.cpp:905
+            const char *img = reinterpret_cast<const char *>(src + (int64_t)blockIdx.z * sv.imageStride + m.base);
+            value = fast_window_value<T, WIN, SCALED>(r, q, m, img, (int)cx, (int)cy, px - cx, py - cy, tid);
         }
         __builtin_nontemporal_store(value, out);
     }
 }
+
+// K3 with the workgroup's source footprint staged through LDS -- MEASURED AND NOT SHIPPED (round 4, profiles/r04_fast_lds.txt): it exists
+// in the experiments build only (make exp; AAI_FAST_LDS=1 selects it).  Idea: the 256 lanes of a workgroup bring
+// the bounding box of the windows of their 16 x 16 dst tile into LDS with coalesced loads (a wave instruction reads 64 consecutive
+// elements of a source row), meet at one barrier and take their windows from LDS.  Result: config 3's fast mode 158 us against 105 for
+// the register-window kernel (2:1 at 45 degrees 256 / 148, 1.5:1 at 61 degrees 471 / 302, 4:1 164 / 129, 5:1 118 / 117): the per-lane
+// window loads of the shipped kernel hit the CU's L1 88 % of the time, so there was no texture-path time to win, while the staged form
+// fetches the slanted tile's whole bounding box (1.6 x the windows' footprint), serialises load -> barrier -> compute inside a
+// workgroup and pays LDS traffic twice.  Results are identical to aai_quad_fast_kernel's, bit for bit (same quad_fast_pixel).
+#if defined(AAI_EXPERIMENTS)
+constexpr int kFastLdsUnroll = 4;            // box rows a wave has in flight per round of the staging loop
+// the window of one lane, read from the staged box; `reg` protocol of quad_fast_pixel
+template <int WIN>
+struct FastLdsSrc {
+    const float *lds;
+    int pitch, A0, B0, A1, B1;               // box [A0, A1] x [B0, B1] along the contiguous (A) and the strided (B) virtual axis
+    bool alongX;                             // A is virtual X (quadrants 0 / 2)
+    float v[WIN * WIN];
+    __device__ __forceinline__ void issue(int xg0, int yg0, unsigned long long, bool allInside)
+    {
+        const int a0 = (alongX ? xg0 : yg0) - A0, b0 = (alongX ? yg0 : xg0) - B0;
+        if (allInside) {
+            const float *p = lds + b0 * pitch + a0;
+            if (alongX) {
+#pragma unroll
+                for (int j = 0; j < WIN; ++j)
+#pragma unroll
+                    for (int i = 0; i < WIN; ++i) v[j * WIN + i] = p[j * pitch + i];
+            } else {
+#pragma unroll
+                for (int i = 0; i < WIN; ++i)
+#pragma unroll
+                    for (int j = 0; j < WIN; ++j) v[j * WIN + i] = p[i * pitch + j];
+            }
+            return;
+        }
+        // at the lattice's border: positions outside it are never used (quad_fast_pixel gives them a far-away coordinate); they are
+        // read from the nearest staged element
+        const int nA = A1 - A0, nB = B1 - B0;
+#pragma unroll
+        for (int j = 0; j < WIN; ++j)
+#pragma unroll
+            for (int i = 0; i < WIN; ++i) {
+                const int a = min(max(a0 + (alongX ? i : j), 0), nA), b = min(max(b0 + (alongX ? j : i), 0), nB);
+                v[j * WIN + i] = lds[b * pitch + a];
+            }
+    }
+    __device__ __forceinline__ float reg(int slot) const { return v[slot]; }
+};
+
+template <int WIN>
+__global__ __launch_bounds__(kQuadBlock) void aai_quad_fast_lds_kernel(RotLaunch r, QuadConsts<float> q, QuadMap m, FastTile ft, const float *__restrict__ src, ImageView sv,
+                                                                      float *__restrict__ dst, ImageView dv, const unsigned long long *__restrict__ skipMasks,
+                                                                      const int *__restrict__ live)
+{
+    extern __shared__ float staged[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tx = blockIdx.x, ty = blockIdx.y;
+    const int dx = tx * 16 + (tid & 15);
+    const int dy = r.dyBase + ty * 16 + (tid >> 4);
+    float *out = dst + (int64_t)blockIdx.z * dv.imageStride + (int64_t)(dy - r.dyBase) * dv.rowStride + dx;
+    const bool inImage = dx < r.dW && dy < r.dyEnd;
+    if (live) {
+        // a tile in a corner of the rotated canvas: every pixel is 0 (rot_live_cols), nothing is staged (block-uniform: no barrier is missed)
+        const int first = live[2 * (ty + r.dyBase / 16)], last = live[2 * (ty + r.dyBase / 16) + 1];
+        if (tx < first || tx > last) {
+            bool flagged = false;
+            if (skipMasks && inImage) flagged = (skipMasks[((size_t)(ty + r.dyBase / 16) * gridDim.x + tx) * (kQuadBlock / 64) + wave] >> (tid & 63)) & 1ull;
+            if (inImage && !flagged) *out = 0.f;
+            return;
+        }
+    }
+    // ---- the tile's box on the virtual lattice (block-uniform), clipped to the lattice --------------------------------------------
+    int X0, X1, Y0, Y1;
+    const bool any = fast_tile_box(r, ft, tx * 16, r.dyBase + ty * 16, X0, X1, Y0, Y1);      // (false: the box misses the lattice)
+    const bool alongX = m.strideX == 1;
+    const int A0 = alongX ? X0 : Y0, A1 = alongX ? X1 : Y1, B0 = alongX ? Y0 : X0, B1 = alongX ? Y1 : X1;
+    const int nA = any ? A1 - A0 + 1 : 0, nB = any ? B1 - B0 + 1 : 0;
+    const int pitch = nA | 1;
+    // ---- staging: wave w takes rows w, w + 4, ... of the box, a lane the elements lane, lane + 64, ... of a row ----------------------
+    {
+        const char *img = reinterpret_cast<const char *>(src + (int64_t)blockIdx.z * sv.imageStride + m.base);
+        const int flipA = alongX ? m.flipX : m.flipY, flipB = alongX ? m.flipY : m.flipX;
+        const int nAimg = alongX ? m.nX : m.nY, nBimg = alongX ? m.nY : m.nX;
+        const unsigned strideB = (unsigned)(alongX ? m.strideY : m.strideX) * 4u;
+        for (int b = wave; b < nB; b += 4 * kFastLdsUnroll) {
+            float t[kFastLdsUnroll][2];
+#pragma unroll
+            for (int u = 0; u < kFastLdsUnroll; ++u) {
+                const int bb = b + 4 * u;
+                const int uB = flipB ? nBimg - 1 - (B0 + bb) : B0 + bb;      // the strided axis: uB IS the source row
+                // (a row band's buffer holds source rows [srcRow0, srcRow1): rows of the box outside it -- the corners of a slanted
+                // box that no window touches -- are not fetched)
+                const bool rowOk = bb < nB && uB >= r.srcRow0 && uB < r.srcRow1;
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    const int a = lane + 64 * k;
+                    const int uA = flipA ? nAimg - 1 - (A0 + a) : A0 + a;
+                    t[u][k] = (rowOk && a < nA) ? *reinterpret_cast<const float *>(img + ((unsigned)uB * strideB + (unsigned)uA * 4u)) : 0.f;
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < kFastLdsUnroll; ++u) {
+                const int bb = b + 4 * u;
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    const int a = lane + 64 * k;
+                    if (bb < nB && a < nA) staged[bb * pitch + a] = t[u][k];
+                }
+            }
+        }
+    }
+    __syncthreads();
+    if (!inImage) return;
+    if (skipMasks) {
+        const unsigned long long mask = skipMasks[((size_t)(ty + r.dyBase / 16) * gridDim.x + tx) * (kQuadBlock / 64) + wave];
+        if ((mask >> (tid & 63)) & 1ull) return;
+    }
+    double px, py;
+    quad_centre(r, dx, dy, px, py);
+    const double cx = floor(px + 0.5), cy = floor(py + 0.5);
+    float value = 0.f;
+    if (cx > -16.0 && cx < (double)r.mW + 16.0 && cy > -16.0 && cy < (double)r.mH + 16.0) {
+        FastLdsSrc<WIN> s;
+        s.lds = staged; s.pitch = pitch; s.A0 = A0; s.B0 = B0; s.A1 = A1; s.B1 = B1; s.alongX = alongX;
+        float sum;
+        int count;
+        quad_fast_pixel<float, WIN, false>(q, (int)cx, (int)cy, px - cx, py - cy, r.mW, r.mH, s, sum, count);
+        value = count > 0 ? sum / (float)count : 0.f;                 // Source.cpp:905
+    }
+    *out = value;
+}
+
+#endif      // AAI_EXPERIMENTS
 
 // Interleaved channels: areas once per (dst, src) pair, applied to every channel (four accumulators).  Dynamic LDS:
 // WIN * WIN * words KiB per block.
@@ -408,24 +539,53 @@ hipError_t launch_quad_win(const RotLaunch &r, const QuadConsts<float> &q, const
         // ... and without replication while a dst pixel is at most 1.6 source pixels wide (1.5:1 at 17.5 degrees 237 -> 189 us, 1:1 at
         // 45 degrees 480 -> 426; from 2:1 on the slanted line of source pixels a row-shaped wave reads costs more than its stores
         // save: 2:1 at 45 degrees 148 -> 206 us, 3:1 at 17.5 degrees 100 -> 158) -- profiles/r03_store_paths.txt
+#if defined(AAI_EXPERIMENTS)
+        if constexpr (std::is_same<T, float>::value) {
+            // experiments build: AAI_FAST_LDS=1 sends plain fp32 images without replication whose tile footprint fits LDS to the staged form
+            static const bool ldsOn = [] { const char *e = experiment_env("AAI_FAST_LDS"); return e && atoi(e) != 0; }();
+            FastTile ft;
+            if (ldsOn && m.scale == 1 && m.anchorRows == 0 && make_fast_tile(r, q, ft)) {
+                const size_t lds = (size_t)(ft.maxSide | 1) * (size_t)ft.maxSide * sizeof(float);
+                static const hipError_t once = hipFuncSetAttribute(reinterpret_cast<const void *>(&aai_quad_fast_lds_kernel<WIN>), hipFuncAttributeMaxDynamicSharedMemorySize, kFastLdsBytes);
+                (void)once;
+                hipLaunchKernelGGL((aai_quad_fast_lds_kernel<WIN>), grid, dim3(kQuadBlock), lds, stream, r, q, m, ft, src, sv, dst, dv, skipMasks, live);
+                set_quad_kernel_note("aai_quad_fast_kernel<lds>");
+                return hipGetLastError();
+            }
+        }
+#endif
         const bool rowShaped = quad_fast_rows_mode() >= 2 || (quad_fast_rows_mode() == 1 && (m.scale > 1 || r.side <= 1.6));
         if (rowShaped && m.anchorRows == 0) {
             // (images of 4 GiB and more keep the 16 x 4 wave: their anchor rows are sized for it)
             const dim3 rows((r.dW + 63) / 64 + 1, grid.y, batch);
             if (m.scale > 1) hipLaunchKernelGGL((aai_quad_fast_rows_kernel<T, WIN, true>), rows, dim3(kQuadBlock), 0, stream, r, q, m, src, sv, dst, dv, skipMasks, live, (int)grid.x);
             else hipLaunchKernelGGL((aai_quad_fast_rows_kernel<T, WIN, false>), rows, dim3(kQuadBlock), 0, stream, r, q, m, src, sv, dst, dv, skipMasks, live, (int)grid.x);
-        } else if (m.scale > 1) hipLaunchKernelGGL((aai_quad_fast_kernel<T, WIN, true>), grid, dim3(kQuadBlock), 0, stream, r, q, m, src, sv, dst, dv, skipMasks, live);
-        else hipLaunchKernelGGL((aai_quad_fast_kernel<T, WIN, false>), grid, dim3(kQuadBlock), 0, stream, r, q, m, src, sv, dst, dv, skipMasks, live);
+        } else {
+            // XCD-aware tile order (xcd_tile): the fast-mode kernel is bound by its fabric traffic, and with one tile row per XCD band
+            // config 3 asks for 1.23 x its source instead of 1.75 x: 98.5 -> 91.6 us (2 rows 95.1, 4 rows 96.6; every geometry tried
+            // equal or faster: profiles/r04_fast_xcd.txt).  Experiments build: AAI_XCD_ROWS.
+            const int band = xcd_band(kFastXcdRowsDefault);
+            const int gy = xcd_grid_rows((int)grid.y, band);
+            const dim3 g(grid.x, gy ? gy : grid.y, grid.z);
+            const int on = gy ? band : 0;
+            if (m.scale > 1) hipLaunchKernelGGL((aai_quad_fast_kernel<T, WIN, true>), g, dim3(kQuadBlock), 0, stream, r, q, m, src, sv, dst, dv, skipMasks, live, on);
+            else hipLaunchKernelGGL((aai_quad_fast_kernel<T, WIN, false>), g, dim3(kQuadBlock), 0, stream, r, q, m, src, sv, dst, dv, skipMasks, live, on);
+        }
         return hipGetLastError();
       }
     }
+    // (the one-lane-per-pixel area kernel takes the same XCD-aware tile order as the fast-mode kernel)
+    const int bandA = xcd_band(kFastXcdRowsDefault);
+    const int gyA = xcd_grid_rows((int)grid.y, bandA);
+    const dim3 gridA(grid.x, gyA ? gyA : grid.y, grid.z);
+    const int onA = gyA ? bandA : 0;
     if constexpr ((FAMILIES & 1) == 0) return hipErrorInvalidValue;
     else if (m.scale > 1) {
-        if (q.hiPrec) hipLaunchKernelGGL((aai_quad_kernel<T, WIN, true, true>), grid, dim3(kQuadBlock), 0, stream, r, q, m, src, sv, dst, dv, skipMasks, live);
-        else hipLaunchKernelGGL((aai_quad_kernel<T, WIN, true, false>), grid, dim3(kQuadBlock), 0, stream, r, q, m, src, sv, dst, dv, skipMasks, live);
+        if (q.hiPrec) hipLaunchKernelGGL((aai_quad_kernel<T, WIN, true, true>), gridA, dim3(kQuadBlock), 0, stream, r, q, m, src, sv, dst, dv, skipMasks, live, onA);
+        else hipLaunchKernelGGL((aai_quad_kernel<T, WIN, true, false>), gridA, dim3(kQuadBlock), 0, stream, r, q, m, src, sv, dst, dv, skipMasks, live, onA);
     } else {
-        if (q.hiPrec) hipLaunchKernelGGL((aai_quad_kernel<T, WIN, false, true>), grid, dim3(kQuadBlock), 0, stream, r, q, m, src, sv, dst, dv, skipMasks, live);
-        else hipLaunchKernelGGL((aai_quad_kernel<T, WIN, false, false>), grid, dim3(kQuadBlock), 0, stream, r, q, m, src, sv, dst, dv, skipMasks, live);
+        if (q.hiPrec) hipLaunchKernelGGL((aai_quad_kernel<T, WIN, false, true>), gridA, dim3(kQuadBlock), 0, stream, r, q, m, src, sv, dst, dv, skipMasks, live, onA);
+        else hipLaunchKernelGGL((aai_quad_kernel<T, WIN, false, false>), gridA, dim3(kQuadBlock), 0, stream, r, q, m, src, sv, dst, dv, skipMasks, live, onA);
     }
     return hipGetLastError();
 }
@@ -558,9 +718,14 @@ bool quad_can_address(const RotLaunch &r, int srcType, ImageView sv)
     return true;
 }
 
+static thread_local const char *g_quadKernelNote = nullptr;
+void set_quad_kernel_note(const char *note) { g_quadKernelNote = note; }
+const char *quad_kernel_note() { return g_quadKernelNote; }
+
 hipError_t launch_quad(const RotLaunch &r, const QuadMap &map, const void *src, int srcType, ImageView sv, float *dst, ImageView dv,
                        int batch, const unsigned long long *skipMasks, hipStream_t stream, const int *live)
 {
+    set_quad_kernel_note(nullptr);
     if (r.dW <= 0 || r.dyEnd <= r.dyBase || batch <= 0) return hipSuccess;
     QuadMap m = map;
     const int64_t esz = srcType == SRC_U8 ? 1 : srcType == SRC_U16 ? 2 : 4;

@@ -68,9 +68,8 @@ __global__ __launch_bounds__(kRotBlock) void aai_fixup_group_kernel(RotLaunch r,
     if (valid) {
         double px, py;
         pixel_centre(r, dx, dy, px, py);
-        const double hb = r.h * (r.c + r.s);
-        const int x0 = max(0, (int)floor(px - hb + 0.5 - AAI_KNIFE_GUARD)), x1 = min(r.mW - 1, (int)ceil(px + hb - 0.5 + AAI_KNIFE_GUARD));
-        const int y0 = max(0, (int)floor(py - hb + 0.5 - AAI_KNIFE_GUARD)), y1 = min(r.mH - 1, (int)ceil(py + hb - 0.5 + AAI_KNIFE_GUARD));
+        int x0, x1, y0, y1;
+        rot_window(r, px, py, x0, x1, y0, y1);
         const int nW = x1 - x0 + 1;
         SVec sv4[4];
         bool haveVertices = false;

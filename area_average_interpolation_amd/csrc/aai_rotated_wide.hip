@@ -145,10 +145,8 @@ __global__ __launch_bounds__(kQuadBlock) void aai_wide_fast_kernel(RotLaunch r, 
     float sum = 0.f;
     int count = 0;
     if (cx > -40.0 && cx < (double)r.mW + 40.0 && cy > -40.0 && cy < (double)r.mH + 40.0) {
-        QuadSrc<T, WIN, false> s;
-        s.img = reinterpret_cast<const char *>(src + (int64_t)blockIdx.z * sv.imageStride + m.base);
-        s.m = &m; s.mW = r.mW; s.mH = r.mH; s.lds = nullptr; s.tid = threadIdx.x;
-        quad_fast_pixel<float, WIN, false>(q, (int)cx, (int)cy, px - cx, py - cy, r.mW, r.mH, s, sum, count, l.partI, l.partJ);
+        const char *img = reinterpret_cast<const char *>(src + (int64_t)blockIdx.z * sv.imageStride + m.base);
+        fast_window_sum<T, WIN, false>(r, q, m, img, (int)cx, (int)cy, px - cx, py - cy, threadIdx.x, l.partI, l.partJ, sum, count);
     }
     const float S = wide_total<PARTS>(sum);
     const int N = wide_total_int<PARTS>(count);

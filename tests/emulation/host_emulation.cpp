@@ -865,6 +865,225 @@ long aai_emu_wide_band_cover(const aai_request *rq, int r0, int r1)
     return outside;
 }
 
+// ---- one cover check for every kernel family that takes a band buffer --------------------------------------------------------------
+// Replays, for dst rows [r0, r1) of a request, what a family's kernel FETCHES, and counts the fetched elements whose source row lies
+// outside the rows aai_band_source_rows reports (rotated_band_source_rows).  The window kernels (QuadSrc: quad, fast -- 16 x 4 and
+// row-shaped waves evaluate the same pixels --, wide, wide fast, cell) are replayed through the product's own pixel functions
+// (quad_pixel / quad_fast_pixel / cell_eval of the math headers) with a source that records instead of loading: window origins, sizes,
+// parts and skip conditions are the kernels' own code, not a restatement; QuadSrc::issue fetches the window's positions clamped to the
+// lattice (its vector loads bring exactly one window line each, its 2 x 2 fetch a subset).  The double-precision kernels (production,
+// rows-as-runs, the strict fix-up pass) visit rot_window(), their 16-byte segment loads stay inside a source row; the samplers fetch
+// N tap rows from floor(sy) + FIRST, clamped to the image.
+// family: 0 = double precision, 1 = quad / wide (area), 2 = quad / wide (fast), 3 = cell, 4 = bilinear, 5 = bicubic.
+// Returns the number of elements outside, -1: the family does not serve the request, -2: bad request.
+extern "C++" {
+namespace {
+struct CoverCount { const RotLaunch *r; int a, b; long outside, fetched; };
+template <int WIN>
+struct CoverSrc {
+    CoverCount *c;
+    void issue(int xg0, int yg0, unsigned long long, bool = false)
+    {
+        const RotLaunch &r = *c->r;
+        for (int j = 0; j < WIN; ++j)
+            for (int i = 0; i < WIN; ++i) {
+                const int X = std::min(std::max(xg0 + i, 0), r.mW - 1), Y = std::min(std::max(yg0 + j, 0), r.mH - 1);
+                const int row = (int)(virt_offset(r, X, Y, /*rowStride*/ 1 << 20) >> 20);
+                ++c->fetched;
+                if (row < c->a || row >= c->b) ++c->outside;
+            }
+    }
+    void commit() {}
+    void at(int, float (&vals)[1]) const { vals[0] = 0.f; }
+    float reg(int) const { return 0.f; }
+};
+
+template <int WIN, bool HP>
+void cover_quad_pixel(const RotLaunch &r, const QuadConsts<float> &q, int dx, int dy, CoverCount &cc)
+{
+    double px, py;
+    if (q.parts > 1) pixel_centre(r, dx, dy, px, py); else quad_centre(r, dx, dy, px, py);      // (as aai_wide_kernel / aai_quad_kernel do)
+    const double cx = std::floor(px + 0.5), cy = std::floor(py + 0.5);
+    // (the kernels' reach tests: 16 for one window, 40 for a wide footprint's parts)
+    const double far = q.parts > 1 ? 40.0 : 16.0;
+    if (!(cx > -far && cx < (double)r.mW + far && cy > -far && cy < (double)r.mH + far)) return;
+    CoverSrc<WIN> s{&cc};
+    float sumA, sumVA[1];
+    if (q.parts == 1) quad_pixel<float, WIN, false, HP, 1>(q, (int)cx, (int)cy, px - cx, py - cy, r.mW, r.mH, s, sumA, sumVA);
+    else
+        for (int part = 0; part < q.parts * q.parts; ++part)
+            quad_pixel<float, WIN, false, HP, 1, CoverSrc<WIN>, true>(q, (int)cx, (int)cy, px - cx, py - cy, r.mW, r.mH, s, sumA, sumVA, part % q.parts, part / q.parts);
+}
+template <int WIN>
+void cover_fast_pixel(const RotLaunch &r, const QuadConsts<float> &q, int dx, int dy, CoverCount &cc)
+{
+    double px, py;
+    if (q.partsFast > 1) pixel_centre(r, dx, dy, px, py); else quad_centre(r, dx, dy, px, py);
+    const double cx = std::floor(px + 0.5), cy = std::floor(py + 0.5);
+    const double far = q.partsFast > 1 ? 40.0 : 16.0;
+    if (!(cx > -far && cx < (double)r.mW + far && cy > -far && cy < (double)r.mH + far)) return;
+    CoverSrc<WIN> s{&cc};
+    float sum; int count;
+    for (int part = 0; part < q.partsFast * q.partsFast; ++part)
+        quad_fast_pixel<float, WIN, false>(q, (int)cx, (int)cy, px - cx, py - cy, r.mW, r.mH, s, sum, count, part % q.partsFast, part / q.partsFast);
+}
+template <int WIN, bool HP>
+void cover_cell(const RotLaunch &r, const QuadConsts<float> &q, const CellConsts<float> &z, int cx, int cy, bool upOnly, CoverCount &cc)
+{
+    int Zx, Zy; double dfx, dfy;
+    if (!cell_anchor(r, cell_column(r, z, cx), cy, Zx, Zy, dfx, dfy)) return;
+    CoverSrc<WIN> s{&cc};
+    float sA[4], sVA[4];
+    cell_eval<float, WIN, false, HP>(q, z, Zx, Zy, dfx, dfy, r.mW, r.mH, s, sA, sVA, upOnly);
+}
+}  // namespace
+}  // extern "C++"
+
+long aai_emu_band_cover(const aai_request *rq, int r0, int r1, int family, long *fetched)
+{
+    Geometry g; std::string msg;
+    if (make_geometry(*rq, g, msg) != AAI_OK) return -2;
+    const bool sampler = family >= 4;
+    const int mode = family == 2 ? AAI_MODE_FAST : (family == 4 ? AAI_MODE_BILINEAR : (family == 5 ? AAI_MODE_BICUBIC : AAI_MODE_AREA));
+    const RotLaunch r = make_rot_launch(g, mode, rq->policy);
+    CoverCount cc{&r, 0, 0, 0, 0};
+    rotated_band_source_rows(g, r0, r1, sampler, cc.a, cc.b);
+    if (fetched) *fetched = 0;
+    if (family == 0) {
+        for (int dy = r0; dy < r1; ++dy)
+            for (int dx = 0; dx < r.dW; ++dx) {
+                double px, py;
+                pixel_centre(r, dx, dy, px, py);
+                int x0, x1, y0, y1;
+                rot_window(r, px, py, x0, x1, y0, y1);
+                for (int Y = y0; Y <= y1; ++Y)
+                    for (int X = x0; X <= x1; ++X) {
+                        const int row = (int)(virt_offset(r, X, Y, 1 << 20) >> 20);
+                        ++cc.fetched;
+                        if (row < cc.a || row >= cc.b) ++cc.outside;
+                    }
+            }
+    } else if (family == 1 || family == 2) {
+        if (!(r.c > 0.0 && r.s > 0.0)) return -1;
+        const QuadConsts<float> q = make_quad_consts<float>(r.side, r.c, r.s, r.policy, r.scale);
+        const bool fast = family == 2;
+        if (fast ? !(r.quad || r.wide) : !(r.quad || r.wide)) return -1;
+        const int win = fast ? q.winFast : q.win;
+        for (int dy = r0; dy < r1; ++dy)
+            for (int dx = 0; dx < r.dW; ++dx) {
+#define AAI_COVER_CASE(W)                                                                                                  \
+    case W:                                                                                                                \
+        if (fast) cover_fast_pixel<W>(r, q, dx, dy, cc);                                                                   \
+        else if (q.hiPrec) cover_quad_pixel<W, true>(r, q, dx, dy, cc);                                                    \
+        else cover_quad_pixel<W, false>(r, q, dx, dy, cc);                                                                 \
+        break;
+                switch (win) { AAI_COVER_CASE(2) AAI_COVER_CASE(3) AAI_COVER_CASE(4) AAI_COVER_CASE(5) AAI_COVER_CASE(6) AAI_COVER_CASE(7) AAI_COVER_CASE(8) default: return -1; }
+#undef AAI_COVER_CASE
+            }
+    } else if (family == 3) {
+        if (!r.cell) return -1;
+        const QuadConsts<float> q = make_cell_quad_consts<float>(r.side, r.c, r.s, r.policy);
+        const CellConsts<float> z = make_cell_consts<float>(r.side, r.c, r.s);
+        for (int cy = r0; cy <= r1; ++cy)
+            for (int cx = 0; cx <= r.dW; ++cx) {
+#define AAI_COVER_CASE(W)                                                                                                  \
+    case W:                                                                                                                \
+        if (q.hiPrec) cover_cell<W, true>(r, q, z, cx, cy, cy == r1, cc);                                                  \
+        else cover_cell<W, false>(r, q, z, cx, cy, cy == r1, cc);                                                          \
+        break;
+                switch (z.win) { AAI_COVER_CASE(2) AAI_COVER_CASE(3) AAI_COVER_CASE(4) AAI_COVER_CASE(5) AAI_COVER_CASE(6) AAI_COVER_CASE(7) AAI_COVER_CASE(8) default: return -1; }
+#undef AAI_COVER_CASE
+            }
+    } else {
+        // aai_sample_kernel: sample point from the host-composed coefficients, N tap rows from floor(sy) + FIRST clamped to the image
+        const int N = family == 4 ? 2 : 4, FIRST = family == 4 ? 0 : -1;
+        for (int dy = r0; dy < r1; ++dy)
+            for (int dx = 0; dx < r.dW; ++dx) {
+                const double sx = std::fma((double)dx, r.sAx, std::fma((double)dy, r.sBx, r.sCx)), sy = std::fma((double)dx, r.sAy, std::fma((double)dy, r.sBy, r.sCy));
+                const double guard = 1e-9;
+                if (sx < -0.5 - guard || sx > r.W - 0.5 + guard || sy < -0.5 - guard || sy > r.H - 0.5 + guard) continue;      // outside the extent: no taps
+                const int iy = (int)std::floor(sy);
+                for (int k = 0; k < N; ++k) {
+                    const int row = std::min(std::max(iy + FIRST + k, 0), r.H - 1);
+                    cc.fetched += N;
+                    if (row < cc.a || row >= cc.b) cc.outside += N;
+                }
+            }
+    }
+    if (fetched) *fetched = cc.fetched;
+    return cc.outside;
+}
+
+// aai_quad_fast_lds_kernel stages the box of every 16 x 16 dst tile (fast_tile_box) in LDS and its lanes take their windows from it:
+// counts the lattice positions of windows (quad_fast_pixel's own, through a recording source) that lie OUTSIDE their tile's box.
+// -1: the staged kernel does not serve the request (replication, a box beyond the LDS budget, a wide footprint).
+extern "C++" {
+namespace {
+struct BoxCount { int X0, X1, Y0, Y1, mW, mH; long outside, seen; };
+template <int WIN>
+struct BoxSrc {
+    BoxCount *c;
+    void issue(int xg0, int yg0, unsigned long long, bool = false)
+    {
+        for (int j = 0; j < WIN; ++j)
+            for (int i = 0; i < WIN; ++i) {
+                const int X = xg0 + i, Y = yg0 + j;
+                if (X < 0 || X >= c->mW || Y < 0 || Y >= c->mH) continue;      // off the lattice: never used
+                ++c->seen;
+                if (X < c->X0 || X > c->X1 || Y < c->Y0 || Y > c->Y1) ++c->outside;
+            }
+    }
+    float reg(int) const { return 0.f; }
+};
+template <int WIN>
+void box_tile(const RotLaunch &r, const QuadConsts<float> &q, const FastTile &ft, int tx, int ty, BoxCount &bc)
+{
+    const bool any = fast_tile_box(r, ft, tx * 16, ty * 16, bc.X0, bc.X1, bc.Y0, bc.Y1);
+    if (!any) { bc.X0 = bc.Y0 = 1; bc.X1 = bc.Y1 = 0; }                        // an empty box: every lattice position of a window counts
+    for (int dy = ty * 16; dy < std::min(ty * 16 + 16, r.dH); ++dy)
+        for (int dx = tx * 16; dx < std::min(tx * 16 + 16, r.dW); ++dx) {
+            double px, py;
+            quad_centre(r, dx, dy, px, py);
+            const double cx = std::floor(px + 0.5), cy = std::floor(py + 0.5);
+            if (!(cx > -16.0 && cx < (double)r.mW + 16.0 && cy > -16.0 && cy < (double)r.mH + 16.0)) continue;
+            BoxSrc<WIN> s{&bc};
+            float sum; int count;
+            quad_fast_pixel<float, WIN, false>(q, (int)cx, (int)cy, px - cx, py - cy, r.mW, r.mH, s, sum, count);
+        }
+}
+}  // namespace
+}  // extern "C++"
+
+long aai_emu_fast_tile_cover(const aai_request *rq, long *seen)
+{
+    Geometry g; std::string msg;
+    if (make_geometry(*rq, g, msg) != AAI_OK) return -2;
+    const RotLaunch r = make_rot_launch(g, AAI_MODE_FAST, rq->policy);
+    if (!r.quad || r.scale != 1 || !(r.c > 0.0 && r.s > 0.0)) return -1;
+    const QuadConsts<float> q = make_quad_consts<float>(r.side, r.c, r.s, r.policy, r.scale);
+    if (q.partsFast != 1) return -1;
+    FastTile ft;
+    if (!make_fast_tile(r, q, ft)) return -1;
+    BoxCount bc{0, 0, 0, 0, r.mW, r.mH, 0, 0};
+    for (int ty = 0; ty < (r.dH + 15) / 16; ++ty)
+        for (int tx = 0; tx < (r.dW + 15) / 16; ++tx) {
+            switch (q.winFast) {
+            case 2: box_tile<2>(r, q, ft, tx, ty, bc); break;
+            case 3: box_tile<3>(r, q, ft, tx, ty, bc); break;
+            case 4: box_tile<4>(r, q, ft, tx, ty, bc); break;
+            case 5: box_tile<5>(r, q, ft, tx, ty, bc); break;
+            case 6: box_tile<6>(r, q, ft, tx, ty, bc); break;
+            case 7: box_tile<7>(r, q, ft, tx, ty, bc); break;
+            case 8: box_tile<8>(r, q, ft, tx, ty, bc); break;
+            default: return -1;
+            }
+            const int side = std::max(bc.X1 - bc.X0, bc.Y1 - bc.Y0) + 1;
+            if (side > ft.maxSide) ++bc.outside;                               // the LDS pitch's bound must hold too
+        }
+    if (seen) *seen = bc.seen;
+    return bc.outside;
+}
+
 // cell_live_rows must be a superset: counts the cells that contribute something (non-zero area sums) although their row lies
 // outside the interval reported for the 64-column strip they belong to.  -1: the cell formulation does not serve the request.
 long aai_emu_cell_live_rows_check(const aai_request *rq)

@@ -103,6 +103,28 @@ def test_nonfinite_and_oversize_arguments_are_rejected(aai):
     assert aai.query(aai.make_request(4, 4, float("nan"), 1, (0, 0), 0))[0] in (L.ERR_NONFINITE, L.ERR_RESOLUTION_MISMATCH)
     assert aai.query(aai.make_request(1 << 20, 1 << 20, 1, 1e6, (0, 0), 0))[0] == L.ERR_TOO_LARGE
     assert aai.query(aai.make_request(4, 4, 1, 1, (0, 0), 0, mode=9))[0] == L.ERR_BAD_ARGUMENT
+    # the weight policy proper is 0 or 1; the OR-able request bits are the three include/aai.h declares, nothing else
+    for ok in (0, 1, L.POLICY_DOUBLE_PRECISION, 1 | L.POLICY_PREFER_CELL, L.POLICY_DIAG_NO_FIXUP | L.POLICY_PREFER_CELL | L.POLICY_DOUBLE_PRECISION):
+        assert aai.query(aai.make_request(4, 4, 1, 1, (0, 0), 0, policy=ok))[0] == L.OK, ok
+    for bad in (2, 0x80, 0x800, 0x1000 | 1, -1):
+        assert aai.query(aai.make_request(4, 4, 1, 1, (0, 0), 0, policy=bad))[0] == L.ERR_BAD_ARGUMENT, bad
+
+
+def test_the_library_has_no_process_wide_debug_switches(aai):
+    """Round 3 shipped three exported globals that steered the library for every caller of the process (aai_debug_skip_fixup -- which
+    switched the correctness pass off --, aai_debug_cell_min_waves, aai_debug_axis_tune) and eleven launch-heuristic getenv switches.
+    They are per-request policy bits now (include/aai.h) or exist in the experiments build only."""
+    import ctypes
+    from area_average_interpolation_amd import _lib as L
+    lib = ctypes.CDLL(L.LIB_PATH)
+    for name in ("aai_debug_skip_fixup", "aai_debug_cell_min_waves", "aai_debug_axis_tune", "aai_debug_plan_shape"):
+        assert not hasattr(lib, name), name
+    blob = open(L.LIB_PATH, "rb").read()
+    for env in (b"AAI_CELL_ROWS", b"AAI_CELL_TAIL", b"AAI_CELL\0", b"AAI_WIDE\0", b"AAI_FAST_ROWS", b"AAI_ROT_TUNE", b"AAI_AXIS_TUNE", b"AAI_AXIS_CLASS_VERIFY",
+                b"AAI_FAST_LDS"):
+        assert env not in blob, env
+    for env in (b"AAI_AXIS_AUTOTUNE", b"AAI_MAX_LISTED_PIXELS", b"AAI_TRACE_PLAN"):      # the three include/aai.h documents
+        assert env in blob, env
 
 
 def test_query_matches_reference_layout_on_golden_cases(aai, small_golden):
@@ -674,6 +696,68 @@ def test_band_source_rows_hold_every_window_the_wide_kernel_fetches(aai, hostemu
             assert out in (0, -1), (W, H, sr, ang, iso, r0, r1, out)
             checked += out == 0
     assert checked > 150, checked
+
+
+def test_band_source_rows_hold_what_every_kernel_family_fetches(aai, hostemu):
+    """ONE cover check for every kernel family that takes a band buffer (the fault class of round 3's band over-read, not its
+    instance): for random bands of random geometries -- four quadrants, replication 1 / 2 / 6 and more, ratios from x6 up-sampling to
+    24:1 -- the emulation replays what each family's kernel fetches for the band's dst rows (the window kernels through the product's
+    own pixel functions with a recording source, the double-precision kernels through rot_window, the samplers' tap rows) and every
+    fetched element must lie in the source rows aai_band_source_rows reports, whose margin is derived from the per-family reach
+    constants of the math headers (rot_window_reach, quad_window_reach, quad_fast_window_reach, cell_window_reach)."""
+    import ctypes
+    rng = np.random.default_rng(31)
+    names = {0: "double precision", 1: "quad / wide, area", 2: "quad / wide, fast", 3: "cell", 4: "bilinear", 5: "bicubic"}
+    served = {k: 0 for k in names}
+    fetched = ctypes.c_long(0)
+    ratios = [1 / 6.0, 0.25, 0.5, 0.77, 1.0, 1.5, 2.0, 2731.0 / 8192, 3.0, 4.0, 5.9, 8.0, 12.0, 24.0]
+    bands = 0
+    for k in range(150):
+        ratio = ratios[k % len(ratios)] if k % 3 else float(rng.uniform(0.17, 24.0))      # source pixels per dst pixel
+        dst_side = int(rng.integers(40, 110))
+        W = max(8, int(dst_side * ratio * rng.uniform(0.7, 1.4))); H = max(8, int(dst_side * ratio * rng.uniform(0.7, 1.4)))
+        ang = float(rng.uniform(0.3, 89.7)) + 90.0 * (k % 4)
+        if k % 11 == 0:
+            ang = 90.0 * (k % 4) + float(rng.choice([0.004, 0.05, 89.95, 45.0, 30.0]))
+        iso = (float(rng.uniform(-3, W + 3)), float(rng.uniform(-3, H + 3)))
+        rq = aai.make_request(W, H, ratio, 1.0, iso, ang, mode=1)
+        rc, msg, lay = aai.query(rq)
+        if rc != 0 or lay.dst_height < 17:
+            continue
+        for _ in range(3):
+            r0 = 16 * int(rng.integers(0, lay.dst_height // 16))
+            r1 = int(rng.integers(r0 + 1, lay.dst_height + 1))
+            bands += 1
+            for family in names:
+                out = hostemu.aai_emu_band_cover(ctypes.byref(rq), r0, r1, family, ctypes.byref(fetched))
+                assert out in (0, -1), (names[family], W, H, ratio, ang, iso, r0, r1, out, lay.scale)
+                served[family] += 1 if (out == 0 and fetched.value > 0) else 0
+    assert bands >= 400 and all(n > 100 for n in served.values()), (bands, served)
+
+
+def test_staged_tile_boxes_hold_every_window_of_their_tile(aai, hostemu):
+    """aai_quad_fast_lds_kernel stages the box of each 16 x 16 dst tile in LDS (fast_tile_box, aai_rot_quad.hpp) and its lanes read
+    their windows from it: every lattice position of every window (quad_fast_pixel's own arithmetic, through a recording source) must
+    lie inside its tile's box, and no box may exceed the side the LDS pitch is sized for.  All quadrants, ratios 1:1 ... 5:1."""
+    import ctypes
+    rng = np.random.default_rng(17)
+    seen = ctypes.c_long(0)
+    served = 0
+    for k in range(160):
+        ratio = float(rng.uniform(0.75, 5.4))
+        W, H = int(rng.integers(60, 260)), int(rng.integers(60, 260))
+        ang = float(rng.uniform(0.3, 89.7)) + 90.0 * (k % 4)
+        if k % 13 == 0:
+            ang = 90.0 * (k % 4) + float(rng.choice([0.01, 45.0, 30.0, 89.99]))
+        iso = (float(rng.uniform(-3, W + 3)), float(rng.uniform(-3, H + 3)))
+        rq = aai.make_request(W, H, ratio, 1.0, iso, ang, mode=2)
+        rc, msg, lay = aai.query(rq)
+        if rc != 0:
+            continue
+        out = hostemu.aai_emu_fast_tile_cover(ctypes.byref(rq), ctypes.byref(seen))
+        assert out in (0, -1), (W, H, ratio, ang, iso, out)
+        served += 1 if (out == 0 and seen.value > 0) else 0
+    assert served > 100, served
 
 
 def test_live_tile_spans_hold_every_nonzero_pixel(aai, hostemu, po):
