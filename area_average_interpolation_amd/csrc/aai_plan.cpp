@@ -216,7 +216,8 @@ QuadMap make_quad_map(const Geometry &g, int64_t rowStride, int srcRow0, int cha
     const int64_t bytes = ((int64_t)(g.H - 1) * rowStride + (int64_t)g.W * channels) * elementBytes;      // of the whole image
     m.lastLoad4 = (uint32_t)std::max<int64_t>(0, std::min<int64_t>(bytes - 4, 0xffffffffll));
     m.lastLoad8 = (uint32_t)std::max<int64_t>(0, std::min<int64_t>(bytes - 8, 0xffffffffll));
-    if (g.scale == 1 && channels == 1 && elementBytes == 4 && g.mW < (1 << 23) && g.mH < (1 << 23)) {
+    m.mul24Ok = (m.nX < (1 << 23) && m.nY < (1 << 23) && rowStride * elementBytes < (1 << 23) && (int64_t)channels * elementBytes < (1 << 23)) ? 1 : 0;
+    if (g.scale == 1 && channels == 1 && elementBytes == 4 && g.mW < (1 << 23) && g.mH < (1 << 23) && m.mul24Ok) {
         const uint32_t sxb = (uint32_t)m.strideX * 4u, syb = (uint32_t)m.strideY * 4u;
         m.fastOk = 1;
         m.fastAlongX = m.strideX == 1 ? 1 : 0;

@@ -83,6 +83,9 @@ struct QuadMap {
     // (last in the struct: kernels that never read them do not pull them into scalar registers with their neighbours)
     uint32_t fastC0, fastSX, fastSY, fastLine, fastRev4;
     int fastAlongX, fastOk;      // fastAlongX: the contiguous axis is virtual X (quadrants 0 / 2)
+    // every index x byte-stride product of the map fits a 24-bit multiply (v_mul_i32_i24, full rate, where the 32-bit multiply runs at a
+    // quarter): fewer than 2^23 source pixels a side and a row pitch below 8 MiB.  fastOk implies it.
+    int mul24Ok;
 };
 QuadMap make_quad_map(const Geometry &g, int64_t rowStride, int srcRow0, int channels = 1, int elementBytes = 4);      // channels: elements per pixel (interleaved)
 

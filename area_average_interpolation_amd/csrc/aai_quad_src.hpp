@@ -96,9 +96,8 @@ struct QuadSrc {
         if (ARR >= 0) {
             // (the caller guarantees: no replication, fp32, QuadMap::fastOk, below 4 GiB)
             if (allInside) {
-                const uint32_t across = (uint32_t)(m->fastAlongX ? yg0 : xg0) * (m->fastAlongX ? m->fastSY : m->fastSX);
-                const int alongStep = (int)(m->fastAlongX ? m->fastSX : m->fastSY);                        // +4 or -4
-                uint32_t line = (uint32_t)(__mul24(m->fastAlongX ? xg0 : yg0, alongStep) + (int)(across + (m->fastC0 - (uint32_t)(WIN - 1) * m->fastRev4)));
+                // (two 24-bit multiplies, QuadMap::mul24Ok, and one three-operand add)
+                uint32_t line = (uint32_t)__mul24(xg0, (int)m->fastSX) + (uint32_t)__mul24(yg0, (int)m->fastSY) + (m->fastC0 - (uint32_t)(WIN - 1) * m->fastRev4);
 #pragma unroll
                 for (int k = 0; k < WIN; ++k) {
                     float seg[WIN];
@@ -130,11 +129,9 @@ struct QuadSrc {
             // The common case of the staged kernels, spelt out: every window of the wave inside the lattice, so no clamps, and the
             // WIN lines (the window axis that is contiguous in memory: virtual X in quadrants 0 / 2, virtual Y in 1 / 3) start a
             // wave-uniform number of bytes apart -- ONE per-lane byte offset from the host-composed coefficients of the map
-            // (QuadMap::fastC0 ...: a multiply along the strided axis, a 24-bit multiply-add along the contiguous one) and one add per
-            // further line, instead of 2 WIN clamped indices, flips, multiplies and adds per lane
-            const uint32_t across = (uint32_t)(m->fastAlongX ? yg0 : xg0) * (m->fastAlongX ? m->fastSY : m->fastSX);
-            const int alongStep = (int)(m->fastAlongX ? m->fastSX : m->fastSY);                            // +4 or -4
-            uint32_t line = (uint32_t)(__mul24(m->fastAlongX ? xg0 : yg0, alongStep) + (int)(across + (m->fastC0 - (uint32_t)(WIN - 1) * m->fastRev4)));
+            // (QuadMap::fastC0 ...: a 24-bit multiply per axis and a three-operand add) and one add per further line, instead of 2 WIN
+            // clamped indices, flips, multiplies and adds per lane
+            uint32_t line = (uint32_t)__mul24(xg0, (int)m->fastSX) + (uint32_t)__mul24(yg0, (int)m->fastSY) + (m->fastC0 - (uint32_t)(WIN - 1) * m->fastRev4);
             arranged = 1 + (m->fastAlongX ? 0 : 2) + (m->fastRev4 ? 1 : 0);
 #pragma unroll
             for (int k = 0; k < WIN; ++k) {
@@ -146,7 +143,7 @@ struct QuadSrc {
             }
             return;
         }
-        if (SCALED && allInside && WIN - 1 <= m->scale && m->anchorRows == 0) {
+        if (SCALED && allInside && WIN - 1 <= m->scale && m->anchorRows == 0 && m->mul24Ok) {
             // Replicated pixels, window no wider than a source pixel plus one: it spans at most two source columns and two
             // source rows -- four loads, and every position selects its value by which side of the split it lies on
             // (x >= 0 here, so (x + 0.5) / scale is at least 0.5 / scale away from an integer: the floor is exact -- in fp32 too,
@@ -156,7 +153,7 @@ struct QuadSrc {
             const int qx0 = (int)(((float)xg0 + 0.5f) * m->invScale), qy0 = (int)(((float)yg0 + 0.5f) * m->invScale);
             const int splitX = scale - (xg0 - __mul24(qx0, scale)), splitY = scale - (yg0 - __mul24(qy0, scale));      // in [1, scale]: first column / row of the second source pixel
             const int ux0 = m->flipX ? m->nX - 1 - qx0 : qx0, uy0 = m->flipY ? m->nY - 1 - qy0 : qy0;
-            const unsigned c0 = (unsigned)ux0 * sxb, r0 = (unsigned)uy0 * syb;
+            const unsigned c0 = (unsigned)__mul24(ux0, (int)sxb), r0 = (unsigned)__mul24(uy0, (int)syb);
             // the second source pixel, where the window reaches it, is one step along the (possibly flipped) axis (never fetched from
             // outside the image)
             const unsigned c1 = splitX < WIN ? (m->flipX ? c0 - sxb : c0 + sxb) : c0, r1 = splitY < WIN ? (m->flipY ? r0 - syb : r0 + syb) : r0;
@@ -190,19 +187,14 @@ struct QuadSrc {
                 rowOff[i] = (unsigned)(m->flipY ? m->nY - 1 - Y : Y);
             }
         } else {
-            // floor division of coordinates that are >= -8 (the window meets the lattice): exact, (n + 0.5) / scale is
-            // at least 0.5 / scale away from an integer; inside the window (rem + i + 0.5) / scale with rem + i <
-            // scale + 8 is far from every integer compared with fp32 rounding
-            const int scale = m->scale;
-            const int tx = xg0 + 8 * scale, ty = yg0 + 8 * scale;
-            const int qx0 = (int)(((double)tx + 0.5) * m->invScaleD), qy0 = (int)(((double)ty + 0.5) * m->invScaleD);
-            const float remX = (float)(tx - qx0 * scale) + 0.5f, remY = (float)(ty - qy0 * scale) + 0.5f;
+            // replicated pixels, any window (also one that misses the lattice altogether): replicated_indices, aai_rot_quad.hpp
+            int qx[WIN], qy[WIN];
+            replicated_indices<WIN>(xg0, mW, m->scale, m->invScaleD, m->invScale, qx);
+            replicated_indices<WIN>(yg0, mH, m->scale, m->invScaleD, m->invScale, qy);
 #pragma unroll
             for (int i = 0; i < WIN; ++i) {
-                const int ix = min(max(xg0 + i, 0), mW - 1) - xg0, iy = min(max(yg0 + i, 0), mH - 1) - yg0;
-                const int qx = qx0 - 8 + (int)((remX + (float)ix) * m->invScale), qy = qy0 - 8 + (int)((remY + (float)iy) * m->invScale);
-                colOff[i] = (unsigned)(m->flipX ? m->nX - 1 - qx : qx);
-                rowOff[i] = (unsigned)(m->flipY ? m->nY - 1 - qy : qy);
+                colOff[i] = (unsigned)(m->flipX ? m->nX - 1 - qx[i] : qx[i]);
+                rowOff[i] = (unsigned)(m->flipY ? m->nY - 1 - qy[i] : qy[i]);
             }
         }
         // Images of 4 GiB and more: offsets are taken from an anchor row of this WAVE instead of the image's first row --

@@ -48,6 +48,9 @@ struct CellConsts {
     F thr;                 // 2k - h: a zone coordinate below this puts the pixel centre within k of the grid line through G
     F hbz;                 // h (c + s) + guard: half extent of the lattice window that holds a zone
     int win;               // lattice positions per axis of that window, <= kQuadMaxWin
+    // classification by intervals (cell_eval, pass 1): along a window row the zone coordinates grow with the column, so each threshold
+    // is crossed at ONE column: az < X from column X / c + (row term) on.  X / c + 1/2 for X = -h, +h, thr and the same with 1 / s:
+    F eALo, eAHi, eAV, eBLo, eBHi, eBH;
     double zx, zy;         // zone centre - dst pixel centre, virtual frame
     double gx, gy;         // G - zone centre, virtual frame
     double kD, hmkD;
@@ -59,6 +62,8 @@ AAI_HD CellConsts<F> make_cell_consts(double side, double c, double s)
     CellConsts<F> z;
     const double h = 0.5 * side, k = 0.5 * (c + s), hmk = h - k;
     z.thr = (F)(2.0 * k - h);
+    z.eALo = (F)(-h / c + 0.5); z.eAHi = (F)(h / c + 0.5); z.eAV = (F)((2.0 * k - h) / c + 0.5);
+    z.eBLo = (F)(-h / s + 0.5); z.eBHi = (F)(h / s + 0.5); z.eBH = (F)((2.0 * k - h) / s + 0.5);
     const double hbz = h * (c + s) + 1e-5;
     z.hbz = (F)hbz;
     z.win = (int)floor(2.0 * hbz) + 1;
@@ -97,6 +102,26 @@ AAI_HD bool cell_supported(double side, double c, double s)
     if (!quad_supported(side, c, s)) return false;
     return (int)floor(2.0 * (0.5 * side * (c + s) + 1e-5)) + 1 <= kQuadMaxWin;
 }
+
+// rows J ... WIN - 1: (a*, b*) = this row's six crossing columns (+ 1/2); stepA / stepB = what a row adds to them
+template <int WIN, int J>
+struct CellRows {
+    template <typename F>
+    static AAI_HD void run(F aLo, F aHi, F aV, F bLo, F bHi, F bH, F stepA, F stepB, RowPlane &pLo, RowPlane &pHi, RowPlane &pV, RowPlane &pH)
+    {
+        // inside the zone: above BOTH lower crossings and below both upper ones
+        quad_row_bits<WIN, J>(quad_columns_below<WIN>(qmax(aLo, bLo)), pLo);
+        quad_row_bits<WIN, J>(quad_columns_below<WIN>(qmin(aHi, bHi)), pHi);
+        quad_row_bits<WIN, J>(quad_columns_below<WIN>(aV), pV);
+        quad_row_bits<WIN, J>(quad_columns_below<WIN>(bH), pH);
+        CellRows<WIN, J + 1>::run(aLo + stepA, aHi + stepA, aV + stepA, bLo + stepB, bHi + stepB, bH + stepB, stepA, stepB, pLo, pHi, pV, pH);
+    }
+};
+template <int WIN>
+struct CellRows<WIN, WIN> {
+    template <typename F>
+    static AAI_HD void run(F, F, F, F, F, F, F, F, RowPlane &, RowPlane &, RowPlane &, RowPlane &) {}
+};
 
 // A grid line cuts a unit pixel into a smaller and a larger part; tp = the line's distance from the pixel's nearer extreme
 // corner (quad_cut_tp's mirrored parameter).  Area of the SMALLER part, exact and under the reference's corner rule for a
@@ -152,8 +177,7 @@ AAI_HD bool cell_eval(const QuadConsts<F> &q, const CellConsts<F> &z, int Zx, in
     typedef typename QuadMask<WIN>::type u64;
     static_assert(WIN >= 1 && WIN <= kQuadMaxWin, "window size");
     const F fpx = (F)dfx, fpy = (F)dfy;
-#pragma unroll
-    for (int t = 0; t < 4; ++t) { sA[t] = F(0); sVA[t] = F(0); }
+    // (the sums start from the parts of the pixel that holds G, below: no zeroing, no first addition)
     auto value = [&](int slot) -> F {
         if (SCAN) return F(1);
         F vals[1];
@@ -180,8 +204,9 @@ AAI_HD bool cell_eval(const QuadConsts<F> &q, const CellConsts<F> &z, int Zx, in
     if (!interior) {
         const int ia = xg0 < 0 ? -xg0 : 0, ib = (mW - 1 - xg0 < WIN - 1) ? mW - 1 - xg0 : WIN - 1;
         const int ja = yg0 < 0 ? -yg0 : 0, jb = (mH - 1 - yg0 < WIN - 1) ? mH - 1 - yg0 : WIN - 1;
-        if (ia > ib || ja > jb) return false;                                 // the whole window misses the image
-        const unsigned cols = (2u << ib) - (1u << ia);
+        // (a window that misses the image altogether has no valid position: every sum below comes out zero -- no early exit, the other
+        // lanes of the wave walk on anyway)
+        const unsigned cols = ia > ib ? 0u : (2u << ib) - (1u << ia);
         valid = 0;
 #pragma unroll
         for (int j = 0; j < WIN; ++j)
@@ -209,35 +234,49 @@ AAI_HD bool cell_eval(const QuadConsts<F> &q, const CellConsts<F> &z, int Zx, in
     bool uncertain = false;
 
     // ---- pass 1: which zone does every lattice point of the window belong to ------------------------------------------
-    QuadPlane<WIN> plZ, plV, plH;         // in this cell's zone; within k of the vertical / horizontal grid line through G
+    // Zone coordinates of window position (i, j): az = ac + (fi0 + i) c - (fj0 + j) s, bz = bc + (fi0 + i) s + (fj0 + j) c -- both grow
+    // with i, so along a window row each threshold X is crossed at ONE column:
+    //   az < X  <=>  i < X / c + iA + j s / c,   iA = -ac / c + fj0 s / c - fi0;     bz < X  <=>  i < X / s + iB - j c / s.
+    // Per row: six running crossing columns, the zone's two bounds (max / min), four column counts and four bit runs (CellRows) -- 20
+    // instructions where testing the row's positions one by one took ~12 each.  The crossing columns carry fp32 rounding of their own:
+    // the scan (below) also classifies position by position and reports every cell where the two disagree.
+    u64 mVtx, mLeft, mTop, mIn;
+    {
+        const F iA = qfma(-ac, q.rc, qfma(fj0, q.m1, -fi0)), iB = qfma(-bc, q.rs, qfma(-fj0, q.im1, -fi0));
+        RowPlane pLo, pHi, pV, pH;
+        CellRows<WIN, 0>::run(iA + z.eALo, iA + z.eAHi, iA + z.eAV, iB + z.eBLo, iB + z.eBHi, iB + z.eBH, q.m1, -q.im1, pLo, pHi, pV, pH);
+        auto whole = [](const RowPlane &p) -> u64 { return WIN * WIN <= 32 ? (u64)p.lo : (u64)(((unsigned long long)p.hi << 32) | p.lo); };
+        const u64 zone = whole(pHi) & ~whole(pLo) & valid, wV = whole(pV), wH = whole(pH);
+        const u64 zv = zone & wV, zn = zone ^ zv;
+        mVtx = zv & wH; mLeft = zv ^ mVtx; mTop = zn & wH; mIn = zn ^ mTop;
+    }
+    if (SCAN) {
+        QuadPlane<WIN> plZ, plV, plH;         // in this cell's zone; within k of the vertical / horizontal grid line through G
 #pragma unroll
-    for (int jj = 0; jj < WIN; ++jj) {
-        const int j = WIN - 1 - jj;                                  // (last slot first: QuadPlane)
-        const F fj = fj0 + (F)j;
-        F rowA, rowB;
-        qfma2(-fj, fj, q.s, q.c, ac, bc, rowA, rowB);
+        for (int jj = 0; jj < WIN; ++jj) {
+            const int j = WIN - 1 - jj;                                  // (last slot first: QuadPlane)
+            const F fj = fj0 + (F)j;
+            F rowA, rowB;
+            qfma2(-fj, fj, q.s, q.c, ac, bc, rowA, rowB);
 #pragma unroll
-        for (int ii = 0; ii < WIN; ++ii) {
-            const int i = WIN - 1 - ii;
-            const F fi = fi0 + (F)i;
-            F az, bz;
-            qfma2(fi, fi, q.c, q.s, rowA, rowB, az, bz);
-            const u64 bit = (u64)1 << (j * WIN + i);
-            plZ.push(j * WIN + i, qabs(az) < q.h && qabs(bz) < q.h);
-            plV.push(j * WIN + i, az < z.thr);
-            plH.push(j * WIN + i, bz < z.thr);
-            if (SCAN) {
+            for (int ii = 0; ii < WIN; ++ii) {
+                const int i = WIN - 1 - ii;
+                const F fi = fi0 + (F)i;
+                F az, bz;
+                qfma2(fi, fi, q.c, q.s, rowA, rowB, az, bz);
+                const u64 bit = (u64)1 << (j * WIN + i);
+                plZ.push(j * WIN + i, qabs(az) < q.h && qabs(bz) < q.h);
+                plV.push(j * WIN + i, az < z.thr);
+                plH.push(j * WIN + i, bz < z.thr);
                 const bool live = (valid & bit) != 0;
                 const F na = qabs(qabs(az) - q.h), nb = qabs(qabs(bz) - q.h);
                 const bool nearZone = qabs(az) < q.h + q.margin && qabs(bz) < q.h + q.margin;
                 if (live && nearZone && (na < q.margin || nb < q.margin || qabs(az - z.thr) < q.margin || qabs(bz - z.thr) < q.margin)) uncertain = true;
             }
         }
+        const u64 pZ = plZ.mask() & valid, pV = plV.mask(), pH = plH.mask();
+        if ((pZ & pV & pH) != mVtx || (pZ & pV & ~pH) != mLeft || (pZ & ~pV & pH) != mTop || (pZ & ~pV & ~pH) != mIn) uncertain = true;
     }
-    u64 pZ = plZ.mask();
-    const u64 pV = plV.mask(), pH = plH.mask();
-    pZ &= valid;
-    u64 mVtx = pZ & pV & pH, mLeft = pZ & pV & ~pH, mTop = pZ & ~pV & pH, mIn = pZ & ~pV & ~pH;
     if (!SCAN) src.commit();
 
     // ---- the pixel that holds G: four wedge areas, one per dst pixel around G ----------------------------------------------
@@ -246,30 +285,32 @@ AAI_HD bool cell_eval(const QuadConsts<F> &q, const CellConsts<F> &z, int Zx, in
         const F rx = floor(gzx + F(0.5)), ry = floor(gzy + F(0.5));
         const F fx = gzx - rx, fy = gzy - ry;
         const int i = (int)rx - i0, j = (int)ry - j0;
-        if (i < 0 || i >= WIN || j < 0 || j >= WIN) { if (SCAN) uncertain = true; }       // cannot happen (the window holds G's pixel)
-        else {
-            const int slot = j * WIN + i;
-            const u64 bit = (u64)1 << slot;
-            if (SCAN && (qabs(fx) > F(0.5) - q.margin || qabs(fy) > F(0.5) - q.margin)) uncertain = true;
-            mVtx &= ~bit; mLeft &= ~bit; mTop &= ~bit; mIn &= ~bit;
-            if (valid & bit) {
-                const F v = value(slot);
-                F area[4];
-                if (HP) {
-                    const double fxD = (dfx + z.gx) - (double)rx, fyD = (dfy + z.gy) - (double)ry;
-                    if (q.steep) {
-                        double areaD[4];
-                        cell_vertex_areas<double>(q.m1D, q.im1D, fxD, fyD, areaD);
+        // (the window always holds G's pixel: its centre lies within hbz - 1e-5 of the zone's; the scan checks it all the same)
+        const bool held = !SCAN || (i >= 0 && i < WIN && j >= 0 && j < WIN);
+        if (!held) uncertain = true;
+        const int slot = held ? j * WIN + i : 0;
+        const u64 bit = (u64)1 << slot;
+        if (SCAN && (qabs(fx) > F(0.5) - q.margin || qabs(fy) > F(0.5) - q.margin)) uncertain = true;
+        // G's pixel lies in the vertex zone (its centre is within 1/2 of G along both lattice axes, i.e. within k along the dst axes),
+        // unless G sits on its rim -- which the scan has just reported
+        mVtx &= ~bit;
+        if (SCAN) { mLeft &= ~bit; mTop &= ~bit; mIn &= ~bit; }
+        F area[4];
+        if (HP) {
+            const double fxD = (dfx + z.gx) - (double)rx, fyD = (dfy + z.gy) - (double)ry;
+            if (q.steep) {
+                double areaD[4];
+                cell_vertex_areas<double>(q.m1D, q.im1D, fxD, fyD, areaD);
 #pragma unroll
-                        for (int t = 0; t < 4; ++t) area[t] = (F)areaD[t];
-                    } else cell_vertex_areas<F>(q.m1, q.im1, (F)fxD, (F)fyD, area);
-                } else cell_vertex_areas<F>(q.m1, q.im1, fx, fy, area);
-                // G is vertex 0 (left/top) of the cell's own dst pixel, vertex 1 (right/top) of its left neighbour,
-                // vertex 2 (left/bottom) of the one above, vertex 3 of the one above left
+                for (int t = 0; t < 4; ++t) area[t] = (F)areaD[t];
+            } else cell_vertex_areas<F>(q.m1, q.im1, (F)fxD, (F)fyD, area);
+        } else cell_vertex_areas<F>(q.m1, q.im1, fx, fy, area);
+        // G is vertex 0 (left/top) of the cell's own dst pixel, vertex 1 (right/top) of its left neighbour,
+        // vertex 2 (left/bottom) of the one above, vertex 3 of the one above left
+        const bool inImage = held && (interior || (valid & bit) != 0);
+        const F v = value(slot);
 #pragma unroll
-                for (int t = 0; t < 4; ++t) addf(t, area[t], v);
-            }
-        }
+        for (int t = 0; t < 4; ++t) { sA[t] = inImage ? area[t] : F(0); sVA[t] = inImage ? area[t] * v : F(0); }
     }
 
     if (upOnly) { mIn = 0; mLeft = 0; }
@@ -337,15 +378,16 @@ AAI_HD bool cell_eval(const QuadConsts<F> &q, const CellConsts<F> &z, int Zx, in
         F sA_, sAr, sB_, unused;
         cell_cut_small(q, tpA, sA_, sAr);
         cell_cut_small(q, tpB, sB_, unused);
-        const F gE = flipA ? F(1) - sA_ : sA_, gW = flipA ? sA_ : F(1) - sA_;          // exact parts E / W of the vertical line
-        const F gEr = flipA ? F(1) - sAr : sAr, gWr = flipA ? sAr : F(1) - sAr;        // ... under the reference's corner rule
-        const F gS = flipB ? F(1) - sB_ : sB_, gN = flipB ? sB_ : F(1) - sB_;          // parts S / N of the horizontal line
-        // the dst pixel between the two rays: both edges cross the pixel, exact
-        const F both = qmax((right ? gE : gW) + (down ? gS : gN) - F(1), F(0));
-        const F aO = right ? (down ? both : gS) : (down ? gEr : F(0));
-        const F aW = right ? (down ? gWr : F(0)) : (down ? both : gS);
-        const F aN = right ? (down ? gN : both) : (down ? F(0) : gEr);
-        const F aNW = right ? (down ? F(0) : gWr) : (down ? gN : both);
+        // E / W of the vertical line: the side `flipA` names holds the larger part; `right`: the dst pixel BETWEEN the two rays lies E of
+        // it (exact part there: both edges cross the pixel), the one across the ray W of it (that cut ALONE: the reference's corner rule)
+        const F bigA = F(1) - sA_, bigAr = F(1) - sAr, bigB = F(1) - sB_;
+        const bool nearA = right == flipA, nearB = down == flipB;
+        const F inA = nearA ? bigA : sA_, loneA = nearA ? sAr : bigAr;
+        const F inB = nearB ? bigB : sB_, loneB = nearB ? sB_ : bigB;
+        const F both = qmax((inA + inB) - F(1), F(0));
+        // `both` goes to the dst pixel on the (right, down) side of G, loneA across the vertical ray, loneB across the horizontal one
+        const F p0 = right ? both : loneA, p1 = right ? loneA : both, q0 = right ? loneB : F(0), q1 = right ? F(0) : loneB;
+        const F aO = down ? p0 : q0, aW = down ? p1 : q1, aN = down ? q0 : p0, aNW = down ? q1 : p1;
         const F v = value(slot);
         if (finite(v)) {
             addf(CELL_O, aO, v); addf(CELL_W, aW, v); addf(CELL_N, aN, v); addf(CELL_NW, aNW, v);
@@ -371,13 +413,16 @@ AAI_HD CellColumn cell_column(const RotLaunch &r, const CellConsts<F> &z, int dx
     return col;
 }
 // false: so far from the lattice that the cell touches nothing (and the integers below would leave int range)
+// NEAR: the caller knows the cell to be near the lattice (the kernel: cell rows inside cell_live_rows of a strip are within 63 cell
+// columns of a cell in reach) -- the test is skipped, a cell beyond reach finds its whole window outside the lattice in cell_eval
+template <bool NEAR = false>
 AAI_HD bool cell_anchor(const RotLaunch &r, const CellColumn &col, int dy, int &Zx, int &Zy, double &dfx, double &dfy)
 {
     const double v = (double)dy;
     const double zx = qfma(v, r.cXb, col.bx), zy = qfma(v, r.cYb, col.by);
     const double cx = floor(zx + 0.5), cy = floor(zy + 0.5);
-    // (one test, not four nested ones: the kernel evaluates this in every row, and short-circuit branches cost more than the compares)
-    const bool inReach = (cx > -16.0) & (cx < (double)r.mW + 16.0) & (cy > -16.0) & (cy < (double)r.mH + 16.0);
+    // (one test, not four nested ones: short-circuit branches cost more than the compares)
+    const bool inReach = NEAR || ((cx > -16.0) & (cx < (double)r.mW + 16.0) & (cy > -16.0) & (cy < (double)r.mH + 16.0));
     if (!inReach) return false;
     Zx = (int)cx; Zy = (int)cy; dfx = zx - cx; dfy = zy - cy;
     return true;

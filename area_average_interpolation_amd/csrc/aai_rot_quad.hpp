@@ -56,6 +56,7 @@ struct QuadConsts {
     F r2cs, rhi, trapOff;             // 1/(2cs), 1/hi, lo/(2 hi)
     F rc, rs, hrc;                    // 1/c, 1/s, 1/(2c)
     F m1, im1;                        // s/c, c/s
+    F hmkRc, hpkRc, hmkRs, hpkRs;     // (h - k) / c, (h + k) / c, (h - k) / s, (h + k) / s: the thresholds of |a|, |b| in window columns (QuadRows)
     F ox[4], oy[4];                   // vertex i = centre + (ox[i], oy[i]); 0 left/top, 1 right/top, 2 left/bottom, 3 right/bottom
     F hbm;                            // h(c+s) - 1/2 + guard: half extent of the window of pixel CENTRES
     F margin;                         // SCAN: decisions closer than this to their threshold are reported
@@ -160,6 +161,7 @@ AAI_HD QuadConsts<F> make_quad_consts(double side, double c, double s, int polic
     q.r2cs = (F)(1.0 / (2.0 * c * s)); q.rhi = (F)(1.0 / hi); q.trapOff = (F)(lo / (2.0 * hi));
     q.rc = (F)(1.0 / c); q.rs = (F)(1.0 / s); q.hrc = (F)(0.5 / c);
     q.m1 = (F)(s / c); q.im1 = (F)(c / s);
+    q.hmkRc = (F)((h - k) / c); q.hpkRc = (F)((h + k) / c); q.hmkRs = (F)((h - k) / s); q.hpkRs = (F)((h + k) / s);
     const double o0x = -h * (c + s), o0y = h * (s - c), o1x = h * (c - s), o1y = -h * (s + c);
     q.ox[0] = (F)o0x; q.oy[0] = (F)o0y; q.ox[1] = (F)o1x; q.oy[1] = (F)o1y;
     q.ox[2] = (F)-o1x; q.oy[2] = (F)-o1y; q.ox[3] = (F)-o0x; q.oy[3] = (F)-o0y;
@@ -390,6 +392,104 @@ struct QuadPlane {
     }
 };
 
+// Source indices of the WIN window positions g0 ... g0 + WIN - 1 along one axis of a REPLICATED lattice (mN = n * scale virtual
+// pixels): every position is clamped onto the lattice first, then divided by the scale relative to the FIRST clamped position -- a
+// non-negative coordinate whose floor division is exact in double precision, and non-negative steps (rem + i + 0.5) / scale with rem
+// + i < scale + WIN, far from every integer compared with fp32 rounding.  Any g0: the cell kernel evaluates cells whose window misses
+// the lattice altogether instead of branching around them (tests/emulation: aai_emu_replicated_indices).
+template <int WIN>
+AAI_HD void replicated_indices(int g0, int mN, int scale, double invScaleD, float invScale, int (&q)[WIN])
+{
+    const int o = g0 < 0 ? 0 : (g0 > mN - 1 ? mN - 1 : g0);
+    const int q0 = (int)(((double)o + 0.5) * invScaleD);
+    const float rem = (float)(o - q0 * scale) + 0.5f;
+#pragma unroll
+    for (int i = 0; i < WIN; ++i) {
+        const int g = g0 + i, c = g < 0 ? 0 : (g > mN - 1 ? mN - 1 : g);
+        q[i] = q0 + (int)((rem + (float)(c - o)) * invScale);          // (c - o in [0, WIN))
+    }
+}
+
+// ---- classification by intervals ------------------------------------------------------------------------------------------------
+// The dst-frame coordinates of the window positions of one row grow with the column (cos, sin > 0), so a threshold is crossed at ONE
+// column, and "which positions of this row lie below X" is a run of bits from column 0 on: the crossing column (one addition per row
+// and threshold), a clamp, a rounding and a bit-run instruction -- where testing the positions one by one costs a multiply-add, a
+// compare and a shift-in EACH.  The helpers below are shared by the quad, wide and cell formulations.
+// bits [OFF, OFF + n) of a word, n = the low five bits of `count`: ONE instruction on the GPU (v_bfm_b32)
+template <int OFF>
+AAI_HD unsigned quad_bit_run(unsigned count)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    unsigned r;
+    asm("v_bfm_b32 %0, %1, %2" : "=v"(r) : "v"(count), "n"(OFF));
+    return r;
+#else
+    return ((1u << (count & 31u)) - 1u) << OFF;
+#endif
+}
+// How many of the columns 0 .. WIN - 1 lie below e, as the low bits of a word; eHalf = e + 1/2.  Clamped to [0, WIN], then rounded to
+// the nearest integer by adding 1.5 x 2^23 (whose low bits are zero): ceil(e) for every e that is not an integer -- and a threshold
+// crossed exactly AT a column is a decision the scan leaves to the fix-up pass anyway.  Two instructions.
+template <int WIN>
+AAI_HD unsigned quad_columns_below(double eHalf)        // (the CPU checks' double-precision instantiation)
+{
+    return (unsigned)__builtin_nearbyint(qmin(qmax(eHalf, 0.0), (double)WIN));
+}
+template <int WIN>
+AAI_HD unsigned quad_columns_below(float eHalf)
+{
+    const float t = qmin(qmax(eHalf, 0.f), (float)WIN) + 12582912.f;
+#if defined(__HIP_DEVICE_COMPILE__)
+    return (unsigned)__float_as_int(t);
+#else
+    unsigned u;
+    __builtin_memcpy(&u, &t, 4);
+    return u;
+#endif
+}
+// a plane of window-slot bits built row by row
+struct RowPlane {
+    unsigned lo = 0, hi = 0;
+    template <int WIN>
+    AAI_HD typename QuadMask<WIN>::type whole() const
+    {
+        typedef typename QuadMask<WIN>::type mask_t;
+        return WIN * WIN <= 32 ? (mask_t)lo : (mask_t)(((unsigned long long)hi << 32) | lo);
+    }
+};
+// the bits of window row J (slots J WIN ... J WIN + WIN - 1) below column count `n`, into a plane
+template <int WIN, int J>
+AAI_HD void quad_row_bits(unsigned n, RowPlane &p)
+{
+    if (J * WIN + WIN <= 32) p.lo |= quad_bit_run<(J * WIN + WIN <= 32 ? J * WIN : 0)>(n);
+    else if (J * WIN >= 32) p.hi |= quad_bit_run<(J * WIN >= 32 ? J * WIN - 32 : 0)>(n);
+    else {
+        const unsigned long long b = (unsigned long long)quad_bit_run<0>(n) << (J * WIN);
+        p.lo |= (unsigned)b; p.hi |= (unsigned)(b >> 32);
+    }
+}
+// rows J ... WIN - 1 of quad_pixel's window: (a0, b0) = the columns (+ 1/2) where a and b cross zero in this row; |a| <= h - k between
+// the columns a0 -/+ hmkRc, |a| < h + k between a0 -/+ hpkRc, the same for b with 1 / s
+template <int WIN, int J>
+struct QuadRows {
+    template <typename F>
+    static AAI_HD void run(const QuadConsts<F> &q, F a0, F b0, RowPlane &aLo, RowPlane &aHi, RowPlane &bLo, RowPlane &bHi, RowPlane &tLo, RowPlane &tHi)
+    {
+        quad_row_bits<WIN, J>(quad_columns_below<WIN>(a0 - q.hmkRc), aLo);
+        quad_row_bits<WIN, J>(quad_columns_below<WIN>(a0 + q.hmkRc), aHi);
+        quad_row_bits<WIN, J>(quad_columns_below<WIN>(b0 - q.hmkRs), bLo);
+        quad_row_bits<WIN, J>(quad_columns_below<WIN>(b0 + q.hmkRs), bHi);
+        quad_row_bits<WIN, J>(quad_columns_below<WIN>(qmax(a0 - q.hpkRc, b0 - q.hpkRs)), tLo);
+        quad_row_bits<WIN, J>(quad_columns_below<WIN>(qmin(a0 + q.hpkRc, b0 + q.hpkRs)), tHi);
+        QuadRows<WIN, J + 1>::run(q, a0 + q.m1, b0 - q.im1, aLo, aHi, bLo, bHi, tLo, tHi);
+    }
+};
+template <int WIN>
+struct QuadRows<WIN, WIN> {
+    template <typename F>
+    static AAI_HD void run(const QuadConsts<F> &, F, F, RowPlane &, RowPlane &, RowPlane &, RowPlane &, RowPlane &, RowPlane &) {}
+};
+
 // One dst pixel.  WIN = window positions per axis (QuadConsts::win, a compile-time constant so that the window pass
 // unrolls and the staged window has a fixed size); window position (i, j) is bit / slot j * WIN + i.
 // (Xc, Yc) = the virtual pixel nearest the centre, (fpx, fpy) = centre - (Xc, Yc), both in [-1/2, 1/2].
@@ -465,26 +565,42 @@ AAI_HD bool quad_pixel(const QuadConsts<F> &q, int Xc, int Yc, double dfx, doubl
     bool uncertain = false;
 
     // ---- pass 1: classify every window position --------------------------------------------------------------
-    // bit planes: |a| <= h - k, |b| <= h - k, touched; the class masks follow from them with three 64-bit operations
-    QuadPlane<WIN> plA, plB, plT;
+    // a = ac + (fi0 + i) c - (fj0 + j) s and b = bc + (fi0 + i) s + (fj0 + j) c grow with the column i, so in row j
+    //   a < X  <=>  i < X / c + iA + j s / c,  iA = -ac / c + fj0 s / c - fi0;      b < X  <=>  i < X / s + iB - j c / s
+    // and the planes |a| <= h - k, |b| <= h - k, touched (|a| < h + k and |b| < h + k) are runs of columns: QuadRows, ~30 instructions
+    // per row where the positions one by one took ~12 each.  The crossing columns carry fp32 rounding of their own: the scan
+    // (below) also classifies position by position and reports every pixel where the two disagree.
+    u64 mIn, mSingle, mDouble;
+    {
+        const F iA = qfma(-ac, q.rc, qfma(fj0, q.m1, -fi0)), iB = qfma(-bc, q.rs, qfma(-fj0, q.im1, -fi0));
+        RowPlane aLo, aHi, bLo, bHi, tLo, tHi;
+        QuadRows<WIN, 0>::run(q, iA + F(0.5), iB + F(0.5), aLo, aHi, bLo, bHi, tLo, tHi);
+        const u64 pA = aHi.template whole<WIN>() & ~aLo.template whole<WIN>(), pB = bHi.template whole<WIN>() & ~bLo.template whole<WIN>();
+        const u64 pT = tHi.template whole<WIN>() & ~tLo.template whole<WIN>() & valid;
+        mIn = pA & pB & valid;                 // wholly inside (inside implies touched: h - k < h + k)
+        mSingle = pT & (pA ^ pB);              // one near line clear of the pixel, the other cuts it
+        mDouble = pT & ~(pA | pB);             // both near lines cut it
+    }
+    if (SCAN) {
+        // bit planes position by position: |a| <= h - k, |b| <= h - k, touched
+        QuadPlane<WIN> plA, plB, plT;
 #pragma unroll
-    for (int jj = 0; jj < WIN; ++jj) {
-        const int j = WIN - 1 - jj;                                  // (last slot first: QuadPlane)
-        const F fj = fj0 + (F)j;
-        F rowA, rowB;
-        qfma2(-fj, fj, q.s, q.c, ac, bc, rowA, rowB);
+        for (int jj = 0; jj < WIN; ++jj) {
+            const int j = WIN - 1 - jj;                                  // (last slot first: QuadPlane)
+            const F fj = fj0 + (F)j;
+            F rowA, rowB;
+            qfma2(-fj, fj, q.s, q.c, ac, bc, rowA, rowB);
 #pragma unroll
-        for (int ii = 0; ii < WIN; ++ii) {
-            const int i = WIN - 1 - ii;
-            const F fi = fi0 + (F)i;
-            F sa, sb;
-            qfma2(fi, fi, q.c, q.s, rowA, rowB, sa, sb);
-            const F a = qabs(sa), b = qabs(sb);
-            const u64 bit = (u64)1 << (j * WIN + i);
-            plA.push(j * WIN + i, a <= q.hmk);
-            plB.push(j * WIN + i, b <= q.hmk);
-            plT.push(j * WIN + i, a < q.hpk && b < q.hpk);
-            if (SCAN) {
+            for (int ii = 0; ii < WIN; ++ii) {
+                const int i = WIN - 1 - ii;
+                const F fi = fi0 + (F)i;
+                F sa, sb;
+                qfma2(fi, fi, q.c, q.s, rowA, rowB, sa, sb);
+                const F a = qabs(sa), b = qabs(sb);
+                const u64 bit = (u64)1 << (j * WIN + i);
+                plA.push(j * WIN + i, a <= q.hmk);
+                plB.push(j * WIN + i, b <= q.hmk);
+                plT.push(j * WIN + i, a < q.hpk && b < q.hpk);
                 // thresholds of |a| (the left/right line also switches formula at t = lo, hi under policy REFERENCE)
                 // and of |b|; one axis' thresholds only matter while the other axis does not already say "outside"
                 F na = qmin(qabs(a - q.hmk), qabs(a - q.hpk));
@@ -494,13 +610,9 @@ AAI_HD bool quad_pixel(const QuadConsts<F> &q, int Xc, int Yc, double dfx, doubl
                 if (live && ((na < q.margin && b < q.hpk + q.margin) || (nb < q.margin && a < q.hpk + q.margin))) uncertain = true;
             }
         }
+        const u64 pA = plA.mask(), pB = plB.mask(), pT = plT.mask() & valid;
+        if ((pA & pB & valid) != mIn || (pT & (pA ^ pB)) != mSingle || (pT & ~(pA | pB)) != mDouble) uncertain = true;
     }
-    const u64 pA = plA.mask(), pB = plB.mask();
-    u64 pT = plT.mask();
-    pT &= valid;
-    u64 mIn = pA & pB & valid;                 // wholly inside (inside implies touched: h - k < h + k)
-    u64 mSingle = pT & (pA ^ pB);              // one near line clear of the pixel, the other cuts it
-    u64 mDouble = pT & ~(pA | pB);             // both near lines cut it
     if (!SCAN) src.commit();
 
     // ---- the four pixels that hold a vertex ----------------------------------------------------------------------

@@ -100,9 +100,10 @@ __device__ __forceinline__ void cell_walk(int dW, int x0, int y0, int y1, bool o
         ownA = 0.f; ownVA = 0.f; belowA = 0.f; belowVA = 0.f; rowU = 0;
         rowLive = !(cy > liveHi || cy < liveLo);
         if (!rowLive) return;                                    // wave-uniform: every cell of this row misses the image
-        float sA[4] = {0.f, 0.f, 0.f, 0.f}, sVA[4] = {0.f, 0.f, 0.f, 0.f};
-        int unc = 0;
-        if (cx <= dW) unc = eval(cx, cy, sA, sVA, upOnly) ? 1 : 0;
+        float sA[4], sVA[4];
+        // (lanes beyond cell column dW -- the last strip's -- evaluate that column once more instead of sitting out: nobody reads their
+        // sums, and the wave has no divergent branch around the cell)
+        const int unc = eval(cx < dW ? cx : dW, cy, sA, sVA, upOnly) ? 1 : 0;
         ownA = sA[CELL_O] + from_next_lane(sA[CELL_W]); ownVA = sVA[CELL_O] + from_next_lane(sVA[CELL_W]);
         belowA = sA[CELL_N] + from_next_lane(sA[CELL_NW]); belowVA = sVA[CELL_N] + from_next_lane(sVA[CELL_NW]);
         rowU = unc | from_next_lane(unc);                        // the two cells of this row that feed column cx
@@ -168,7 +169,7 @@ __global__ __launch_bounds__(kQuadBlock, cell_min_waves(WIN)) void aai_cell_kern
     cell_segment(blockY0, blockY1, rpw, wave, y0, y1, ownsBottom);           // dst rows [y0, y1); cell rows y0 .. y1
     float *image = dst + (int64_t)blockIdx.z * dv.imageStride;
     const char *img = reinterpret_cast<const char *>(src + (int64_t)blockIdx.z * sv.imageStride + m.base);
-    const CellColumn col = cell_column(r, z, x0 + lane);
+    const CellColumn col = cell_column(r, z, min(x0 + lane, r.dW));          // (cell_walk: lanes beyond column dW repeat it)
     int liveLo, liveHi;
     cell_live_rows(live, x0, x0 + 63, liveLo, liveHi);         // wave-uniform
     // per-pixel masks only where a 16 x 16 tile this segment touches holds a flagged pixel (QuadMap::tileFlags; wave-uniform, scalar loads)
@@ -186,7 +187,7 @@ __global__ __launch_bounds__(kQuadBlock, cell_min_waves(WIN)) void aai_cell_kern
         [&](int cx, int cy, float (&sA)[4], float (&sVA)[4], bool upOnly) -> bool {
             int Zx, Zy;
             double dfx, dfy;
-            if (!cell_anchor(r, col, cy, Zx, Zy, dfx, dfy)) return false;
+            cell_anchor<true>(r, col, cy, Zx, Zy, dfx, dfy);
             QuadSrc<T, WIN, SCALED, true> s;
             s.img = img; s.m = &m; s.mW = r.mW; s.mH = r.mH; s.lds = window; s.tid = tid;
             // (the workgroup's bottom cell row only feeds its last pixel row: its interior / left-edge zones are skipped)
@@ -217,7 +218,7 @@ __global__ __launch_bounds__(kQuadBlock) void aai_cell_scan_kernel(RotLaunch r, 
     int y0, y1;
     bool ownsBottom;
     cell_segment(blockY0, blockY1, rowsPerWave, wave, y0, y1, ownsBottom);
-    const CellColumn col = cell_column(r, z, x0 + lane);
+    const CellColumn col = cell_column(r, z, min(x0 + lane, r.dW));
     int liveLo, liveHi;
     cell_live_rows(live, x0, x0 + 63, liveLo, liveHi);
     cell_walk(r.dW, x0, y0, y1, ownsBottom, wave, hand, liveLo, liveHi, lane,
@@ -225,7 +226,11 @@ __global__ __launch_bounds__(kQuadBlock) void aai_cell_scan_kernel(RotLaunch r, 
         [&](int cx, int cy, float (&sA)[4], float (&sVA)[4], bool) -> bool {
             int Zx, Zy;
             double dfx, dfy;
-            if (!cell_anchor(r, col, cy, Zx, Zy, dfx, dfy)) return false;
+            if (!cell_anchor(r, col, cy, Zx, Zy, dfx, dfy)) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t) { sA[t] = 0.f; sVA[t] = 0.f; }
+                return false;
+            }
             NoSrc s;
             return cell_eval<float, WIN, true, HP>(q, z, Zx, Zy, dfx, dfy, r.mW, r.mH, s, sA, sVA);
         },

@@ -365,7 +365,13 @@ def config_block(aai, torch, policy, cfg2_cpu, cpu_procs, cpu_pool, with_cpu, cp
         launch()
         torch.cuda.synchronize()
         one = max(time.perf_counter() - t0, 1e-5)
-        n = int(max(5, min(2000, 0.4 / one)))                      # about 0.4 s of launches per configuration
+        n = int(max(5, min(4000, 0.5 / one)))                      # about 0.5 s of launches per configuration ...
+        # ... after as many untimed ones: the CPU leg of the previous configuration left the GPU idle for seconds, and the kernels
+        # that are bound by instruction issue run ~12 % slower until its clocks are back up (config 3: 0.189 ms in a cold 0.4 s
+        # block, 0.167 ms in the 6 s leg of `--workload cfg3` on the same box)
+        for _ in range(n):
+            launch()
+        torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(n):

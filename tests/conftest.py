@@ -132,6 +132,8 @@ def hostemu(aai):
     lib.aai_emu_cell_live_rows_check.argtypes = [ctypes.POINTER(L.Request)]
     lib.aai_emu_fast_tile_cover.restype = ctypes.c_long
     lib.aai_emu_fast_tile_cover.argtypes = [ctypes.POINTER(L.Request), ctypes.POINTER(ctypes.c_long)]
+    lib.aai_emu_replicated_indices.restype = ctypes.c_long
+    lib.aai_emu_replicated_indices.argtypes = [ctypes.c_int] * 4
     lib.aai_emu_band_cover.restype = ctypes.c_long
     lib.aai_emu_band_cover.argtypes = [ctypes.POINTER(L.Request), ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_long)]
     lib.aai_emu_cell_band_cover.restype = ctypes.c_long

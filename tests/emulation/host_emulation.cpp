@@ -930,14 +930,32 @@ void cover_fast_pixel(const RotLaunch &r, const QuadConsts<float> &q, int dx, in
 template <int WIN, bool HP>
 void cover_cell(const RotLaunch &r, const QuadConsts<float> &q, const CellConsts<float> &z, int cx, int cy, bool upOnly, CoverCount &cc)
 {
+    // as aai_cell_kernel does: every cell of a strip's live rows is evaluated, without a reach test, whatever its window meets
     int Zx, Zy; double dfx, dfy;
-    if (!cell_anchor(r, cell_column(r, z, cx), cy, Zx, Zy, dfx, dfy)) return;
+    cell_anchor<true>(r, cell_column(r, z, cx), cy, Zx, Zy, dfx, dfy);
     CoverSrc<WIN> s{&cc};
     float sA[4], sVA[4];
     cell_eval<float, WIN, false, HP>(q, z, Zx, Zy, dfx, dfy, r.mW, r.mH, s, sA, sVA, upOnly);
 }
 }  // namespace
 }  // extern "C++"
+
+// replicated_indices against integer division, for every window origin from `lo` to `hi` on a lattice of n * scale virtual pixels:
+// the number of window positions whose source index differs from clamp(g, 0, n scale - 1) / scale
+long aai_emu_replicated_indices(int n, int scale, int lo, int hi)
+{
+    long bad = 0;
+    const int mN = n * scale;
+    for (int g0 = lo; g0 <= hi; ++g0) {
+        int q[8];
+        replicated_indices<8>(g0, mN, scale, 1.0 / scale, (float)(1.0 / scale), q);
+        for (int i = 0; i < 8; ++i) {
+            const int g = g0 + i, c = g < 0 ? 0 : (g > mN - 1 ? mN - 1 : g);
+            if (q[i] != c / scale) ++bad;
+        }
+    }
+    return bad;
+}
 
 long aai_emu_band_cover(const aai_request *rq, int r0, int r1, int family, long *fetched)
 {
@@ -984,8 +1002,20 @@ long aai_emu_band_cover(const aai_request *rq, int r0, int r1, int family, long 
         if (!r.cell) return -1;
         const QuadConsts<float> q = make_cell_quad_consts<float>(r.side, r.c, r.s, r.policy);
         const CellConsts<float> z = make_cell_consts<float>(r.side, r.c, r.s);
+        const CellLive live = make_cell_live(r, z);
         for (int cy = r0; cy <= r1; ++cy)
             for (int cx = 0; cx <= r.dW; ++cx) {
+                // (the kernel's strips of 63 columns: rows outside a strip's live range are not evaluated at all)
+                // (a strip holds 64 cell columns: its 63 dst columns and the first one of the next strip)
+                int liveLo, liveHi;
+                const int x0 = std::min(cx, r.dW - 1) / 63 * 63;
+                cell_live_rows(live, x0, x0 + 63, liveLo, liveHi);
+                bool rowLive = cy >= liveLo && cy <= liveHi;
+                if (cx % 63 == 0 && cx >= 63) {
+                    cell_live_rows(live, cx - 63, cx, liveLo, liveHi);
+                    rowLive = rowLive || (cy >= liveLo && cy <= liveHi);
+                }
+                if (!rowLive) continue;
 #define AAI_COVER_CASE(W)                                                                                                  \
     case W:                                                                                                                \
         if (q.hiPrec) cover_cell<W, true>(r, q, z, cx, cy, cy == r1, cc);                                                  \

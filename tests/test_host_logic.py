@@ -1008,3 +1008,14 @@ def test_empty_output_and_shape_errors(aai):
         aai.resample_host(np.zeros((4, 4, 3), np.float32), 2, 1, (1.5, 1.5), 0.0)
     rc, msg, dst, iso, lay = aai.resample_host(np.zeros((0,), np.float32), 2, 1, (0, 0), 0.0)
     assert rc == L.ERR_NO_ROWS and msg == "There is no data in src array."
+
+
+def test_replicated_window_indices_stay_on_the_image_for_any_window_origin(hostemu):
+    """The replicated (up-sampling) border path of the window kernels turns lattice positions into source indices with a floating-point
+    division.  The cell kernel evaluates cells whose window lies wholly beside the lattice (it has no branch around them): the indices
+    must equal clamp(position) // scale for ANY origin -- an earlier form was exact only for windows that met the lattice and produced
+    index n (one past the image) for origins beyond it, which the GPU answered with a memory access fault."""
+    for n, scale in ((50, 2), (33, 3), (1024, 4), (17, 6), (4096, 6), (5, 7), (100000, 2), (3, 16)):
+        mN = n * scale
+        for lo, hi in ((-700, 700), (mN - 700, mN + 700)):
+            assert hostemu.aai_emu_replicated_indices(n, scale, lo, hi) == 0, (n, scale, lo, hi)
