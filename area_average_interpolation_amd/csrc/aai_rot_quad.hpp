@@ -332,13 +332,10 @@ AAI_HD F quad_vertex_area(const QuadConsts<F> &q, F fx, F fy, int vidx);
 template <typename F>
 AAI_HD F quad_vertex_area(F m1, F im1, F fx, F fy, int vidx)
 {
-    F x, y;
-    switch (vidx) {
-    case 0: x = fx; y = fy; break;
-    case 1: x = fy; y = -fx; break;
-    case 2: x = -fy; y = fx; break;
-    default: x = -fx; y = -fy; break;
-    }
+    // (selects, not a switch: the wide kernel's lanes each evaluate their own vertex)
+    const bool straight = vidx == 0 || vidx == 3;
+    const F ax = straight ? fx : fy, ay = straight ? fy : fx;
+    const F x = vidx >= 2 ? -ax : ax, y = (vidx & 1) ? -ay : ay;      // 0: (fx, fy)  1: (fy, -fx)  2: (-fy, fx)  3: (-fx, -fy)
     // vertex 0: the wedge opens towards +x between the rays (c,-s) and (s,c)
     const F dR = F(0.5) - x, dT = y + F(0.5), dB = F(0.5) - y;
     const F y1 = qfma(-dR, m1, y), y2 = qfma(dR, im1, y);          // where the two rays meet the line x = 1/2
@@ -366,6 +363,18 @@ AAI_HD int quad_ctz(unsigned m)
     return __builtin_ctz(m);
 #endif
 }
+AAI_HD int quad_popcount(unsigned long long m) { return __builtin_popcount((unsigned)m) + __builtin_popcount((unsigned)(m >> 32)); }
+AAI_HD int quad_popcount(unsigned m) { return __builtin_popcount(m); }
+// v where keep is all ones, +0 where it is zero
+AAI_HD float quad_keep_bits(float v, int keep)
+{
+    unsigned u;
+    __builtin_memcpy(&u, &v, 4);
+    u &= (unsigned)keep;
+    __builtin_memcpy(&v, &u, 4);
+    return v;
+}
+AAI_HD double quad_keep_bits(double v, int keep) { return keep ? v : 0.0; }
 // position masks: one bit per window slot -- 32 bits are enough up to 5 x 5
 template <int WIN, bool SMALL = (WIN * WIN <= 32)> struct QuadMask { typedef unsigned long long type; };
 template <int WIN> struct QuadMask<WIN, true> { typedef unsigned type; };
@@ -616,6 +625,39 @@ AAI_HD bool quad_pixel(const QuadConsts<F> &q, int Xc, int Yc, double dfx, doubl
     if (!SCAN) src.commit();
 
     // ---- the four pixels that hold a vertex ----------------------------------------------------------------------
+    if (PART && !HP) {
+        // A part of a wide window holds ONE of the four vertices as a rule (two or none where the window's split passes beside them).
+        // Every lane first finds its vertices (position tests only), then evaluates them in a loop of its own -- one turn in almost
+        // every wave -- where four blocks in a row made all lanes sit through the vertices of the other three parts.
+        unsigned held = 0;
+        F hx[4], hy[4];
+        int hs[4];
+#pragma unroll
+        for (int vtx = 0; vtx < 4; ++vtx) {
+            const F wx = fpx + q.ox[vtx], wy = fpy + q.oy[vtx];       // vertex relative to (Xc, Yc)
+            const F rx = floor(wx + F(0.5)), ry = floor(wy + F(0.5));
+            hx[vtx] = wx - rx; hy[vtx] = wy - ry;
+            const int i = (int)rx - i0, j = (int)ry - j0;
+            hs[vtx] = j * WIN + i;
+            const bool mine = i >= 0 && i < WIN && j >= 0 && j < WIN;      // (else another part's)
+            if (mine) held |= 1u << vtx;
+            if (SCAN && mine && (qabs(hx[vtx]) > F(0.5) - q.margin || qabs(hy[vtx]) > F(0.5) - q.margin)) uncertain = true;
+        }
+        while (held) {
+            const int vtx = quad_ctz(held);
+            held &= held - 1;
+            const bool v0 = vtx == 0, v1 = vtx == 1, v2 = vtx == 2;
+            const int slot = v0 ? hs[0] : (v1 ? hs[1] : (v2 ? hs[2] : hs[3]));
+            const F fx = v0 ? hx[0] : (v1 ? hx[1] : (v2 ? hx[2] : hx[3])), fy = v0 ? hy[0] : (v1 ? hy[1] : (v2 ? hy[2] : hy[3]));
+            const u64 bit = (u64)1 << slot;
+            mDouble &= ~bit;
+            if (valid & bit) {
+                const F area = quad_vertex_area(q, fx, fy, vtx);
+                sumA += area;
+                accumulate(area, slot);
+            }
+        }
+    } else {
 #pragma unroll
     for (int vtx = 0; vtx < 4; ++vtx) {
         const F wx = fpx + q.ox[vtx], wy = fpy + q.oy[vtx];       // vertex relative to (Xc, Yc)
@@ -640,13 +682,35 @@ AAI_HD bool quad_pixel(const QuadConsts<F> &q, int Xc, int Yc, double dfx, doubl
             accumulate(area, slot);
         }
     }
+    }
 
     // ---- pixels wholly inside: area 1 ------------------------------------------------------------------------------
-    while (mIn) {
-        const int slot = quad_ctz(mIn);
-        mIn &= mIn - 1;
-        sumA += F(1);
-        accumulate(F(1), slot);
+    if (WIN >= 6) {
+        // Large windows (the parts of a wide footprint: most of their 36 ... 64 positions are interior): one straight pass over the
+        // positions -- a value from a fixed address, a bit test and an add each, in slot order -- instead of a loop over the set
+        // bits, whose every turn finds the bit, clears it and computes an address (~14 instructions with 64-bit masks) and which runs
+        // as long as the fullest lane of the wave
+        sumA += (F)quad_popcount(mIn);
+#pragma unroll
+        for (int slot = 0; slot < WIN * WIN; ++slot) {
+            F vals[NC];
+            if (SCAN) {
+#pragma unroll
+                for (int c = 0; c < NC; ++c) vals[c] = F(1);
+            } else src.at(slot, vals);
+            // (the position's bit spread over a word and ANDed onto the value's bits -- a select, not a product: a NaN outside stays outside)
+            const unsigned word = slot < 32 ? (unsigned)mIn : (unsigned)((unsigned long long)mIn >> 32);
+            const int keep = (int)(word << (31 - (slot & 31))) >> 31;
+#pragma unroll
+            for (int c = 0; c < NC; ++c) sumVA[c] += quad_keep_bits(vals[c], keep);
+        }
+    } else {
+        while (mIn) {
+            const int slot = quad_ctz(mIn);
+            mIn &= mIn - 1;
+            sumA += F(1);
+            accumulate(F(1), slot);
+        }
     }
     // ---- pixels cut by one edge line ---------------------------------------------------------------------------------
     while (mSingle) {

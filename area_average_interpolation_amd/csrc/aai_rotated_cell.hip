@@ -29,6 +29,11 @@
 #include <cstdlib>
 #include <cstring>
 
+// (a cap on the kernel's scalar registers -- 96 would admit a seventh wave per SIMD -- was measured and LOSES: config 3 156 -> 164 us, the
+// spills cost more than the wave brings; -DAAI_CELL_SGPRS=n brings it back; profiles/r04_cell_kernel.txt)
+#ifndef AAI_CELL_SGPRS
+#define AAI_CELL_SGPRS 0
+#endif
 namespace aai {
 
 // dst rows a wave walks.  A workgroup of 4 waves pays 4 R + 1 cell rows for 4 R dst rows, so taller is cheaper in instructions --
@@ -43,7 +48,10 @@ static int cell_rows_per_wave(int dW, int rows, int batch, double srcRowsPerDstR
     if (e && atoi(e) > 0) return atoi(e);
     const int64_t strips = ((int64_t)dW + 62) / 63 * batch;
     const double want = 14.0 / (srcRowsPerDstRow > 0.05 ? srcRowsPerDstRow : 0.05);
-    int R = want < 5.7 ? 4 : (want < 11.4 ? 8 : (want < 22.7 ? 16 : 32));      // the nearest power of two
+    // (the nearest power of two, except that ratios from ~1.9:1 up keep 4: since the classification by intervals the kernel waits for
+    // memory sooner -- 2:1 at 45 degrees, 4 images per launch: 229 / 254 / 372 us per image at 4 / 8 / 16 rows; config 3 at 8 images per
+    // launch: 163 / 194 us at 4 / 8 -- profiles/r04_cell_kernel.txt)
+    int R = want < 7.4 ? 4 : (want < 11.4 ? 8 : (want < 22.7 ? 16 : 32));
     while (R > 4 && strips * ((rows + R - 1) / R) < 24576) R >>= 1;
     while ((rows + 4 * R - 1) / (4 * R) > 65535) R <<= 1;       // grid.y
     return R;
@@ -144,7 +152,7 @@ __device__ __forceinline__ void cell_segment(int blockY0, int blockY1, int rowsP
 }
 
 template <typename T, int WIN, bool SCALED, bool HP>
-__global__ __launch_bounds__(kQuadBlock, cell_min_waves(WIN)) void aai_cell_kernel(
+__global__ __launch_bounds__(kQuadBlock, cell_min_waves(WIN)) __attribute__((amdgpu_num_sgpr(AAI_CELL_SGPRS))) void aai_cell_kernel(
     RotLaunch r, QuadConsts<float> q, CellConsts<float> z, CellLive live, QuadMap m, const T *__restrict__ src, ImageView sv, float *__restrict__ dst, ImageView dv,
     const unsigned long long *__restrict__ skipMasks, int tilesX, int rowsPerWave, int bigBlocks, int tailRows, int xcdRows, int rowBlocks)
 {
