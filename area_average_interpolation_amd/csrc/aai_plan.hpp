@@ -86,6 +86,9 @@ struct QuadMap {
     // every index x byte-stride product of the map fits a 24-bit multiply (v_mul_i32_i24, full rate, where the 32-bit multiply runs at a
     // quarter): fewer than 2^23 source pixels a side and a row pitch below 8 MiB.  fastOk implies it.
     int mul24Ok;
+    // set by the cell kernel's launcher for plain images of 4 GiB and more: every wave moves its base pointer to the first source row its
+    // cells can touch and takes that row's byte offset (mod 2^32) off its 32-bit lane offsets (QuadSrc::rebase, aai_rotated_cell.hip)
+    int rebaseWaves;
 };
 QuadMap make_quad_map(const Geometry &g, int64_t rowStride, int srcRow0, int channels = 1, int elementBytes = 4);      // channels: elements per pixel (interleaved)
 

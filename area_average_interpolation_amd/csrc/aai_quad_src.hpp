@@ -81,6 +81,10 @@ struct QuadSrc {
     int tid;
     T v[WIN * WIN];
     int arranged;                    // STAGED: 0 = v[] is in slot order; else 1 + arrangement of the vector-loaded lines (commit)
+    // Images of 4 GiB and more under the cell kernel: `img` points at a source row of the wave's own choosing and `rebase` is that row's
+    // byte offset modulo 2^32 -- the lane offsets below are computed modulo 2^32 as for a small image and `rebase` taken off: what
+    // remains is the true offset from `img` as long as the wave's rows span less than 4 GiB (cell_can_serve)
+    uint32_t rebase = 0;
 
     // index of window position (i, j) in v[] under arrangement ARR
     static __device__ __forceinline__ constexpr int mem_index(int j, int i)
@@ -131,7 +135,7 @@ struct QuadSrc {
             // wave-uniform number of bytes apart -- ONE per-lane byte offset from the host-composed coefficients of the map
             // (QuadMap::fastC0 ...: a 24-bit multiply per axis and a three-operand add) and one add per further line, instead of 2 WIN
             // clamped indices, flips, multiplies and adds per lane
-            uint32_t line = (uint32_t)__mul24(xg0, (int)m->fastSX) + (uint32_t)__mul24(yg0, (int)m->fastSY) + (m->fastC0 - (uint32_t)(WIN - 1) * m->fastRev4);
+            uint32_t line = (uint32_t)__mul24(xg0, (int)m->fastSX) + (uint32_t)__mul24(yg0, (int)m->fastSY) + (m->fastC0 - (uint32_t)(WIN - 1) * m->fastRev4 - rebase);
             arranged = 1 + (m->fastAlongX ? 0 : 2) + (m->fastRev4 ? 1 : 0);
 #pragma unroll
             for (int k = 0; k < WIN; ++k) {
@@ -153,7 +157,7 @@ struct QuadSrc {
             const int qx0 = (int)(((float)xg0 + 0.5f) * m->invScale), qy0 = (int)(((float)yg0 + 0.5f) * m->invScale);
             const int splitX = scale - (xg0 - __mul24(qx0, scale)), splitY = scale - (yg0 - __mul24(qy0, scale));      // in [1, scale]: first column / row of the second source pixel
             const int ux0 = m->flipX ? m->nX - 1 - qx0 : qx0, uy0 = m->flipY ? m->nY - 1 - qy0 : qy0;
-            const unsigned c0 = (unsigned)__mul24(ux0, (int)sxb), r0 = (unsigned)__mul24(uy0, (int)syb);
+            const unsigned c0 = (unsigned)__mul24(ux0, (int)sxb), r0 = (unsigned)__mul24(uy0, (int)syb) - rebase;
             // the second source pixel, where the window reaches it, is one step along the (possibly flipped) axis (never fetched from
             // outside the image)
             const unsigned c1 = splitX < WIN ? (m->flipX ? c0 - sxb : c0 + sxb) : c0, r1 = splitY < WIN ? (m->flipY ? r0 - syb : r0 + syb) : r0;
@@ -211,7 +215,7 @@ struct QuadSrc {
             }
         }
 #pragma unroll
-        for (int i = 0; i < WIN; ++i) { colOff[i] *= sxb; rowOff[i] *= syb; }
+        for (int i = 0; i < WIN; ++i) { colOff[i] *= sxb; rowOff[i] = rowOff[i] * syb - rebase; }
         // Without replication one axis of the window is contiguous in memory (virtual X along source x in quadrants 0 / 2,
         // virtual Y in 1 / 3): fetch each of its WIN lines with one or two vector loads instead of WIN scalar ones -- lanes
         // are L source pixels apart, so every load instruction touches a dozen cache lines and their NUMBER is what the

@@ -180,6 +180,28 @@ __global__ __launch_bounds__(kQuadBlock, cell_min_waves(WIN)) __attribute__((amd
     const CellColumn col = cell_column(r, z, min(x0 + lane, r.dW));          // (cell_walk: lanes beyond column dW repeat it)
     int liveLo, liveHi;
     cell_live_rows(live, x0, x0 + 63, liveLo, liveHi);         // wave-uniform
+    // Images of 4 GiB and more (QuadMap::rebaseWaves): this wave's base pointer moves to the first source row its cells can touch -- the
+    // zone centres are affine in the cell, so the extremes along the strided axis sit at the wave's corner cells (first / last lane, first
+    // / last cell row); +- WIN + 2 lattice points for the windows; clamped onto the lattice like the positions themselves
+    uint32_t rebase = 0;
+    if (m.rebaseWaves) {
+        const bool rowsAlongX = m.strideX > m.strideY;         // the window axis that walks the source rows
+        int Zx, Zy;
+        double dfx, dfy;
+        cell_anchor<true>(r, col, y0, Zx, Zy, dfx, dfy);
+        const int a0 = rowsAlongX ? Zx : Zy;
+        cell_anchor<true>(r, col, y1, Zx, Zy, dfx, dfy);
+        const int a1 = rowsAlongX ? Zx : Zy;
+        const int lo = min(a0, a1), hi = max(a0, a1);
+        const int mN = rowsAlongX ? r.mW : r.mH, nS = rowsAlongX ? m.nX : m.nY;
+        const int wlo = min(__builtin_amdgcn_readlane(lo, 0), __builtin_amdgcn_readlane(lo, 63)) - (WIN + 2);
+        const int whi = max(__builtin_amdgcn_readlane(hi, 0), __builtin_amdgcn_readlane(hi, 63)) + (WIN + 2);
+        const int clo = min(max(wlo, 0), mN - 1) / m.scale, chi = min(max(whi, 0), mN - 1) / m.scale;          // source rows (replication)
+        const int first = (rowsAlongX ? m.flipX : m.flipY) ? nS - 1 - chi : clo;
+        const int64_t bytes = (int64_t)first * (rowsAlongX ? m.strideX : m.strideY) * (int64_t)sizeof(T);
+        img += bytes;
+        rebase = (uint32_t)bytes;
+    }
     // per-pixel masks only where a 16 x 16 tile this segment touches holds a flagged pixel (QuadMap::tileFlags; wave-uniform, scalar loads)
     const unsigned long long *masks = skipMasks;
     if (masks && m.tileFlags) {
@@ -197,7 +219,7 @@ __global__ __launch_bounds__(kQuadBlock, cell_min_waves(WIN)) __attribute__((amd
             double dfx, dfy;
             cell_anchor<true>(r, col, cy, Zx, Zy, dfx, dfy);
             QuadSrc<T, WIN, SCALED, true> s;
-            s.img = img; s.m = &m; s.mW = r.mW; s.mH = r.mH; s.lds = window; s.tid = tid;
+            s.img = img; s.m = &m; s.mW = r.mW; s.mH = r.mH; s.lds = window; s.tid = tid; s.rebase = rebase;
             // (the workgroup's bottom cell row only feeds its last pixel row: its interior / left-edge zones are skipped)
             cell_eval<float, WIN, false, HP>(q, z, Zx, Zy, dfx, dfy, r.mW, r.mH, s, sA, sVA, upOnly);
             return false;
@@ -369,7 +391,12 @@ bool cell_can_serve(const RotLaunch &r, int srcType, ImageView sv)
     // (AAI_POLICY_PREFER_CELL asks for the cell kernel all the same)
     if (!r.preferCell && (int64_t)((r.dW + 62) / 63) * ((r.dH + 7) / 8) < 1024) return false;
     const int64_t esz = srcType == SRC_U8 ? 1 : srcType == SRC_U16 ? 2 : 4;
-    return (int64_t)r.H * sv.rowStride * esz < ((int64_t)1 << 32);
+    if ((int64_t)r.H * sv.rowStride * esz < ((int64_t)1 << 32)) return true;
+    // 4 GiB and more: every wave rebases its offsets on its own first source row (aai_cell_kernel, QuadMap::rebaseWaves); the rows one
+    // wave can touch -- 64 cell columns and up to 33 cell rows of `side` lattice points each, plus its windows -- must span less than
+    // 4 GiB, and the 24-bit multiplies of the window addresses need a pitch below 8 MiB
+    const int64_t span = (int64_t)((97.0 * r.side + 24.0) / (r.scale > 0 ? r.scale : 1)) + 2;
+    return sv.rowStride * esz < ((int64_t)1 << 23) && span * sv.rowStride * esz < ((int64_t)1 << 32);
 }
 
 hipError_t launch_cell(const RotLaunch &r, const QuadMap &map, const void *src, int srcType, ImageView sv, float *dst, ImageView dv,
@@ -378,6 +405,10 @@ hipError_t launch_cell(const RotLaunch &r, const QuadMap &map, const void *src, 
     if (r.dW <= 0 || r.dyEnd <= r.dyBase || batch <= 0) return hipSuccess;
     QuadMap m = map;
     m.anchorRows = 0;
+    {
+        const int64_t esz = srcType == SRC_U8 ? 1 : srcType == SRC_U16 ? 2 : 4;
+        m.rebaseWaves = (int64_t)r.H * sv.rowStride * esz >= ((int64_t)1 << 32) ? 1 : 0;
+    }
     switch (srcType) {
     case SRC_U8: return launch_cell_u8(r, m, static_cast<const unsigned char *>(src), sv, dst, dv, batch, skipMasks, stream);
     case SRC_U16: return launch_cell_u16(r, m, static_cast<const unsigned short *>(src), sv, dst, dv, batch, skipMasks, stream);

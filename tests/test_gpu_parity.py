@@ -1265,7 +1265,8 @@ def test_sources_larger_than_4_gib(gpu, po):
     """A 33,000 x 33,000 fp32 source (4.36 GB: byte offsets from the image's first element no longer fit 32 bits) and, for
     K1, a 46,500 x 46,500 one (8.6 GB, 2.16 G elements: past 32-bit element offsets too): K1 streams them, the fp32
     window kernels of the rotated requests (one window per dst pixel, or a window in parts for wide footprints) take their 32-bit
-    lane offsets from an anchor row per wave (QuadMap::anchorRows), in every quadrant.  Sampled row bands against the CPU oracle's rows."""
+    lane offsets from an anchor row per wave (QuadMap::anchorRows) and the cell kernel rebases every wave on its own first source row
+    (QuadMap::rebaseWaves), in every quadrant.  Sampled row bands against the CPU oracle's rows."""
     import torch
     st = torch.cuda.current_stream().cuda_stream
     for (W, H, cases) in ((33000, 33000, ((4.0, 1.0, 0.0, 1, po.MODE_EXACT), (3.0, 1.0, 17.5, 1, po.MODE_EXACT), (3.0, 1.0, 17.5, 2, po.MODE_FAST),
@@ -1283,7 +1284,10 @@ def test_sources_larger_than_4_gib(gpu, po):
             rc, msg, lay = gpu.query(rq)
             assert rc == 0, msg
             out = _device_run(gpu, rq, src)
-            assert any(t in gpu.last_kernel() for t in ("quad", "wide")) == (ang % 90.0 != 0.0), gpu.last_kernel()
+            assert any(t in gpu.last_kernel() for t in ("quad", "wide", "cell")) == (ang % 90.0 != 0.0), gpu.last_kernel()
+            # (plain area requests at 3:1: the cell kernel, every wave with its offsets rebased on its own first source row)
+            if mode == 1 and sr == 3.0:
+                assert "cell" in gpu.last_kernel(), gpu.last_kernel()
             dH, dW = lay.dst_height, lay.dst_width
             for r0 in (0, dH // 3, dH // 2, dH - 8):
                 gold = po.oracle_rows(omode, host, sr, dr, iso, ang, r0, r0 + 8, dW)
