@@ -39,7 +39,18 @@
 
 #include "aai_rot_quad.hpp"
 
+// The shape of the kernel's wave: 1 = 64 consecutive cell columns of ONE cell row per step (63 dst columns a strip); 2 = 32 cell columns
+// of TWO consecutive cell rows (31 dst columns a strip, the upper half-wave a row below the lower one): the two rows' windows share half
+// of their source lines, which one load instruction then fetches once (cell_walk2, aai_rotated_cell.hip)
+#ifndef AAI_CELL_WAVE_ROWS
+#define AAI_CELL_WAVE_ROWS 2
+#endif
+
 namespace aai {
+
+constexpr int kCellWaveRows = AAI_CELL_WAVE_ROWS;
+constexpr int kCellLanes = 64 / kCellWaveRows;            // cell columns a wave evaluates per cell row
+constexpr int kCellCols = kCellLanes - 1;                 // dst columns it completes (the last cell column only feeds its left neighbour)
 
 enum CellTarget { CELL_O = 0, CELL_W = 1, CELL_N = 2, CELL_NW = 3 };     // own dst pixel (x, y); (x-1, y); (x, y-1); (x-1, y-1)
 

@@ -46,13 +46,13 @@ static int cell_rows_per_wave(int dW, int rows, int batch, double srcRowsPerDstR
 {
     const char *e = experiment_env("AAI_CELL_ROWS");
     if (e && atoi(e) > 0) return atoi(e);
-    const int64_t strips = ((int64_t)dW + 62) / 63 * batch;
+    const int64_t strips = ((int64_t)dW + kCellCols - 1) / kCellCols * batch;
     const double want = 14.0 / (srcRowsPerDstRow > 0.05 ? srcRowsPerDstRow : 0.05);
     // (the nearest power of two, except that ratios from ~1.9:1 up keep 4: since the classification by intervals the kernel waits for
     // memory sooner -- 2:1 at 45 degrees, 4 images per launch: 229 / 254 / 372 us per image at 4 / 8 / 16 rows; config 3 at 8 images per
     // launch: 163 / 194 us at 4 / 8 -- profiles/r04_cell_kernel.txt)
     int R = want < 7.4 ? 4 : (want < 11.4 ? 8 : (want < 22.7 ? 16 : 32));
-    while (R > 4 && strips * ((rows + R - 1) / R) < 24576) R >>= 1;
+    while (R > 4 && strips * ((rows + R - 1) / R) < 24576 * kCellWaveRows) R >>= 1;
     while ((rows + 4 * R - 1) / (4 * R) > 65535) R <<= 1;       // grid.y
     return R;
 }
@@ -81,6 +81,11 @@ constexpr int kCellWaves = kQuadBlock / 64;          // waves of a workgroup: co
 
 // What the waves of a workgroup hand to the wave above them: the N / NW parts of their first cell row (which finish the last
 // dst row of the segment above), [wave][A, VA, uncertain][lane]
+#if AAI_CELL_WAVE_ROWS == 2
+#define AAI_CELL_WALK cell_walk2
+#else
+#define AAI_CELL_WALK cell_walk
+#endif
 struct CellHandoff { float a[kCellWaves][64], va[kCellWaves][64]; int u[kCellWaves][64]; };
 
 // The walk both kernels share.  A workgroup owns 63 dst columns x (kCellWaves x rowsPerWave) dst rows; wave w walks DOWN the
@@ -142,6 +147,73 @@ __device__ __forceinline__ void cell_walk(int dW, int x0, int y0, int y1, bool o
     }
 }
 
+// The same walk with a wave of 32 cell columns x 2 cell rows: lanes 0-31 evaluate cell row c, lanes 32-63 cell row c + 1 of the same 32
+// columns, c = y0, y0 + 2, ... y1.  Every lane finishes the dst pixel ABOVE its cell, (cx, cy - 1) = the own + W parts of cell row cy - 1
+// (held by the other half-wave: one exchange across the halves per step serves both directions -- the upper half uses the lower half's
+// sums of THIS step, the lower half keeps the upper half's for the NEXT one) + the N + NW parts of its own cell.  Cell row y1 comes
+// from the wave below (its first row's parts, parked in LDS before the workgroup's one barrier) unless this wave owns the bottom row.
+// Per-cell arithmetic, the order of the additions and therefore every result are those of cell_walk.
+template <typename Look, typename Eval, typename Emit>
+__device__ __forceinline__ void cell_walk2(int dW, int x0, int y0, int y1, bool ownsBottom, int wave, CellHandoff &hand, int liveLo, int liveHi, int lane,
+                                           Look look, Eval eval, Emit emit)
+{
+    const int half = lane >> 5, hl = lane & 31;
+    const int cx = x0 + hl;
+    const bool column = hl < 31 && cx < dW;                     // this lane's column is one the wave completes
+    const int last = ownsBottom ? y1 : y1 - 1;                  // last cell row this wave evaluates itself
+    const bool active = y0 < y1;
+    const int other = (lane ^ 32) << 2;                          // ds_bpermute address of the same column in the other half-wave
+    float keptA = 0.f, keptVA = 0.f;                             // lower half: own + W of cell row c - 1, handed down by the upper half a step ago
+    int keptU = 0;
+    bool prevDead = false;                                       // wave-uniform: the previous step's two cell rows cannot touch the image (cell_live_rows)
+    for (int c = y0;; c += 2) {
+        const bool first = c == y0;
+        const int cy = c + half;
+        const int py = cy - 1;                                   // the dst row this lane finishes in this step
+        const bool emits = column && py >= y0 && py < y1;
+        decltype(look(cx, cy, false)) seen = {};
+        if (active) seen = look(cx, py, emits);
+        float ownA = 0.f, ownVA = 0.f, belowA = 0.f, belowVA = 0.f;
+        int rowU = 0;
+        // (wave-uniform: neither cell row of this step is one the wave evaluates, or both miss the image -- cell_live_rows)
+        const bool dead = c > liveHi || c + 1 < liveLo;
+        const bool live = active && c <= last && !dead;
+        if (live) {
+            float sA[4], sVA[4];
+            // (lanes beyond cell column dW, or whose row is not the wave's to evaluate, repeat a cell of the wave instead of sitting out:
+            // nobody reads their sums, and the wave has no divergent branch around the cell)
+            const bool mine = cy <= last;
+            const int unc = eval(cx < dW ? cx : dW, mine ? cy : last, sA, sVA, cy == y1) ? 1 : 0;
+            ownA = sA[CELL_O] + from_next_lane(sA[CELL_W]); ownVA = sVA[CELL_O] + from_next_lane(sVA[CELL_W]);
+            belowA = sA[CELL_N] + from_next_lane(sA[CELL_NW]); belowVA = sVA[CELL_N] + from_next_lane(sVA[CELL_NW]);
+            rowU = unc | from_next_lane(unc);
+            if (!mine) { ownA = 0.f; ownVA = 0.f; belowA = 0.f; belowVA = 0.f; rowU = 0; }
+        }
+        if (first) {
+            if (active && half == 0) { hand.a[wave][hl] = belowA; hand.va[wave][hl] = belowVA; hand.u[wave][hl] = rowU; }
+            __syncthreads();
+            if (!active) break;
+        }
+        // cell row y1 of a wave that does not own the bottom row: the parts the wave below parked (after the barrier, also in the first step)
+        if (cy == y1 && !ownsBottom) { belowA = hand.a[wave + 1][hl]; belowVA = hand.va[wave + 1][hl]; rowU = hand.u[wave + 1][hl]; }
+        // own + W of the other half-wave's cell row: the upper half needs the lower half's of THIS step, the lower half keeps the upper
+        // half's for the next step
+        const float swapA = __int_as_float(__builtin_amdgcn_ds_bpermute(other, __float_as_int(ownA)));
+        const float swapVA = __int_as_float(__builtin_amdgcn_ds_bpermute(other, __float_as_int(ownVA)));
+        const int swapU = __builtin_amdgcn_ds_bpermute(other, rowU);
+        if (emits) {
+            const float aboveA = half ? swapA : keptA, aboveVA = half ? swapVA : keptVA;
+            const int aboveU = half ? swapU : keptU;
+            // (a pixel row between cell rows that all miss the image -- the corners of a rotated canvas -- has no area: its zeros go
+            // out without the sums and the division; the knife scan may still have listed such a pixel)
+            if (dead && prevDead) emit(cx, py, 0.f, 0.f, 0, seen);
+            else emit(cx, py, aboveA + belowA, aboveVA + belowVA, aboveU | rowU, seen);
+        }
+        keptA = swapA; keptVA = swapVA; keptU = swapU; prevDead = dead;
+        if (c + 2 > y1) break;
+    }
+}
+
 // dst rows [y0, y1) of wave `wave` of the workgroup whose rows start at blockY0 and end before blockY1; ownsBottom: no wave below
 // it in the workgroup has rows
 __device__ __forceinline__ void cell_segment(int blockY0, int blockY1, int rowsPerWave, int wave, int &y0, int &y1, bool &ownsBottom)
@@ -166,7 +238,7 @@ __global__ __launch_bounds__(kQuadBlock, cell_min_waves(WIN)) __attribute__((amd
     // source lines neighbouring strips share are fetched through one L2
     xcd_tile(xcdRows, bx, by);
     if (by >= rowBlocks) return;                               // (block-uniform; rows the padded grid adds)
-    const int x0 = bx * 63;                                    // (block-uniform: every wave reaches the walk's barrier)
+    const int x0 = bx * kCellCols;                             // (block-uniform: every wave reaches the walk's barrier)
     // the last workgroups of a launch are shorter (tailRows rows per wave instead of rowsPerWave): the waves that finish it live a
     // fraction as long, and the chip drains in a fraction of the time
     const int rpw = by < bigBlocks ? rowsPerWave : tailRows;
@@ -177,9 +249,9 @@ __global__ __launch_bounds__(kQuadBlock, cell_min_waves(WIN)) __attribute__((amd
     cell_segment(blockY0, blockY1, rpw, wave, y0, y1, ownsBottom);           // dst rows [y0, y1); cell rows y0 .. y1
     float *image = dst + (int64_t)blockIdx.z * dv.imageStride;
     const char *img = reinterpret_cast<const char *>(src + (int64_t)blockIdx.z * sv.imageStride + m.base);
-    const CellColumn col = cell_column(r, z, min(x0 + lane, r.dW));          // (cell_walk: lanes beyond column dW repeat it)
+    const CellColumn col = cell_column(r, z, min(x0 + (lane & (kCellLanes - 1)), r.dW));      // (cell_walk: lanes beyond column dW repeat it)
     int liveLo, liveHi;
-    cell_live_rows(live, x0, x0 + 63, liveLo, liveHi);         // wave-uniform
+    cell_live_rows(live, x0, x0 + kCellCols, liveLo, liveHi);  // wave-uniform
     // Images of 4 GiB and more (QuadMap::rebaseWaves): this wave's base pointer moves to the first source row its cells can touch -- the
     // zone centres are affine in the cell, so the extremes along the strided axis sit at the wave's corner cells (first / last lane, first
     // / last cell row); +- WIN + 2 lattice points for the windows; clamped onto the lattice like the positions themselves
@@ -194,8 +266,8 @@ __global__ __launch_bounds__(kQuadBlock, cell_min_waves(WIN)) __attribute__((amd
         const int a1 = rowsAlongX ? Zx : Zy;
         const int lo = min(a0, a1), hi = max(a0, a1);
         const int mN = rowsAlongX ? r.mW : r.mH, nS = rowsAlongX ? m.nX : m.nY;
-        const int wlo = min(__builtin_amdgcn_readlane(lo, 0), __builtin_amdgcn_readlane(lo, 63)) - (WIN + 2);
-        const int whi = max(__builtin_amdgcn_readlane(hi, 0), __builtin_amdgcn_readlane(hi, 63)) + (WIN + 2);
+        const int wlo = min(__builtin_amdgcn_readlane(lo, 0), __builtin_amdgcn_readlane(lo, kCellLanes - 1)) - (WIN + 2);
+        const int whi = max(__builtin_amdgcn_readlane(hi, 0), __builtin_amdgcn_readlane(hi, kCellLanes - 1)) + (WIN + 2);
         const int clo = min(max(wlo, 0), mN - 1) / m.scale, chi = min(max(whi, 0), mN - 1) / m.scale;          // source rows (replication)
         const int first = (rowsAlongX ? m.flipX : m.flipY) ? nS - 1 - chi : clo;
         const int64_t bytes = (int64_t)first * (rowsAlongX ? m.strideX : m.strideY) * (int64_t)sizeof(T);
@@ -206,10 +278,10 @@ __global__ __launch_bounds__(kQuadBlock, cell_min_waves(WIN)) __attribute__((amd
     const unsigned long long *masks = skipMasks;
     if (masks && m.tileFlags) {
         bool any = false;
-        for (int tr = y0 >> 4; tr <= (y1 - 1) >> 4; ++tr) any = any || tiles_flagged(m.tileFlags, m.tileFlagWords, tr, x0 >> 4, 5);
+        for (int tr = y0 >> 4; tr <= (y1 - 1) >> 4; ++tr) any = any || tiles_flagged(m.tileFlags, m.tileFlagWords, tr, x0 >> 4, kCellCols / 16 + 2);
         if (!any) masks = nullptr;
     }
-    cell_walk(r.dW, x0, y0, y1, ownsBottom, wave, hand, liveLo, liveHi, lane,
+    AAI_CELL_WALK(r.dW, x0, y0, y1, ownsBottom, wave, hand, liveLo, liveHi, lane,
         [&](int px, int py, bool wanted) -> bool {
             // is the pixel one the plan's scans left to the fix-up pass?  (requested here, used after the cell is evaluated)
             return masks && wanted && ((masks[flag_word(px, py, tilesX)] >> flag_bit(px, py)) & 1ull);
@@ -242,16 +314,16 @@ __global__ __launch_bounds__(kQuadBlock) void aai_cell_scan_kernel(RotLaunch r, 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int x0 = blockIdx.x * 63;
+    const int x0 = blockIdx.x * kCellCols;
     const int blockY0 = (band0 + blockIdx.y) * (kCellWaves * rowsPerWave);
     const int blockY1 = min(blockY0 + kCellWaves * rowsPerWave, r.dH);
     int y0, y1;
     bool ownsBottom;
     cell_segment(blockY0, blockY1, rowsPerWave, wave, y0, y1, ownsBottom);
-    const CellColumn col = cell_column(r, z, min(x0 + lane, r.dW));
+    const CellColumn col = cell_column(r, z, min(x0 + (lane & (kCellLanes - 1)), r.dW));
     int liveLo, liveHi;
-    cell_live_rows(live, x0, x0 + 63, liveLo, liveHi);
-    cell_walk(r.dW, x0, y0, y1, ownsBottom, wave, hand, liveLo, liveHi, lane,
+    cell_live_rows(live, x0, x0 + kCellCols, liveLo, liveHi);
+    AAI_CELL_WALK(r.dW, x0, y0, y1, ownsBottom, wave, hand, liveLo, liveHi, lane,
         [&](int, int, bool) -> int { return 0; },
         [&](int cx, int cy, float (&sA)[4], float (&sVA)[4], bool) -> bool {
             int Zx, Zy;
@@ -280,7 +352,7 @@ hipError_t launch_cell_tile(const RotLaunch &r, const QuadConsts<float> &q, cons
 {
     const int rows = r.dyEnd - r.dyBase;
     const int rowsPerWave = cell_rows_per_wave(r.dW, rows, batch, r.side / (m.scale > 0 ? m.scale : 1));
-    const int strips = (r.dW + 62) / 63;
+    const int strips = (r.dW + kCellCols - 1) / kCellCols;
     const int blockRows = kCellWaves * rowsPerWave;
     // (Shorter segments for the last rows of a launch -- waves that live half as long, so that the chip drains sooner -- paid with
     // 8-row strips per wave; with four waves per strip segment they measure nothing: config 3 160.7 us without, 161.0 ... 166.3 with.
@@ -389,7 +461,7 @@ bool cell_can_serve(const RotLaunch &r, int srcType, ImageView sv)
     // waves (about 720 x 720 dst pixels) cannot fill the chip with them -- the reference's own example call (158 x 158 dst
     // pixels at 5.9 : 1) takes 71 us on 60 cell waves and 36 us on 390 one-shot quad waves.
     // (AAI_POLICY_PREFER_CELL asks for the cell kernel all the same)
-    if (!r.preferCell && (int64_t)((r.dW + 62) / 63) * ((r.dH + 7) / 8) < 1024) return false;
+    if (!r.preferCell && (int64_t)((r.dW + 62) / 63) * ((r.dH + 7) / 8) < 1024) return false;      // (in waves of 63 columns x 8 rows, whatever the wave's shape)
     const int64_t esz = srcType == SRC_U8 ? 1 : srcType == SRC_U16 ? 2 : 4;
     if ((int64_t)r.H * sv.rowStride * esz < ((int64_t)1 << 32)) return true;
     // 4 GiB and more: every wave rebases its offsets on its own first source row (aai_cell_kernel, QuadMap::rebaseWaves); the rows one
@@ -425,7 +497,7 @@ hipError_t launch_cell_scan(const RotLaunch &r, unsigned long long *laneMasks, u
     const CellConsts<float> z = make_cell_consts<float>(r.side, r.c, r.s);
     const CellLive live = make_cell_live(r, z);
     const int rows = 4;                                        // per wave: workgroups of 16 dst rows
-    const int strips = (r.dW + 62) / 63;
+    const int strips = (r.dW + kCellCols - 1) / kCellCols;
     const int tilesX = (r.dW + 15) / 16;
     const int bands = (r.dH + kCellWaves * rows - 1) / (kCellWaves * rows);
     for (int b0 = 0; b0 < bands; b0 += 65535) {                // grid.y carries at most 65535 bands

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Randomised GPU-vs-oracle parity sweep (longer than the test-suite allows): random sizes, ratios, isocenters,
 rotations (generic and structured), modes, policies, source types, batches with padded strides, and row bands.
-usage: python tools/fuzz_parity.py [cases] [seed]"""
+usage: python tools/fuzz_parity.py [cases] [seed]      (FUZZ_MAX=<largest side>, FUZZ_CELL=1: the cell kernel for small outputs too)"""
 import os, sys, math
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -15,6 +15,8 @@ N = int(sys.argv[1]) if len(sys.argv) > 1 else 300
 REPORT = float(os.environ.get("FUZZ_REPORT", "1"))       # print the cases whose error exceeds this (default: none)
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 aai.set_device(0)
+if os.environ.get("FUZZ_CELL", "0") == "1":
+    aai.debug_cell_min_waves(0)       # every plain rotated area request carries AAI_POLICY_PREFER_CELL: the cell kernel on the fuzz's small images too
 st = torch.cuda.current_stream().cuda_stream
 special = [0, 30, 45, 60, 90, 180, 270, math.degrees(math.atan(0.5)), 17.5, 1e-6, 89.999999]
 worst, bad, tail = 0.0, 0, 0
