@@ -41,9 +41,12 @@
 
 // The shape of the kernel's wave: 1 = 64 consecutive cell columns of ONE cell row per step (63 dst columns a strip); 2 = 32 cell columns
 // of TWO consecutive cell rows (31 dst columns a strip, the upper half-wave a row below the lower one): the two rows' windows share half
-// of their source lines, which one load instruction then fetches once (cell_walk2, aai_rotated_cell.hip)
+// of their source lines, which one load instruction then fetches once (cell_walk2, aai_rotated_cell.hip).  Shape 2 is correct (all GPU
+// tests) and was measured against shape 1 on one box (profiles/r04_cell_kernel.txt, 6.): config 3 at 8 images per launch 160.6 -> 148.5
+// us per image, but one image 157.9 -> 173.3, config 5 2627 -> 3041, 2:1 at 45 degrees 228 -> 290, 1:1 at 30 degrees 820 -> 951: shape 1
+// ships, -DAAI_CELL_WAVE_ROWS=2 builds the other.
 #ifndef AAI_CELL_WAVE_ROWS
-#define AAI_CELL_WAVE_ROWS 2
+#define AAI_CELL_WAVE_ROWS 1
 #endif
 
 namespace aai {
