@@ -386,6 +386,29 @@ def config_block(aai, torch, policy, cfg2_cpu, cpu_procs, cpu_pool, with_cpu, cp
                  "ms": round(ms, 5), "launches": n, "mpix_s": round(B * dW * dH / (ms * 1e-3) / 1e6, 1),
                  "gbps": round(alg / (ms * 1e-3) / 1e9, 1), "frac": round(alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
                  "prepare_ms": round(prepare_ms, 2), "plan": compact_shape(aai.plan_shape(rq))}
+        if ms < 0.03:
+            # a launch-bound configuration: the same launches captured ONCE into a HIP graph (the plan exists: a capture records
+            # launches only) and replayed -- what a caller with a fixed pipeline pays per launch
+            try:
+                per = 64
+                g, cs = torch.cuda.CUDAGraph(), torch.cuda.Stream()
+                with torch.cuda.graph(g, stream=cs):
+                    for _ in range(per):
+                        aai.resample_device(rq, src.data_ptr(), W, dst.data_ptr(), dW, torch.cuda.current_stream().cuda_stream, batch=B,
+                                            src_image_stride=W * H, dst_image_stride=dW * dH)
+                reps = max(4, n // per)
+                for _ in range(reps):
+                    g.replay()
+                torch.cuda.synchronize()
+                e0.record()
+                for _ in range(reps):
+                    g.replay()
+                e1.record()
+                torch.cuda.synchronize()
+                entry["graph_ms"] = round(e0.elapsed_time(e1) / (reps * per), 5)
+                del g
+            except Exception as exc:        # (reported, not fatal: the launch figures above stand)
+                entry["graph_ms"] = "failed: %s" % (str(exc)[:60],)
         del src, dst
         torch.cuda.empty_cache()
         if with_cpu and mode in (MODE_AREA, MODE_FAST):
@@ -732,7 +755,7 @@ def worker(args):
             torch.cuda.empty_cache()
             line["configs"] = config_block(aai, torch, policy, line.get("cpu_baseline"), cpu_procs, cpu_pool, not args.no_cpu_baseline, args.cpu_scale)
             line["configs_note"] = ("per BASELINE configuration, kernel-only: ms per launch, output Mpixels/s, algorithmic GB/s and fraction of the 8 TB/s HBM peak, "
-                                    "cold aai_prepare ms; cpu = [Mpixels/s of the unmodified reference on 1 core of this host, output pixels of its sample, seconds]")
+                                    "cold aai_prepare ms, graph_ms = the same launches replayed from a HIP graph (launch-bound configurations only); cpu = [Mpixels/s of the unmodified reference on 1 core of this host, output pixels of its sample, seconds]")
         if cfg4_rank is not None:
             line["cfg4"] = cfg4_rank
         if saved_stdout is not None:
