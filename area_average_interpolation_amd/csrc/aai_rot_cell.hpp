@@ -184,28 +184,45 @@ AAI_HD void cell_vertex_areas(F m1, F im1, F fx, F fy, F (&area)[4])
 // value says whether a decision of this cell is too close to its threshold for fp32.
 // upOnly: only the parts for the dst pixels ABOVE the cell's row are wanted (the extra cell row below a strip): the interior and
 // left-edge zones, which feed this row only, are skipped (the own / W sums are then incomplete and must not be used).
-template <typename F, int WIN, bool SCAN, bool HP, typename Src>
+// NC: interleaved channels share every area: sVA[t * NC + c] = target t, channel c (NC = 1: a plain image; src.at() hands NC values)
+template <typename F, int WIN, bool SCAN, bool HP, int NC = 1, typename Src>
 AAI_HD bool cell_eval(const QuadConsts<F> &q, const CellConsts<F> &z, int Zx, int Zy, double dfx, double dfy, int mW, int mH, Src &src,
-                      F (&sA)[4], F (&sVA)[4], bool upOnly = false)
+                      F (&sA)[4], F (&sVA)[4 * NC], bool upOnly = false)
 {
     typedef typename QuadMask<WIN>::type u64;
     static_assert(WIN >= 1 && WIN <= kQuadMaxWin, "window size");
     const F fpx = (F)dfx, fpy = (F)dfy;
     // (the sums start from the parts of the pixel that holds G, below: no zeroing, no first addition)
-    auto value = [&](int slot) -> F {
-        if (SCAN) return F(1);
-        F vals[1];
-        src.at(slot, vals);
-        return vals[0];
+    struct Vals { F v[NC]; };
+    auto value = [&](int slot) -> Vals {
+        Vals r;
+        if (SCAN) {
+#pragma unroll
+            for (int c = 0; c < NC; ++c) r.v[c] = F(1);
+        } else src.at(slot, r.v);
+        return r;
     };
     // A pixel that does not reach a target contributes area 0 there -- and must then contribute nothing, whatever its value: 0 x NaN
     // would put a source pixel's NaN into a dst pixel it does not overlap.  Only the vertex zone's two-ray pixels have such targets
     // (`add`, behind a vote on the value).  Everywhere else the areas are positive: an interior pixel has area 1; a pixel cut by one
     // grid line gives both sides a positive part and the pixel that holds G four positive wedges unless a zone decision or G sits
     // within the scan's margin of its threshold -- and then the scan has left every dst pixel this cell feeds to the fix-up pass.
-    auto add = [&](int target, F area, F v) { sA[target] += area; sVA[target] = qfma(area, area != F(0) ? v : F(0), sVA[target]); };
-    auto addf = [&](int target, F area, F v) { sA[target] += area; sVA[target] = qfma(area, v, sVA[target]); };
-    auto finite = [&](F v) -> bool { return AAI_WAVE_ALL(qabs(v) <= F(3.0e38)); };
+    auto add = [&](int target, F area, const Vals &v) {
+        sA[target] += area;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) sVA[target * NC + c] = qfma(area, area != F(0) ? v.v[c] : F(0), sVA[target * NC + c]);
+    };
+    auto addf = [&](int target, F area, const Vals &v) {
+        sA[target] += area;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) sVA[target * NC + c] = qfma(area, v.v[c], sVA[target * NC + c]);
+    };
+    auto finite = [&](const Vals &v) -> bool {
+        bool ok = true;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) ok = ok && qabs(v.v[c]) <= F(3.0e38);
+        return AAI_WAVE_ALL(ok);
+    };
 
     // window origin: the first lattice point the zone's bounding box can hold
     const F fi0 = ceil(fpx - z.hbz), fj0 = ceil(fpy - z.hbz);
@@ -322,9 +339,13 @@ AAI_HD bool cell_eval(const QuadConsts<F> &q, const CellConsts<F> &z, int Zx, in
         // G is vertex 0 (left/top) of the cell's own dst pixel, vertex 1 (right/top) of its left neighbour,
         // vertex 2 (left/bottom) of the one above, vertex 3 of the one above left
         const bool inImage = held && (interior || (valid & bit) != 0);
-        const F v = value(slot);
+        const Vals v = value(slot);
 #pragma unroll
-        for (int t = 0; t < 4; ++t) { sA[t] = inImage ? area[t] : F(0); sVA[t] = inImage ? area[t] * v : F(0); }
+        for (int t = 0; t < 4; ++t) {
+            sA[t] = inImage ? area[t] : F(0);
+#pragma unroll
+            for (int c = 0; c < NC; ++c) sVA[t * NC + c] = inImage ? area[t] * v.v[c] : F(0);
+        }
     }
 
     if (upOnly) { mIn = 0; mLeft = 0; }
@@ -348,7 +369,7 @@ AAI_HD bool cell_eval(const QuadConsts<F> &q, const CellConsts<F> &z, int Zx, in
         if (SCAN && q.ref != 0 && qabs(tp - q.lo) < (HP ? q.marginT : q.margin)) uncertain = true;
         F sE, sR;
         cell_cut_small(q, tp, sE, sR);
-        const F v = value(slot);
+        const Vals v = value(slot);
         const F big = F(1) - sR;
         addf(CELL_O, flip ? big : sR, v);                  // flip: the E side holds the larger part
         addf(CELL_W, flip ? sR : big, v);
@@ -364,7 +385,7 @@ AAI_HD bool cell_eval(const QuadConsts<F> &q, const CellConsts<F> &z, int Zx, in
         if (HP) tp = precise_tp(fi0 + (F)i, fj0 + (F)j, false, flip);
         F sS, unused;
         cell_cut_small(q, tp, sS, unused);
-        const F v = value(slot);
+        const Vals v = value(slot);
         const F big = F(1) - sS;
         addf(CELL_O, flip ? big : sS, v);
         addf(CELL_N, flip ? sS : big, v);
@@ -402,7 +423,7 @@ AAI_HD bool cell_eval(const QuadConsts<F> &q, const CellConsts<F> &z, int Zx, in
         // `both` goes to the dst pixel on the (right, down) side of G, loneA across the vertical ray, loneB across the horizontal one
         const F p0 = right ? both : loneA, p1 = right ? loneA : both, q0 = right ? loneB : F(0), q1 = right ? F(0) : loneB;
         const F aO = down ? p0 : q0, aW = down ? p1 : q1, aN = down ? q0 : p0, aNW = down ? q1 : p1;
-        const F v = value(slot);
+        const Vals v = value(slot);
         if (finite(v)) {
             addf(CELL_O, aO, v); addf(CELL_W, aW, v); addf(CELL_N, aN, v); addf(CELL_NW, aNW, v);
         } else {

@@ -467,7 +467,7 @@ static hipError_t launch_rotated_band(const RotLaunch &r, const QuadMap &m, cons
     const bool quad = quad_serves(r, srcType, sv);
     if (cell_serves(r, srcType, sv, flags)) {
         // the cell formulation: one lane per cell of the dst grid, every (dst, src) pair evaluated once
-        if (kernelName) *kernelName = "aai_cell_kernel<area>";
+        if (kernelName) *kernelName = r.chan > 1 ? "aai_cell_multi_kernel<area, channels>" : "aai_cell_kernel<area>";
         return launch_cell(r, m, src, srcType, sv, dst, dv, batch, flags.count ? flags.masks : nullptr, stream);
     }
     if (wide_serves(r, srcType, sv)) {

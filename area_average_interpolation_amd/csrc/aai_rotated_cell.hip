@@ -76,17 +76,20 @@ constexpr int cell_min_waves(int win) { return win <= 4 ? 6 : (cell_waves_per_si
 __device__ __forceinline__ size_t flag_word(int dx, int dy, int tilesX) { return ((size_t)(dy >> 4) * tilesX + (dx >> 4)) * 4 + ((dy & 15) >> 2); }
 __device__ __forceinline__ int flag_bit(int dx, int dy) { return ((dy & 3) << 4) | (dx & 15); }
 
+constexpr int kCellMultiMaxKiB = 64;        // the interleaved kernel's window: WIN * WIN * WORDS KiB of LDS at most
 constexpr int kCellXcdRowsDefault = 2;      // row blocks per XCD band without replication (profiles/r04_fast_xcd.txt)
 constexpr int kCellWaves = kQuadBlock / 64;          // waves of a workgroup: consecutive row segments of ONE strip of 63 dst columns
 
 // What the waves of a workgroup hand to the wave above them: the N / NW parts of their first cell row (which finish the last
 // dst row of the segment above), [wave][A, VA, uncertain][lane]
 #if AAI_CELL_WAVE_ROWS == 2
-#define AAI_CELL_WALK cell_walk2
+#define AAI_CELL_WALK cell_walk2<1>
 #else
-#define AAI_CELL_WALK cell_walk
+#define AAI_CELL_WALK cell_walk<1>
 #endif
-struct CellHandoff { float a[kCellWaves][64], va[kCellWaves][64]; int u[kCellWaves][64]; };
+template <int NC>
+struct CellHandoffN { float a[kCellWaves][64], va[kCellWaves][NC][64]; int u[kCellWaves][64]; };
+typedef CellHandoffN<1> CellHandoff;
 
 // The walk both kernels share.  A workgroup owns 63 dst columns x (kCellWaves x rowsPerWave) dst rows; wave w walks DOWN the
 // dst rows [y0, y1) of its segment: per iteration every lane evaluates one cell (eval(cx, cy, sA, sVA, upOnly) -> this cell is
@@ -99,30 +102,40 @@ struct CellHandoff { float a[kCellWaves][64], va[kCellWaves][64]; int u[kCellWav
 // look(px, py) runs at the top of the iteration that will finish pixel (px, py) and its result is handed to emit: whatever emit
 // needs from memory (the flag word of the pixel) is requested before the cell is evaluated, not waited for after it.
 // Every wave of the workgroup must call this (the barrier), also with an empty segment (y0 >= y1).
-template <typename Look, typename Eval, typename Emit>
-__device__ __forceinline__ void cell_walk(int dW, int x0, int y0, int y1, bool ownsBottom, int wave, CellHandoff &hand, int liveLo, int liveHi, int lane,
+// NC: interleaved channels (every sum of area x value once per channel; sVA[t * NC + c], emit's VA[c])
+template <int NC, typename Look, typename Eval, typename Emit>
+__device__ __forceinline__ void cell_walk(int dW, int x0, int y0, int y1, bool ownsBottom, int wave, CellHandoffN<NC> &hand, int liveLo, int liveHi, int lane,
                                           Look look, Eval eval, Emit emit)
 {
     const int cx = x0 + lane;
     const bool column = lane < 63 && cx < dW;                   // this lane's column is one the wave completes
-    float ownA = 0.f, ownVA = 0.f, belowA = 0.f, belowVA = 0.f;
+    float ownA = 0.f, ownVA[NC], belowA = 0.f, belowVA[NC];
     int rowU = 0;
     // one cell row: own + W of this row (own*), N + NW for the row above (below*)
     bool rowLive = false, aboveLive = false;                     // wave-uniform: this cell row / the one above can touch the image
     auto row = [&](int cy, bool upOnly) {
-        ownA = 0.f; ownVA = 0.f; belowA = 0.f; belowVA = 0.f; rowU = 0;
+        ownA = 0.f; belowA = 0.f; rowU = 0;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) { ownVA[c] = 0.f; belowVA[c] = 0.f; }
         rowLive = !(cy > liveHi || cy < liveLo);
         if (!rowLive) return;                                    // wave-uniform: every cell of this row misses the image
-        float sA[4], sVA[4];
+        float sA[4], sVA[4 * NC];
         // (lanes beyond cell column dW -- the last strip's -- evaluate that column once more instead of sitting out: nobody reads their
         // sums, and the wave has no divergent branch around the cell)
         const int unc = eval(cx < dW ? cx : dW, cy, sA, sVA, upOnly) ? 1 : 0;
-        ownA = sA[CELL_O] + from_next_lane(sA[CELL_W]); ownVA = sVA[CELL_O] + from_next_lane(sVA[CELL_W]);
-        belowA = sA[CELL_N] + from_next_lane(sA[CELL_NW]); belowVA = sVA[CELL_N] + from_next_lane(sVA[CELL_NW]);
+        ownA = sA[CELL_O] + from_next_lane(sA[CELL_W]);
+        belowA = sA[CELL_N] + from_next_lane(sA[CELL_NW]);
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            ownVA[c] = sVA[CELL_O * NC + c] + from_next_lane(sVA[CELL_W * NC + c]);
+            belowVA[c] = sVA[CELL_N * NC + c] + from_next_lane(sVA[CELL_NW * NC + c]);
+        }
         rowU = unc | from_next_lane(unc);                        // the two cells of this row that feed column cx
     };
     const bool active = y0 < y1;
-    float carryA = 0.f, carryVA = 0.f;                           // own + W of the row above, waiting for this row's N / NW parts
+    float carryA = 0.f, carryVA[NC];                             // own + W of the row above, waiting for this row's N / NW parts
+#pragma unroll
+    for (int c = 0; c < NC; ++c) { carryVA[c] = 0.f; ownVA[c] = 0.f; belowVA[c] = 0.f; }
     int carryU = 0;
     // ONE loop over the cell rows y0 .. y1 (one copy of the cell evaluation in the code): the first iteration parks its N / NW parts
     // and meets the other waves at the barrier, the last one takes them from the wave below unless this wave owns the bottom row
@@ -131,19 +144,35 @@ __device__ __forceinline__ void cell_walk(int dW, int x0, int y0, int y1, bool o
         decltype(look(cx, cy, false)) seen = {};
         if (!first) seen = look(cx, cy - 1, column);
         if (active && (!last || ownsBottom)) row(cy, last);
-        else if (active) { belowA = hand.a[wave + 1][lane]; belowVA = hand.va[wave + 1][lane]; rowU = hand.u[wave + 1][lane]; rowLive = true; }
+        else if (active) {
+            belowA = hand.a[wave + 1][lane]; rowU = hand.u[wave + 1][lane]; rowLive = true;
+#pragma unroll
+            for (int c = 0; c < NC; ++c) belowVA[c] = hand.va[wave + 1][c][lane];
+        }
         if (first) {
-            if (active) { hand.a[wave][lane] = belowA; hand.va[wave][lane] = belowVA; hand.u[wave][lane] = rowU; }
+            if (active) {
+                hand.a[wave][lane] = belowA; hand.u[wave][lane] = rowU;
+#pragma unroll
+                for (int c = 0; c < NC; ++c) hand.va[wave][c][lane] = belowVA[c];
+            }
             __syncthreads();
             if (!active) break;
         } else if (column) {
             // (a pixel row between two cell rows that miss the image -- the corners of a rotated canvas, half of config 5's rows --
             // has no area: its zeros go out without the sums and the division; the knife scan may still have listed such a pixel)
-            if (!rowLive && !aboveLive) emit(cx, cy - 1, 0.f, 0.f, 0, seen);
-            else emit(cx, cy - 1, carryA + belowA, carryVA + belowVA, carryU | rowU, seen);
+            float VA[NC];
+#pragma unroll
+            for (int c = 0; c < NC; ++c) VA[c] = carryVA[c] + belowVA[c];
+            if (!rowLive && !aboveLive) {
+#pragma unroll
+                for (int c = 0; c < NC; ++c) VA[c] = 0.f;
+                emit(cx, cy - 1, 0.f, VA, 0, seen);
+            } else emit(cx, cy - 1, carryA + belowA, VA, carryU | rowU, seen);
         }
         if (last) break;
-        carryA = ownA; carryVA = ownVA; carryU = rowU; aboveLive = rowLive;
+        carryA = ownA; carryU = rowU; aboveLive = rowLive;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) carryVA[c] = ownVA[c];
     }
 }
 
@@ -153,10 +182,11 @@ __device__ __forceinline__ void cell_walk(int dW, int x0, int y0, int y1, bool o
 // sums of THIS step, the lower half keeps the upper half's for the NEXT one) + the N + NW parts of its own cell.  Cell row y1 comes
 // from the wave below (its first row's parts, parked in LDS before the workgroup's one barrier) unless this wave owns the bottom row.
 // Per-cell arithmetic, the order of the additions and therefore every result are those of cell_walk.
-template <typename Look, typename Eval, typename Emit>
-__device__ __forceinline__ void cell_walk2(int dW, int x0, int y0, int y1, bool ownsBottom, int wave, CellHandoff &hand, int liveLo, int liveHi, int lane,
+template <int NC, typename Look, typename Eval, typename Emit>
+__device__ __forceinline__ void cell_walk2(int dW, int x0, int y0, int y1, bool ownsBottom, int wave, CellHandoffN<NC> &hand, int liveLo, int liveHi, int lane,
                                            Look look, Eval eval, Emit emit)
 {
+    static_assert(NC == 1, "the two-row wave serves plain images");
     const int half = lane >> 5, hl = lane & 31;
     const int cx = x0 + hl;
     const bool column = hl < 31 && cx < dW;                     // this lane's column is one the wave completes
@@ -190,12 +220,12 @@ __device__ __forceinline__ void cell_walk2(int dW, int x0, int y0, int y1, bool 
             if (!mine) { ownA = 0.f; ownVA = 0.f; belowA = 0.f; belowVA = 0.f; rowU = 0; }
         }
         if (first) {
-            if (active && half == 0) { hand.a[wave][hl] = belowA; hand.va[wave][hl] = belowVA; hand.u[wave][hl] = rowU; }
+            if (active && half == 0) { hand.a[wave][hl] = belowA; hand.va[wave][0][hl] = belowVA; hand.u[wave][hl] = rowU; }
             __syncthreads();
             if (!active) break;
         }
         // cell row y1 of a wave that does not own the bottom row: the parts the wave below parked (after the barrier, also in the first step)
-        if (cy == y1 && !ownsBottom) { belowA = hand.a[wave + 1][hl]; belowVA = hand.va[wave + 1][hl]; rowU = hand.u[wave + 1][hl]; }
+        if (cy == y1 && !ownsBottom) { belowA = hand.a[wave + 1][hl]; belowVA = hand.va[wave + 1][0][hl]; rowU = hand.u[wave + 1][hl]; }
         // own + W of the other half-wave's cell row: the upper half needs the lower half's of THIS step, the lower half keeps the upper
         // half's for the next step
         const float swapA = __int_as_float(__builtin_amdgcn_ds_bpermute(other, __float_as_int(ownA)));
@@ -206,8 +236,9 @@ __device__ __forceinline__ void cell_walk2(int dW, int x0, int y0, int y1, bool 
             const int aboveU = half ? swapU : keptU;
             // (a pixel row between cell rows that all miss the image -- the corners of a rotated canvas -- has no area: its zeros go
             // out without the sums and the division; the knife scan may still have listed such a pixel)
-            if (dead && prevDead) emit(cx, py, 0.f, 0.f, 0, seen);
-            else emit(cx, py, aboveA + belowA, aboveVA + belowVA, aboveU | rowU, seen);
+            const float zero[1] = {0.f}, total[1] = {aboveVA + belowVA};
+            if (dead && prevDead) emit(cx, py, 0.f, zero, 0, seen);
+            else emit(cx, py, aboveA + belowA, total, aboveU | rowU, seen);
         }
         keptA = swapA; keptVA = swapVA; keptU = swapU; prevDead = dead;
         if (c + 2 > y1) break;
@@ -296,10 +327,71 @@ __global__ __launch_bounds__(kQuadBlock, cell_min_waves(WIN)) __attribute__((amd
             cell_eval<float, WIN, false, HP>(q, z, Zx, Zy, dfx, dfy, r.mW, r.mH, s, sA, sVA, upOnly);
             return false;
         },
-        [&](int px, int py, float A, float VA, int, bool skip) {
+        [&](int px, int py, float A, const float (&VA)[1], int, bool skip) {
             if (skip) return;                                  // a pixel the plan's scans left to the fix-up pass is not written here
             // (written once, never read back: around the caches -- 1 % at configs 3 and 5)
-            __builtin_nontemporal_store(A > 0.f ? VA / A : 0.f, image + ((int64_t)(py - r.dyBase) * dv.rowStride + px));         // Source.cpp:577
+            __builtin_nontemporal_store(A > 0.f ? VA[0] / A : 0.f, image + ((int64_t)(py - r.dyBase) * dv.rowStride + px));         // Source.cpp:577
+        });
+}
+
+// Interleaved channels (2 .. 4 per pixel): the same walk with one sum of area x value per channel -- the areas of a (dst, src) pair are
+// computed once and applied to every channel -- over QuadSrcMulti's window, whose slots hold all channels of their pixel as WORDS raw
+// words (8-bit RGB(A): one word, like a plain image).  Wherever cell_can_serve says no, interleaved requests keep aai_quad_multi_kernel;
+// no rebasing (below 4 GiB).  Dynamic LDS: WIN * WIN * WORDS KiB.
+constexpr int cell_multi_min_waves(int win, int words)
+{
+    return 160 / (win * win * words + 7) >= 6 ? 6 : (160 / (win * win * words + 7) >= 1 ? 160 / (win * win * words + 7) : 1);
+}
+template <typename T, int WIN, bool SCALED, bool HP, int WORDS>
+__global__ __launch_bounds__(kQuadBlock, cell_multi_min_waves(WIN, WORDS)) void aai_cell_multi_kernel(
+    RotLaunch r, QuadConsts<float> q, CellConsts<float> z, CellLive live, QuadMap m, const T *__restrict__ src, ImageView sv, float *__restrict__ dst, ImageView dv,
+    const unsigned long long *__restrict__ skipMasks, int tilesX, int rowsPerWave, int xcdRows, int rowBlocks)
+{
+    extern __shared__ unsigned windowWords[];
+    __shared__ CellHandoffN<kQuadMaxChan> hand;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int bx = blockIdx.x, by = blockIdx.y;
+    xcd_tile(xcdRows, bx, by);
+    if (by >= rowBlocks) return;                               // (block-uniform; rows the padded grid adds)
+    const int x0 = bx * kCellCols;
+    const int blockY0 = r.dyBase + by * (kCellWaves * rowsPerWave);
+    const int blockY1 = min(blockY0 + kCellWaves * rowsPerWave, r.dyEnd);
+    int y0, y1;
+    bool ownsBottom;
+    cell_segment(blockY0, blockY1, rowsPerWave, wave, y0, y1, ownsBottom);
+    const int chan = r.chan;
+    float *image = dst + (int64_t)blockIdx.z * dv.imageStride;
+    const char *img = reinterpret_cast<const char *>(src + (int64_t)blockIdx.z * sv.imageStride + m.base);
+    const CellColumn col = cell_column(r, z, min(x0 + lane, r.dW));
+    int liveLo, liveHi;
+    cell_live_rows(live, x0, x0 + kCellCols, liveLo, liveHi);
+    const unsigned long long *masks = skipMasks;
+    if (masks && m.tileFlags) {
+        bool any = false;
+        for (int tr = y0 >> 4; tr <= (y1 - 1) >> 4; ++tr) any = any || tiles_flagged(m.tileFlags, m.tileFlagWords, tr, x0 >> 4, kCellCols / 16 + 2);
+        if (!any) masks = nullptr;
+    }
+    cell_walk<kQuadMaxChan>(r.dW, x0, y0, y1, ownsBottom, wave, hand, liveLo, liveHi, lane,
+        [&](int px, int py, bool wanted) -> bool {
+            return masks && wanted && ((masks[flag_word(px, py, tilesX)] >> flag_bit(px, py)) & 1ull);
+        },
+        [&](int cx, int cy, float (&sA)[4], float (&sVA)[4 * kQuadMaxChan], bool upOnly) -> bool {
+            int Zx, Zy;
+            double dfx, dfy;
+            cell_anchor<true>(r, col, cy, Zx, Zy, dfx, dfy);
+            QuadSrcMulti<T, WIN, SCALED, WORDS> s;
+            s.img = img; s.m = &m; s.mW = r.mW; s.mH = r.mH; s.chan = chan; s.lds = windowWords; s.tid = tid;
+            cell_eval<float, WIN, false, HP, kQuadMaxChan>(q, z, Zx, Zy, dfx, dfy, r.mW, r.mH, s, sA, sVA, upOnly);
+            return false;
+        },
+        [&](int px, int py, float A, const float (&VA)[kQuadMaxChan], int, bool skip) {
+            if (skip) return;                                  // a pixel the plan's scans left to the fix-up pass is not written here
+            float *out = image + ((int64_t)(py - r.dyBase) * dv.rowStride + (int64_t)px * chan);
+#pragma unroll
+            for (int c = 0; c < kQuadMaxChan; ++c)
+                if (c < chan) out[c] = A > 0.f ? VA[c] / A : 0.f;                                  // Source.cpp:577
         });
 }
 
@@ -336,7 +428,7 @@ __global__ __launch_bounds__(kQuadBlock) void aai_cell_scan_kernel(RotLaunch r, 
             NoSrc s;
             return cell_eval<float, WIN, true, HP>(q, z, Zx, Zy, dfx, dfy, r.mW, r.mH, s, sA, sVA);
         },
-        [&](int px, int py, float A, float, int uncertain, int) {
+        [&](int px, int py, float A, const float (&)[1], int uncertain, int) {
             if (uncertain | ((A > 0.f && A < q.minArea) ? 1 : 0)) {
                 const unsigned long long bit = 1ull << flag_bit(px, py);
                 const unsigned long long old = atomicOr(laneMasks + flag_word(px, py, tilesX), bit);
@@ -412,6 +504,76 @@ hipError_t launch_cell_typed(const RotLaunch &r, const QuadMap &m, const T *src,
     }
 }
 
+// LDS words one window slot takes with `chan` interleaved channels of T (QuadSrcMulti)
+template <typename T> constexpr int cell_slot_words(int chan) { return sizeof(T) == 4 ? chan : (sizeof(T) == 2 ? (chan + 1) / 2 : 1); }
+
+template <typename T, int WIN, int WORDS>
+hipError_t launch_cell_multi_words(const RotLaunch &r, const QuadConsts<float> &q, const CellConsts<float> &z, const QuadMap &m, const T *src, ImageView sv,
+                                   float *dst, ImageView dv, int batch, const unsigned long long *skipMasks, hipStream_t stream)
+{
+    if constexpr (WIN * WIN * WORDS > kCellMultiMaxKiB) return hipErrorInvalidValue;          // (cell_can_serve keeps such windows on the quad kernel)
+    else {
+        const int rows = r.dyEnd - r.dyBase;
+        const int rowsPerWave = cell_rows_per_wave(r.dW, rows, batch, r.side / (m.scale > 0 ? m.scale : 1));
+        const int strips = (r.dW + kCellCols - 1) / kCellCols;
+        const int rowBlocks = (rows + kCellWaves * rowsPerWave - 1) / (kCellWaves * rowsPerWave);
+        const int band = xcd_band(m.scale > 1 ? 0 : kCellXcdRowsDefault);
+        const int gy = xcd_grid_rows(rowBlocks, band);
+        const int xcdRows = gy ? band : 0;
+        const dim3 grid(strips, gy ? gy : rowBlocks, batch);
+        const int tilesX = (r.dW + 15) / 16;
+        const CellLive live = make_cell_live(r, z);
+        const size_t lds = (size_t)WIN * WIN * WORDS * kQuadBlock * sizeof(unsigned);
+#define AAI_CELL_MULTI_LAUNCH(SCALED, HP)                                                                                                                     \
+    {                                                                                                                                                         \
+        static const hipError_t once = hipFuncSetAttribute(reinterpret_cast<const void *>(&aai_cell_multi_kernel<T, WIN, SCALED, HP, WORDS>),                  \
+                                                           hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);                                         \
+        (void)once;                                                                                                                                           \
+        hipLaunchKernelGGL((aai_cell_multi_kernel<T, WIN, SCALED, HP, WORDS>), grid, dim3(kQuadBlock), lds, stream, r, q, z, live, m, src, sv, dst, dv,         \
+                           skipMasks, tilesX, rowsPerWave, xcdRows, rowBlocks);                                                                               \
+    }
+        if (m.scale > 1) {
+            if (q.hiPrec) AAI_CELL_MULTI_LAUNCH(true, true) else AAI_CELL_MULTI_LAUNCH(true, false)
+        } else {
+            if (q.hiPrec) AAI_CELL_MULTI_LAUNCH(false, true) else AAI_CELL_MULTI_LAUNCH(false, false)
+        }
+#undef AAI_CELL_MULTI_LAUNCH
+        return hipGetLastError();
+    }
+}
+
+template <typename T, int WIN>
+hipError_t launch_cell_multi_win(const RotLaunch &r, const QuadConsts<float> &q, const CellConsts<float> &z, const QuadMap &m, const T *src, ImageView sv,
+                                 float *dst, ImageView dv, int batch, const unsigned long long *skipMasks, hipStream_t stream)
+{
+    const int words = cell_slot_words<T>(r.chan);
+    if constexpr (sizeof(T) == 1) return launch_cell_multi_words<T, WIN, 1>(r, q, z, m, src, sv, dst, dv, batch, skipMasks, stream);
+    else if constexpr (sizeof(T) == 2) {
+        if (words == 1) return launch_cell_multi_words<T, WIN, 1>(r, q, z, m, src, sv, dst, dv, batch, skipMasks, stream);
+        return launch_cell_multi_words<T, WIN, 2>(r, q, z, m, src, sv, dst, dv, batch, skipMasks, stream);
+    } else {
+        if (words == 2) return launch_cell_multi_words<T, WIN, 2>(r, q, z, m, src, sv, dst, dv, batch, skipMasks, stream);
+        if (words == 3) return launch_cell_multi_words<T, WIN, 3>(r, q, z, m, src, sv, dst, dv, batch, skipMasks, stream);
+        return launch_cell_multi_words<T, WIN, 4>(r, q, z, m, src, sv, dst, dv, batch, skipMasks, stream);
+    }
+}
+
+template <typename T>
+hipError_t launch_cell_multi_typed(const RotLaunch &r, const QuadMap &m, const T *src, ImageView sv, float *dst, ImageView dv, int batch,
+                                   const unsigned long long *skipMasks, hipStream_t stream)
+{
+    const QuadConsts<float> q = make_cell_quad_consts<float>(r.side, r.c, r.s, r.policy);
+    const CellConsts<float> z = make_cell_consts<float>(r.side, r.c, r.s);
+    switch (z.win) {
+    case 2: return launch_cell_multi_win<T, 2>(r, q, z, m, src, sv, dst, dv, batch, skipMasks, stream);
+    case 3: return launch_cell_multi_win<T, 3>(r, q, z, m, src, sv, dst, dv, batch, skipMasks, stream);
+    case 4: return launch_cell_multi_win<T, 4>(r, q, z, m, src, sv, dst, dv, batch, skipMasks, stream);
+    case 5: return launch_cell_multi_win<T, 5>(r, q, z, m, src, sv, dst, dv, batch, skipMasks, stream);
+    case 6: return launch_cell_multi_win<T, 6>(r, q, z, m, src, sv, dst, dv, batch, skipMasks, stream);
+    default: return hipErrorInvalidValue;                      // (cell_can_serve: windows up to 6 x 6)
+    }
+}
+
 }  // namespace
 
 // ---- translation units ----------------------------------------------------------------------------------------------------------
@@ -451,18 +613,55 @@ hipError_t launch_cell_u16(const RotLaunch &r, const QuadMap &m, const unsigned 
 }
 #endif
 
+hipError_t launch_cell_multi_f32(const RotLaunch &r, const QuadMap &m, const float *src, ImageView sv, float *dst, ImageView dv, int batch, const unsigned long long *skipMasks, hipStream_t stream);
+hipError_t launch_cell_multi_u8(const RotLaunch &r, const QuadMap &m, const unsigned char *src, ImageView sv, float *dst, ImageView dv, int batch, const unsigned long long *skipMasks, hipStream_t stream);
+hipError_t launch_cell_multi_u16(const RotLaunch &r, const QuadMap &m, const unsigned short *src, ImageView sv, float *dst, ImageView dv, int batch, const unsigned long long *skipMasks, hipStream_t stream);
+#if AAI_CELL_WAVE_ROWS == 1
+#if !defined(AAI_CELL_PART) || AAI_CELL_PART == 6
+hipError_t launch_cell_multi_f32(const RotLaunch &r, const QuadMap &m, const float *src, ImageView sv, float *dst, ImageView dv, int batch, const unsigned long long *skipMasks, hipStream_t stream)
+{
+    return launch_cell_multi_typed<float>(r, m, src, sv, dst, dv, batch, skipMasks, stream);
+}
+#endif
+#if !defined(AAI_CELL_PART) || AAI_CELL_PART == 7
+hipError_t launch_cell_multi_u8(const RotLaunch &r, const QuadMap &m, const unsigned char *src, ImageView sv, float *dst, ImageView dv, int batch, const unsigned long long *skipMasks, hipStream_t stream)
+{
+    return launch_cell_multi_typed<unsigned char>(r, m, src, sv, dst, dv, batch, skipMasks, stream);
+}
+#endif
+#if !defined(AAI_CELL_PART) || AAI_CELL_PART == 8
+hipError_t launch_cell_multi_u16(const RotLaunch &r, const QuadMap &m, const unsigned short *src, ImageView sv, float *dst, ImageView dv, int batch, const unsigned long long *skipMasks, hipStream_t stream)
+{
+    return launch_cell_multi_typed<unsigned short>(r, m, src, sv, dst, dv, batch, skipMasks, stream);
+}
+#endif
+#endif
+
 #if !defined(AAI_CELL_PART) || AAI_CELL_PART == 1
 bool cell_can_serve(const RotLaunch &r, int srcType, ImageView sv)
 {
     // plain images below 4 GiB (lanes address their pixels with unsigned 32-bit byte offsets from the image's first element)
     static const bool enabled = [] { const char *e = experiment_env("AAI_CELL"); return !(e && atoi(e) == 0); }();      // experiments: AAI_CELL=0 keeps the quad kernel
-    if (!enabled || !r.cell || r.chan > 1 || r.mode != AAI_MODE_AREA) return false;
+    if (!enabled || !r.cell || r.mode != AAI_MODE_AREA) return false;
     // Small outputs stay on the quad kernel: a cell wave lives for rows + 1 cell rows, and an image of fewer than ~1000 such
     // waves (about 720 x 720 dst pixels) cannot fill the chip with them -- the reference's own example call (158 x 158 dst
     // pixels at 5.9 : 1) takes 71 us on 60 cell waves and 36 us on 390 one-shot quad waves.
     // (AAI_POLICY_PREFER_CELL asks for the cell kernel all the same)
     if (!r.preferCell && (int64_t)((r.dW + 62) / 63) * ((r.dH + 7) / 8) < 1024) return false;      // (in waves of 63 columns x 8 rows, whatever the wave's shape)
     const int64_t esz = srcType == SRC_U8 ? 1 : srcType == SRC_U16 ? 2 : 4;
+    if (r.chan > 1) {
+        // interleaved channels (aai_cell_multi_kernel): the 64 x 1 wave, windows whose slots fit 64 KiB of LDS, below 4 GiB
+        if (kCellWaveRows != 1 || r.chan > kQuadMaxChan) return false;
+        // Where it wins (tools/interleaved_bench.py, profiles/r04_interleaved.txt): replicated sources of any type (x2 up-sampling of RGB
+        // fp32 at 30 degrees: 1.48 ms against the quad kernel's 2.78) and fp32 pixels (config 3's geometry, RGB: 0.72 against 0.77);
+        // 8- / 16-bit pixels without replication stay on aai_quad_multi_kernel (RGB 8-bit: 0.49 ms there, 0.68 here -- one lane's window
+        // of packed words is unpacked for four dst pixels' sums, and four channels' sums cross lanes and rows)
+        if (esz != 4 && r.scale <= 1 && !r.preferCell) return false;
+        const int words = esz == 4 ? r.chan : (esz == 2 ? (r.chan + 1) / 2 : 1);
+        const CellConsts<float> z = make_cell_consts<float>(r.side, r.c, r.s);
+        if (z.win > 6 || z.win * z.win * words > kCellMultiMaxKiB) return false;
+        return (int64_t)r.H * sv.rowStride * esz < ((int64_t)1 << 32);
+    }
     if ((int64_t)r.H * sv.rowStride * esz < ((int64_t)1 << 32)) return true;
     // 4 GiB and more: every wave rebases its offsets on its own first source row (aai_cell_kernel, QuadMap::rebaseWaves); the rows one
     // wave can touch -- 64 cell columns and up to 33 cell rows of `side` lattice points each, plus its windows -- must span less than
@@ -480,6 +679,14 @@ hipError_t launch_cell(const RotLaunch &r, const QuadMap &map, const void *src, 
     {
         const int64_t esz = srcType == SRC_U8 ? 1 : srcType == SRC_U16 ? 2 : 4;
         m.rebaseWaves = (int64_t)r.H * sv.rowStride * esz >= ((int64_t)1 << 32) ? 1 : 0;
+    }
+    if (r.chan > 1) {
+        m.rebaseWaves = 0;
+        switch (srcType) {
+        case SRC_U8: return launch_cell_multi_u8(r, m, static_cast<const unsigned char *>(src), sv, dst, dv, batch, skipMasks, stream);
+        case SRC_U16: return launch_cell_multi_u16(r, m, static_cast<const unsigned short *>(src), sv, dst, dv, batch, skipMasks, stream);
+        default: return launch_cell_multi_f32(r, m, static_cast<const float *>(src), sv, dst, dv, batch, skipMasks, stream);
+        }
     }
     switch (srcType) {
     case SRC_U8: return launch_cell_u8(r, m, static_cast<const unsigned char *>(src), sv, dst, dv, batch, skipMasks, stream);

@@ -33,114 +33,6 @@ namespace aai {
 
 namespace {
 
-// (kQuadBlock = 256 lanes: 16 x 16 dst pixels, the tiling of the scans -- aai_quad_src.hpp)
-constexpr int kQuadMaxChan = 4;
-
-// the `chan` (2..4) interleaved fp32 channels of one pixel in ONE load instruction (element-aligned)
-__device__ __forceinline__ void load_channels(const float *p, int chan, float (&v)[kQuadMaxChan])
-{
-    typedef float f2u __attribute__((ext_vector_type(2), aligned(4)));
-    typedef float f3u __attribute__((ext_vector_type(3), aligned(4)));
-    typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
-    v[2] = 0.f; v[3] = 0.f;
-    if (chan == 3) { const f3u q = *reinterpret_cast<const f3u *>(p); v[0] = q.x; v[1] = q.y; v[2] = q.z; }
-    else if (chan == 4) { const f4u q = *reinterpret_cast<const f4u *>(p); v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w; }
-    else { const f2u q = *reinterpret_cast<const f2u *>(p); v[0] = q.x; v[1] = q.y; }
-}
-
-// Interleaved channels (2..4 per pixel): the same window, every slot holding all channels of its pixel -- as WORDS raw
-// words, so that 8-bit RGB(A) costs one LDS word per slot like a plain image (16-bit: one or two, fp32: one per
-// channel).  Like the plain window it is fetched up front into registers and parked in LDS after the classification.
-template <typename T, int WIN, bool SCALED, int WORDS>
-struct QuadSrcMulti {
-    const char *img;
-    const QuadMap *m;
-    int mW, mH, chan;
-    unsigned *lds;                   // [WIN * WIN * WORDS][kQuadBlock]
-    int tid;
-    unsigned v[WIN * WIN * WORDS];
-
-    __device__ __forceinline__ void issue(int xg0, int yg0, unsigned long long)
-    {
-        unsigned colOff[WIN], rowOff[WIN];
-        const unsigned sxb = (unsigned)m->strideX * (unsigned)sizeof(T), syb = (unsigned)m->strideY * (unsigned)sizeof(T);
-        int qx0 = 0, qy0 = 0;
-        float remX = 0.f, remY = 0.f;
-        if (SCALED) {
-            const int scale = m->scale;
-            const int tx = xg0 + 8 * scale, ty = yg0 + 8 * scale;
-            qx0 = (int)(((double)tx + 0.5) * m->invScaleD); qy0 = (int)(((double)ty + 0.5) * m->invScaleD);
-            remX = (float)(tx - qx0 * scale) + 0.5f; remY = (float)(ty - qy0 * scale) + 0.5f;
-        }
-#pragma unroll
-        for (int i = 0; i < WIN; ++i) {
-            int qx = min(max(xg0 + i, 0), mW - 1), qy = min(max(yg0 + i, 0), mH - 1);
-            if (SCALED) {
-                qx = qx0 - 8 + (int)((remX + (float)(qx - xg0)) * m->invScale);
-                qy = qy0 - 8 + (int)((remY + (float)(qy - yg0)) * m->invScale);
-            }
-            colOff[i] = (unsigned)(m->flipX ? m->nX - 1 - qx : qx) * sxb;
-            rowOff[i] = (unsigned)(m->flipY ? m->nY - 1 - qy : qy) * syb;
-        }
-#pragma unroll
-        for (int j = 0; j < WIN; ++j)
-#pragma unroll
-            for (int i = 0; i < WIN; ++i) {
-                const T *p = reinterpret_cast<const T *>(img + (colOff[i] + rowOff[j]));
-                unsigned *w = v + (j * WIN + i) * WORDS;
-                if (sizeof(T) == 4) {
-                    float f[kQuadMaxChan];
-                    load_channels(reinterpret_cast<const float *>(p), chan, f);
-#pragma unroll
-                    for (int c = 0; c < WORDS; ++c) w[c] = __float_as_uint(f[c]);
-                } else if (sizeof(T) == 2) {
-                    // 2..4 sixteen-bit channels = 4..8 bytes: ONE load (the number of load instructions, each touching ~64
-                    // cache lines, is what bounds these kernels), started early enough to stay inside the image
-                    typedef unsigned u1w __attribute__((aligned(2)));
-                    typedef unsigned u2w __attribute__((ext_vector_type(2), aligned(2)));
-                    const unsigned want = colOff[i] + rowOff[j];
-                    if (WORDS == 1) w[0] = *reinterpret_cast<const u1w *>(img + want);
-                    else {
-                        const unsigned from = min(want, m->lastLoad8);
-                        const u2w q2 = *reinterpret_cast<const u2w *>(img + from);
-                        const unsigned long long both = (((unsigned long long)q2.y << 32) | q2.x) >> (8u * (want - from));
-                        w[0] = (unsigned)both;
-                        w[WORDS - 1] = chan > 3 ? (unsigned)(both >> 32) : (unsigned)(both >> 32) & 65535u;
-                    }
-                } else {
-                    typedef unsigned u1b __attribute__((aligned(1)));
-                    typedef unsigned short u1s __attribute__((aligned(1)));
-                    const unsigned want = colOff[i] + rowOff[j];
-                    if (chan == 2) w[0] = *reinterpret_cast<const u1s *>(img + want);
-                    else {
-                        const unsigned from = min(want, m->lastLoad4);
-                        const unsigned q1 = *reinterpret_cast<const u1b *>(img + from) >> (8u * (want - from));
-                        w[0] = chan > 3 ? q1 : q1 & 0xffffffu;
-                    }
-                }
-            }
-    }
-    __device__ __forceinline__ void commit()
-    {
-#pragma unroll
-        for (int k = 0; k < WIN * WIN * WORDS; ++k) lds[(size_t)k * kQuadBlock + tid] = v[k];
-    }
-    __device__ __forceinline__ void at(int slot, float (&vals)[kQuadMaxChan]) const
-    {
-        const unsigned *p = lds + (size_t)(slot * WORDS) * kQuadBlock + tid;
-        if (sizeof(T) == 4) {
-#pragma unroll
-            for (int c = 0; c < kQuadMaxChan; ++c) vals[c] = c < WORDS ? __uint_as_float(p[(size_t)c * kQuadBlock]) : 0.f;
-        } else if (sizeof(T) == 2) {
-            const unsigned w0 = p[0], w1 = WORDS > 1 ? p[kQuadBlock] : 0u;
-            vals[0] = (float)(w0 & 65535u); vals[1] = (float)(w0 >> 16); vals[2] = (float)(w1 & 65535u); vals[3] = (float)(w1 >> 16);
-        } else {
-            const unsigned w0 = p[0];
-            vals[0] = (float)(w0 & 255u); vals[1] = (float)((w0 >> 8) & 255u); vals[2] = (float)((w0 >> 16) & 255u); vals[3] = (float)(w0 >> 24);
-        }
-    }
-};
-
 // Tile order: launch order (x fastest).  Workgroups are dealt round-robin over the 8 XCDs, so neighbouring tiles sit on
 // different L2s and the fast kernel fetches 1.75 x the source at config 3 -- yet giving each XCD contiguous bands, or
 // cyclically dealt 8 x 8 super-tiles, made every kernel SLOWER (profiles/r02_xcd_tile_order.txt): these kernels are bound

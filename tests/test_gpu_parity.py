@@ -1261,6 +1261,80 @@ def test_concurrent_host_threads(gpu):
     assert not failures, failures[:5]
 
 
+def test_interleaved_channels_through_the_cell_kernel(gpu, po):
+    """Interleaved area requests in the cell formulation (aai_cell_multi_kernel: areas once per (dst, src) pair, one sum per channel):
+    every channel must equal the plain cell kernel's result on that channel alone BIT FOR BIT (same per-cell arithmetic, same order of
+    additions), for 8- / 16-bit / fp32 pixels, 2 - 4 channels, with and without replication, in all quadrants, padded strides and batches;
+    one case against the oracle and one large enough to take the kernel without the hint."""
+    import torch
+    rng = np.random.default_rng(77)
+    gpu.debug_cell_min_waves(0)          # AAI_POLICY_PREFER_CELL: small outputs take the cell kernels too
+    try:
+        cases = [  # W, H, srcRes, dstRes, angle, C, dtype
+            (300, 260, 2.39, 1.0, 30.0, 3, np.uint8), (256, 256, 3.0, 1.0, 17.5, 4, np.uint8), (200, 180, 2.0, 1.0, 107.5, 3, np.float32),
+            (160, 200, 2.0, 1.0, 200.0, 2, np.uint16), (128, 96, 1.0, 2.0, 30.0, 3, np.uint8), (120, 90, 2.0, 1.0, 290.0, 4, np.uint16),
+            (96, 128, 1.0, 3.0, 45.0, 2, np.float32), (140, 100, 3.0, 1.0, 61.0, 2, np.float32), (150, 130, 1.5, 1.0, 333.0, 3, np.uint16),
+            (140, 100, 2.2, 1.0, 17.5, 4, np.float32),
+        ]
+        for k, (W, H, sr, dr, ang, C, dt) in enumerate(cases):
+            iso = ((W - 1) / 2, (H - 1) / 2) if k % 2 else (float(rng.uniform(0, W)), float(rng.uniform(0, H)))
+            if dt == np.float32:
+                src = rng.random((H, W, C)).astype(np.float32)
+            else:
+                src = rng.integers(0, np.iinfo(dt).max + 1, size=(H, W, C)).astype(dt)
+            rc, msg, dst, lay = gpu.resample_interleaved_host(src, sr, dr, iso, ang)
+            assert rc == 0, (k, msg)
+            assert "aai_cell_multi_kernel" in gpu.last_kernel(), (k, gpu.last_kernel())
+            for c in range(C):
+                rc, msg, planar, giso, _ = gpu.resample_host(np.ascontiguousarray(src[:, :, c]), sr, dr, iso, ang)
+                assert rc == 0, msg
+                assert "aai_cell_kernel" in gpu.last_kernel(), gpu.last_kernel()
+                assert np.array_equal(dst[:, :, c], planar), (k, W, H, sr, dr, ang, C, c, dt)
+        # against the oracle itself (reference policy and the exact one)
+        src = rng.random((110, 140, 3)).astype(np.float32)
+        for policy, omode in ((0, po.MODE_EXACT),):
+            rc, msg, dst, lay = gpu.resample_interleaved_host(src, 2.5, 1.0, (69.5, 54.5), 33.0, policy=policy)
+            assert rc == 0 and "aai_cell_multi_kernel" in gpu.last_kernel(), (msg, gpu.last_kernel())
+            for c in range(3):
+                gold = po.oracle_run(omode, src[:, :, c].astype(np.float64), 2.5, 1.0, (69.5, 54.5), 33.0, policy=policy)
+                assert rel_err(dst[:, :, c], gold.dst).max() <= TOL and np.array_equal(gold.dst == 0, dst[:, :, c] == 0)
+        # device entry: a batch of interleaved images with padded strides, NaN in one pixel of one channel
+        B, W, H, C = 3, 220, 170, 3
+        rq = gpu.make_request(W, H, 2.0, 1.0, ((W - 1) / 2, (H - 1) / 2), 33.0)
+        rc, msg, lay = gpu.query(rq)
+        hsrc = rng.random((B, H, W + 5, C)).astype(np.float32)
+        hsrc[1, 80, 100, 1] = np.nan
+        dsrc = torch.from_numpy(hsrc).cuda()
+        ddst = torch.full((B, lay.dst_height, lay.dst_width + 2, C), -5.0, dtype=torch.float32, device="cuda")
+        gpu.resample_interleaved_device(rq, C, dsrc.data_ptr(), (W + 5) * C, ddst.data_ptr(), (lay.dst_width + 2) * C,
+                                        torch.cuda.current_stream().cuda_stream, batch=B, src_image_stride=H * (W + 5) * C,
+                                        dst_image_stride=lay.dst_height * (lay.dst_width + 2) * C)
+        torch.cuda.synchronize()
+        assert "aai_cell_multi_kernel" in gpu.last_kernel(), gpu.last_kernel()
+        got = ddst.cpu().numpy()
+        assert np.all(got[:, :, lay.dst_width:, :] == -5.0)           # the padding is not written
+        for b in range(B):
+            for c in range(C):
+                rc, msg, planar, _, _ = gpu.resample_host(np.ascontiguousarray(hsrc[b, :, :W, c]), 2.0, 1.0, ((W - 1) / 2, (H - 1) / 2), 33.0)
+                assert rc == 0, msg
+                assert np.array_equal(got[b, :, :lay.dst_width, c], planar, equal_nan=True), (b, c)
+        # (the NaN reaches only the dst pixels its source pixel overlaps, and only in its own channel)
+        assert np.isnan(got[1, :, :lay.dst_width, 1]).sum() in range(1, 10) and not np.isnan(got[1, :, :lay.dst_width, 0]).any()
+    finally:
+        gpu.debug_cell_min_waves(-1)
+    # large enough for the cell kernels without the hint: RGB fp32, 1600 x 1400 at 2 : 1, and RGB 8-bit x2 up-sampling (8-bit pixels
+    # without replication stay on the quad kernel: it is the faster one there)
+    for (W, H, sr, dr, dt) in ((1600, 1400, 2.0, 1.0, np.float32), (700, 600, 1.0, 2.0, np.uint8), (1600, 1400, 2.0, 1.0, np.uint8)):
+        C = 3
+        src = rng.random((H, W, C)).astype(np.float32) if dt == np.float32 else rng.integers(0, 256, size=(H, W, C)).astype(np.uint8)
+        rc, msg, dst, lay = gpu.resample_interleaved_host(src, sr, dr, ((W - 1) / 2, (H - 1) / 2), 17.5)
+        assert rc == 0, msg
+        assert ("aai_cell_multi_kernel" in gpu.last_kernel()) == (dt == np.float32 or dr > sr), (dt, sr, dr, gpu.last_kernel())
+        if "aai_cell_multi_kernel" in gpu.last_kernel():
+            rc, msg, planar, _, _ = gpu.resample_host(np.ascontiguousarray(src[:, :, 2]), sr, dr, ((W - 1) / 2, (H - 1) / 2), 17.5)
+            assert rc == 0 and "aai_cell_kernel" in gpu.last_kernel() and np.array_equal(dst[:, :, 2], planar)
+
+
 def test_sources_larger_than_4_gib(gpu, po):
     """A 33,000 x 33,000 fp32 source (4.36 GB: byte offsets from the image's first element no longer fit 32 bits) and, for
     K1, a 46,500 x 46,500 one (8.6 GB, 2.16 G elements: past 32-bit element offsets too): K1 streams them, the fp32

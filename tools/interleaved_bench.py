@@ -23,6 +23,7 @@ def timed(fn, n=7):
 
 for (W, sr, dr, ang, C, dt, mode) in ((8192, 8192.0, 2731.0, 17.5, 3, "f32", 1), (8192, 8192.0, 2731.0, 17.5, 3, "u8", 1), (8192, 8192.0, 2731.0, 17.5, 4, "u8", 1),
                                       (8192, 4.0, 1.0, 0.5, 3, "u8", 1), (8192, 1.0, 1.0, 1.0, 3, "u8", 1), (4096, 1.0, 2.0, 30.0, 3, "f32", 1),
+                                      (4096, 1.0, 2.0, 30.0, 3, "u8", 1), (4096, 1.0, 3.0, 45.0, 4, "u8", 1), (8192, 2.0, 1.0, 45.0, 3, "f32", 1),
                                       # fast mode (the reference's default mode)
                                       (8192, 8192.0, 2731.0, 17.5, 1, "f32", 2), (8192, 8192.0, 2731.0, 17.5, 3, "f32", 2), (8192, 8192.0, 2731.0, 17.5, 3, "u8", 2),
                                       (8192, 8192.0, 2731.0, 17.5, 4, "u8", 2), (4096, 1.0, 2.0, 30.0, 3, "u8", 2)):
