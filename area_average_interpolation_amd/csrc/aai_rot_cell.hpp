@@ -39,21 +39,18 @@
 
 #include "aai_rot_quad.hpp"
 
-// The shape of the kernel's wave: 1 = 64 consecutive cell columns of ONE cell row per step (63 dst columns a strip); 2 = 32 cell columns
-// of TWO consecutive cell rows (31 dst columns a strip, the upper half-wave a row below the lower one): the two rows' windows share half
-// of their source lines, which one load instruction then fetches once (cell_walk2, aai_rotated_cell.hip).  Shape 2 is correct (all GPU
-// tests) and was measured against shape 1 on one box (profiles/r04_cell_kernel.txt, 6.): config 3 at 8 images per launch 160.6 -> 148.5
-// us per image, but one image 157.9 -> 173.3, config 5 2627 -> 3041, 2:1 at 45 degrees 228 -> 290, 1:1 at 30 degrees 820 -> 951: shape 1
-// ships, -DAAI_CELL_WAVE_ROWS=2 builds the other.
-#ifndef AAI_CELL_WAVE_ROWS
-#define AAI_CELL_WAVE_ROWS 1
-#endif
-
 namespace aai {
 
-constexpr int kCellWaveRows = AAI_CELL_WAVE_ROWS;
-constexpr int kCellLanes = 64 / kCellWaveRows;            // cell columns a wave evaluates per cell row
-constexpr int kCellCols = kCellLanes - 1;                 // dst columns it completes (the last cell column only feeds its left neighbour)
+// The shape of the cell kernel's wave.  1: 64 consecutive cell columns of ONE cell row per step (63 dst columns a strip).  2: 32 cell columns
+// of TWO consecutive cell rows (31 dst columns a strip, the upper half-wave a row below the lower one): the two rows' windows share half
+// of their source lines, which one load instruction then fetches once -- L1 -> L2 requests -44 %, fabric reads -54 % at config 3 -- at the
+// price of row pieces of 124 bytes per store instead of 252.  Measured (profiles/r04_cell_kernel.txt, 6.): shape 2 wins where the source
+// is larger than the output (config 3 one image 158 -> 147 us, 8 images per launch 163 -> 130 us per image; 2:1 at 45 degrees level) and
+// loses where the stores weigh as much as the loads (1:1 at 30 degrees 824 -> 934 us, config 5's replicated source 2.65 -> 3.04 ms).
+// The kernel, its launcher and the CPU replay of its fetches (tests/emulation) all ask this function.
+AAI_HD int cell_wave_rows(double side, int scale) { return scale <= 1 && side >= 2.0 ? 2 : 1; }
+constexpr int cell_wave_lanes(int waveRows) { return 64 / waveRows; }              // cell columns a wave evaluates per cell row
+constexpr int cell_wave_cols(int waveRows) { return 64 / waveRows - 1; }           // dst columns it completes (the last cell column only feeds its left neighbour)
 
 enum CellTarget { CELL_O = 0, CELL_W = 1, CELL_N = 2, CELL_NW = 3 };     // own dst pixel (x, y); (x-1, y); (x, y-1); (x-1, y-1)
 

@@ -42,17 +42,28 @@ namespace aai {
 // x4 up-sampling -> 16 ... 32: the workgroup's footprint, 4 R dst rows of `srcRowsPerDstRow` source rows each, wants to be about 50
 // source rows (a CU's cache holds them while its waves walk).  Never so tall that the launch has fewer than several waves for every
 // SIMD of the chip (1024 SIMDs x ~6 wave slots).
-static int cell_rows_per_wave(int dW, int rows, int batch, double srcRowsPerDstRow)
+static int cell_rows_per_wave(int dW, int rows, int batch, double srcRowsPerDstRow, int waveRows = 1)
 {
     const char *e = experiment_env("AAI_CELL_ROWS");
     if (e && atoi(e) > 0) return atoi(e);
-    const int64_t strips = ((int64_t)dW + kCellCols - 1) / kCellCols * batch;
-    const double want = 14.0 / (srcRowsPerDstRow > 0.05 ? srcRowsPerDstRow : 0.05);
-    // (the nearest power of two, except that ratios from ~1.9:1 up keep 4: since the classification by intervals the kernel waits for
-    // memory sooner -- 2:1 at 45 degrees, 4 images per launch: 229 / 254 / 372 us per image at 4 / 8 / 16 rows; config 3 at 8 images per
-    // launch: 163 / 194 us at 4 / 8 -- profiles/r04_cell_kernel.txt)
-    int R = want < 7.4 ? 4 : (want < 11.4 ? 8 : (want < 22.7 ? 16 : 32));
-    while (R > 4 && strips * ((rows + R - 1) / R) < 24576 * kCellWaveRows) R >>= 1;
+    const int cols = cell_wave_cols(waveRows);
+    const int64_t strips = ((int64_t)dW + cols - 1) / cols * batch;
+    int R;
+    int64_t floorWaves = 24576;
+    if (waveRows == 2) {
+        // the 32 x 2 wave (ratios from 2:1 up; us per image, tools/cell_wave_ab.sh): 16 rows up to config 3's ratio (one image 174 / 154 /
+        // 147 at 4 / 8 / 16 rows; 8 images per launch 150 / 133 / 130; 2:1 at 30 degrees 290 / 275 / 273 at 8 / 16 / 32), 8 rows from
+        // ~2.7:1 up (3:1 at 30 degrees 281 / 323 / 342 at 8 / 16 / 32; 4:1 at 45: 184 / 210 / 251; 5:1 at 17.5: 189 / 214 / 240)
+        R = srcRowsPerDstRow < 2.7 ? 16 : 8;
+        floorWaves = 16384;                                     // (config 3, one image, 16 rows: 24 k waves -- and the best of 4 / 8 / 16)
+    } else {
+        const double want = 14.0 / (srcRowsPerDstRow > 0.05 ? srcRowsPerDstRow : 0.05);
+        // (the nearest power of two, except that ratios from ~1.9:1 up keep 4: since the classification by intervals the kernel waits for
+        // memory sooner -- 2:1 at 45 degrees, 4 images per launch: 229 / 254 / 372 us per image at 4 / 8 / 16 rows; config 3 at 8 images per
+        // launch: 163 / 194 us at 4 / 8 -- profiles/r04_cell_kernel.txt)
+        R = want < 7.4 ? 4 : (want < 11.4 ? 8 : (want < 22.7 ? 16 : 32));
+    }
+    while (R > 4 && strips * ((rows + R - 1) / R) < floorWaves) R >>= 1;
     while ((rows + 4 * R - 1) / (4 * R) > 65535) R <<= 1;       // grid.y
     return R;
 }
@@ -82,11 +93,6 @@ constexpr int kCellWaves = kQuadBlock / 64;          // waves of a workgroup: co
 
 // What the waves of a workgroup hand to the wave above them: the N / NW parts of their first cell row (which finish the last
 // dst row of the segment above), [wave][A, VA, uncertain][lane]
-#if AAI_CELL_WAVE_ROWS == 2
-#define AAI_CELL_WALK cell_walk2<1>
-#else
-#define AAI_CELL_WALK cell_walk<1>
-#endif
 template <int NC>
 struct CellHandoffN { float a[kCellWaves][64], va[kCellWaves][NC][64]; int u[kCellWaves][64]; };
 typedef CellHandoffN<1> CellHandoff;
@@ -254,11 +260,13 @@ __device__ __forceinline__ void cell_segment(int blockY0, int blockY1, int rowsP
     ownsBottom = wave == kCellWaves - 1 || y1 >= blockY1;
 }
 
-template <typename T, int WIN, bool SCALED, bool HP>
+// WR: the wave's shape (cell_wave_rows): 1 = 64 cell columns x 1 cell row per step, 2 = 32 x 2
+template <typename T, int WIN, bool SCALED, bool HP, int WR>
 __global__ __launch_bounds__(kQuadBlock, cell_min_waves(WIN)) __attribute__((amdgpu_num_sgpr(AAI_CELL_SGPRS))) void aai_cell_kernel(
     RotLaunch r, QuadConsts<float> q, CellConsts<float> z, CellLive live, QuadMap m, const T *__restrict__ src, ImageView sv, float *__restrict__ dst, ImageView dv,
     const unsigned long long *__restrict__ skipMasks, int tilesX, int rowsPerWave, int bigBlocks, int tailRows, int xcdRows, int rowBlocks)
 {
+    constexpr int kCellLanes = cell_wave_lanes(WR), kCellCols = cell_wave_cols(WR);
     __shared__ float window[WIN * WIN][kQuadBlock];
     __shared__ CellHandoff hand;
     const int tid = threadIdx.x;
@@ -312,12 +320,11 @@ __global__ __launch_bounds__(kQuadBlock, cell_min_waves(WIN)) __attribute__((amd
         for (int tr = y0 >> 4; tr <= (y1 - 1) >> 4; ++tr) any = any || tiles_flagged(m.tileFlags, m.tileFlagWords, tr, x0 >> 4, kCellCols / 16 + 2);
         if (!any) masks = nullptr;
     }
-    AAI_CELL_WALK(r.dW, x0, y0, y1, ownsBottom, wave, hand, liveLo, liveHi, lane,
-        [&](int px, int py, bool wanted) -> bool {
+    auto look = [&](int px, int py, bool wanted) -> bool {
             // is the pixel one the plan's scans left to the fix-up pass?  (requested here, used after the cell is evaluated)
             return masks && wanted && ((masks[flag_word(px, py, tilesX)] >> flag_bit(px, py)) & 1ull);
-        },
-        [&](int cx, int cy, float (&sA)[4], float (&sVA)[4], bool upOnly) -> bool {
+        };
+    auto eval = [&](int cx, int cy, float (&sA)[4], float (&sVA)[4], bool upOnly) -> bool {
             int Zx, Zy;
             double dfx, dfy;
             cell_anchor<true>(r, col, cy, Zx, Zy, dfx, dfy);
@@ -326,12 +333,14 @@ __global__ __launch_bounds__(kQuadBlock, cell_min_waves(WIN)) __attribute__((amd
             // (the workgroup's bottom cell row only feeds its last pixel row: its interior / left-edge zones are skipped)
             cell_eval<float, WIN, false, HP>(q, z, Zx, Zy, dfx, dfy, r.mW, r.mH, s, sA, sVA, upOnly);
             return false;
-        },
-        [&](int px, int py, float A, const float (&VA)[1], int, bool skip) {
+        };
+    auto emit = [&](int px, int py, float A, const float (&VA)[1], int, bool skip) {
             if (skip) return;                                  // a pixel the plan's scans left to the fix-up pass is not written here
             // (written once, never read back: around the caches -- 1 % at configs 3 and 5)
             __builtin_nontemporal_store(A > 0.f ? VA[0] / A : 0.f, image + ((int64_t)(py - r.dyBase) * dv.rowStride + px));         // Source.cpp:577
-        });
+        };
+    if constexpr (WR == 2) cell_walk2<1>(r.dW, x0, y0, y1, ownsBottom, wave, hand, liveLo, liveHi, lane, look, eval, emit);
+    else cell_walk<1>(r.dW, x0, y0, y1, ownsBottom, wave, hand, liveLo, liveHi, lane, look, eval, emit);
 }
 
 // Interleaved channels (2 .. 4 per pixel): the same walk with one sum of area x value per channel -- the areas of a (dst, src) pair are
@@ -347,6 +356,7 @@ __global__ __launch_bounds__(kQuadBlock, cell_multi_min_waves(WIN, WORDS)) void 
     RotLaunch r, QuadConsts<float> q, CellConsts<float> z, CellLive live, QuadMap m, const T *__restrict__ src, ImageView sv, float *__restrict__ dst, ImageView dv,
     const unsigned long long *__restrict__ skipMasks, int tilesX, int rowsPerWave, int xcdRows, int rowBlocks)
 {
+    constexpr int kCellCols = cell_wave_cols(1);
     extern __shared__ unsigned windowWords[];
     __shared__ CellHandoffN<kQuadMaxChan> hand;
     const int tid = threadIdx.x;
@@ -402,6 +412,7 @@ template <int WIN, bool HP>
 __global__ __launch_bounds__(kQuadBlock) void aai_cell_scan_kernel(RotLaunch r, QuadConsts<float> q, CellConsts<float> z, CellLive live, unsigned long long *__restrict__ laneMasks,
                                                                   unsigned *__restrict__ counter, int tilesX, int rowsPerWave, int band0)
 {
+    constexpr int kCellLanes = cell_wave_lanes(1), kCellCols = cell_wave_cols(1);      // (the flags do not depend on the wave's shape: the scan keeps 64 x 1)
     __shared__ CellHandoff hand;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -415,7 +426,7 @@ __global__ __launch_bounds__(kQuadBlock) void aai_cell_scan_kernel(RotLaunch r, 
     const CellColumn col = cell_column(r, z, min(x0 + (lane & (kCellLanes - 1)), r.dW));
     int liveLo, liveHi;
     cell_live_rows(live, x0, x0 + kCellCols, liveLo, liveHi);
-    AAI_CELL_WALK(r.dW, x0, y0, y1, ownsBottom, wave, hand, liveLo, liveHi, lane,
+    cell_walk<1>(r.dW, x0, y0, y1, ownsBottom, wave, hand, liveLo, liveHi, lane,
         [&](int, int, bool) -> int { return 0; },
         [&](int cx, int cy, float (&sA)[4], float (&sVA)[4], bool) -> bool {
             int Zx, Zy;
@@ -443,8 +454,14 @@ hipError_t launch_cell_tile(const RotLaunch &r, const QuadConsts<float> &q, cons
                             float *dst, ImageView dv, int batch, const unsigned long long *skipMasks, hipStream_t stream)
 {
     const int rows = r.dyEnd - r.dyBase;
-    const int rowsPerWave = cell_rows_per_wave(r.dW, rows, batch, r.side / (m.scale > 0 ? m.scale : 1));
-    const int strips = (r.dW + kCellCols - 1) / kCellCols;
+    // the wave's shape (cell_wave_rows; experiments build: AAI_CELL_WAVE=1 / 2)
+    int waveRows = cell_wave_rows(r.side, m.scale);
+    {
+        const char *e = experiment_env("AAI_CELL_WAVE");
+        if (e && m.scale <= 1 && (atoi(e) == 1 || atoi(e) == 2)) waveRows = atoi(e);
+    }
+    const int rowsPerWave = cell_rows_per_wave(r.dW, rows, batch, r.side / (m.scale > 0 ? m.scale : 1), waveRows);
+    const int strips = (r.dW + cell_wave_cols(waveRows) - 1) / cell_wave_cols(waveRows);
     const int blockRows = kCellWaves * rowsPerWave;
     // (Shorter segments for the last rows of a launch -- waves that live half as long, so that the chip drains sooner -- paid with
     // 8-row strips per wave; with four waves per strip segment they measure nothing: config 3 160.7 us without, 161.0 ... 166.3 with.
@@ -472,15 +489,18 @@ hipError_t launch_cell_tile(const RotLaunch &r, const QuadConsts<float> &q, cons
     const dim3 grid(strips, gy ? gy : rowBlocks, batch);
     const int tilesX = (r.dW + 15) / 16;
     const CellLive live = make_cell_live(r, z);
-#define AAI_CELL_LAUNCH(SCALED, HP) \
-    hipLaunchKernelGGL((aai_cell_kernel<T, WIN, SCALED, HP>), grid, dim3(kQuadBlock), 0, stream, r, q, z, live, m, src, sv, dst, dv, skipMasks, tilesX, rowsPerWave, bigBlocks, tailRows, xcdRows, rowBlocks)
+#define AAI_CELL_LAUNCH(SCALED, HP, WR) \
+    hipLaunchKernelGGL((aai_cell_kernel<T, WIN, SCALED, HP, WR>), grid, dim3(kQuadBlock), 0, stream, r, q, z, live, m, src, sv, dst, dv, skipMasks, tilesX, rowsPerWave, bigBlocks, tailRows, xcdRows, rowBlocks)
     if ((q.hiPrec != 0) != (HPSEL == 1) && HPSEL != 2) return hipErrorInvalidValue;       // (the dispatcher picks the unit that holds the variant)
-    if (m.scale > 1) {
-        if (HPSEL != 0 && q.hiPrec) AAI_CELL_LAUNCH(true, true);
-        if (HPSEL != 1 && !q.hiPrec) AAI_CELL_LAUNCH(true, false);
+    if (m.scale > 1) {                                          // (replicated sources: the 64 x 1 wave only)
+        if (HPSEL != 0 && q.hiPrec) AAI_CELL_LAUNCH(true, true, 1);
+        if (HPSEL != 1 && !q.hiPrec) AAI_CELL_LAUNCH(true, false, 1);
+    } else if (waveRows == 2) {
+        if (HPSEL != 0 && q.hiPrec) AAI_CELL_LAUNCH(false, true, 2);
+        if (HPSEL != 1 && !q.hiPrec) AAI_CELL_LAUNCH(false, false, 2);
     } else {
-        if (HPSEL != 0 && q.hiPrec) AAI_CELL_LAUNCH(false, true);
-        if (HPSEL != 1 && !q.hiPrec) AAI_CELL_LAUNCH(false, false);
+        if (HPSEL != 0 && q.hiPrec) AAI_CELL_LAUNCH(false, true, 1);
+        if (HPSEL != 1 && !q.hiPrec) AAI_CELL_LAUNCH(false, false, 1);
     }
 #undef AAI_CELL_LAUNCH
     return hipGetLastError();
@@ -515,7 +535,7 @@ hipError_t launch_cell_multi_words(const RotLaunch &r, const QuadConsts<float> &
     else {
         const int rows = r.dyEnd - r.dyBase;
         const int rowsPerWave = cell_rows_per_wave(r.dW, rows, batch, r.side / (m.scale > 0 ? m.scale : 1));
-        const int strips = (r.dW + kCellCols - 1) / kCellCols;
+        const int strips = (r.dW + cell_wave_cols(1) - 1) / cell_wave_cols(1);
         const int rowBlocks = (rows + kCellWaves * rowsPerWave - 1) / (kCellWaves * rowsPerWave);
         const int band = xcd_band(m.scale > 1 ? 0 : kCellXcdRowsDefault);
         const int gy = xcd_grid_rows(rowBlocks, band);
@@ -616,7 +636,6 @@ hipError_t launch_cell_u16(const RotLaunch &r, const QuadMap &m, const unsigned 
 hipError_t launch_cell_multi_f32(const RotLaunch &r, const QuadMap &m, const float *src, ImageView sv, float *dst, ImageView dv, int batch, const unsigned long long *skipMasks, hipStream_t stream);
 hipError_t launch_cell_multi_u8(const RotLaunch &r, const QuadMap &m, const unsigned char *src, ImageView sv, float *dst, ImageView dv, int batch, const unsigned long long *skipMasks, hipStream_t stream);
 hipError_t launch_cell_multi_u16(const RotLaunch &r, const QuadMap &m, const unsigned short *src, ImageView sv, float *dst, ImageView dv, int batch, const unsigned long long *skipMasks, hipStream_t stream);
-#if AAI_CELL_WAVE_ROWS == 1
 #if !defined(AAI_CELL_PART) || AAI_CELL_PART == 6
 hipError_t launch_cell_multi_f32(const RotLaunch &r, const QuadMap &m, const float *src, ImageView sv, float *dst, ImageView dv, int batch, const unsigned long long *skipMasks, hipStream_t stream)
 {
@@ -635,7 +654,6 @@ hipError_t launch_cell_multi_u16(const RotLaunch &r, const QuadMap &m, const uns
     return launch_cell_multi_typed<unsigned short>(r, m, src, sv, dst, dv, batch, skipMasks, stream);
 }
 #endif
-#endif
 
 #if !defined(AAI_CELL_PART) || AAI_CELL_PART == 1
 bool cell_can_serve(const RotLaunch &r, int srcType, ImageView sv)
@@ -650,8 +668,8 @@ bool cell_can_serve(const RotLaunch &r, int srcType, ImageView sv)
     if (!r.preferCell && (int64_t)((r.dW + 62) / 63) * ((r.dH + 7) / 8) < 1024) return false;      // (in waves of 63 columns x 8 rows, whatever the wave's shape)
     const int64_t esz = srcType == SRC_U8 ? 1 : srcType == SRC_U16 ? 2 : 4;
     if (r.chan > 1) {
-        // interleaved channels (aai_cell_multi_kernel): the 64 x 1 wave, windows whose slots fit 64 KiB of LDS, below 4 GiB
-        if (kCellWaveRows != 1 || r.chan > kQuadMaxChan) return false;
+        // interleaved channels (aai_cell_multi_kernel, 64 x 1 wave): windows whose slots fit 64 KiB of LDS, below 4 GiB
+        if (r.chan > kQuadMaxChan) return false;
         // Where it wins (tools/interleaved_bench.py, profiles/r04_interleaved.txt): replicated sources of any type (x2 up-sampling of RGB
         // fp32 at 30 degrees: 1.48 ms against the quad kernel's 2.78) and fp32 pixels (config 3's geometry, RGB: 0.72 against 0.77);
         // 8- / 16-bit pixels without replication stay on aai_quad_multi_kernel (RGB 8-bit: 0.49 ms there, 0.68 here -- one lane's window
@@ -704,7 +722,7 @@ hipError_t launch_cell_scan(const RotLaunch &r, unsigned long long *laneMasks, u
     const CellConsts<float> z = make_cell_consts<float>(r.side, r.c, r.s);
     const CellLive live = make_cell_live(r, z);
     const int rows = 4;                                        // per wave: workgroups of 16 dst rows
-    const int strips = (r.dW + kCellCols - 1) / kCellCols;
+    const int strips = (r.dW + cell_wave_cols(1) - 1) / cell_wave_cols(1);
     const int tilesX = (r.dW + 15) / 16;
     const int bands = (r.dH + kCellWaves * rows - 1) / (kCellWaves * rows);
     for (int b0 = 0; b0 < bands; b0 += 65535) {                // grid.y carries at most 65535 bands

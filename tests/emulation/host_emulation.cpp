@@ -1006,15 +1006,16 @@ long aai_emu_band_cover(const aai_request *rq, int r0, int r1, int family, long 
         for (int cy = r0; cy <= r1; ++cy)
             for (int cx = 0; cx <= r.dW; ++cx) {
                 // (the kernel's strips of 63 columns: rows outside a strip's live range are not evaluated at all)
-                // (a strip holds kCellLanes cell columns: its kCellCols dst columns and the first one of the next strip; with two cell
-                // rows per step a row is evaluated when it or its partner of the step is live: one row of margin covers either pairing)
+                // (a strip holds the wave's cell columns: its dst columns and the first one of the next strip; with two cell rows per
+                // step -- cell_wave_rows -- a row is evaluated when it or its partner of the step is live: one row of margin covers either
+                // pairing)
                 int liveLo, liveHi;
-                const int x0 = std::min(cx, r.dW - 1) / kCellCols * kCellCols;
-                cell_live_rows(live, x0, x0 + kCellCols, liveLo, liveHi);
-                const int pairing = kCellWaveRows - 1;
+                const int waveRows = cell_wave_rows(r.side, r.scale), cols = cell_wave_cols(waveRows), pairing = waveRows - 1;
+                const int x0 = std::min(cx, r.dW - 1) / cols * cols;
+                cell_live_rows(live, x0, x0 + cols, liveLo, liveHi);
                 bool rowLive = cy >= liveLo - pairing && cy <= liveHi + pairing;
-                if (cx % kCellCols == 0 && cx >= kCellCols) {
-                    cell_live_rows(live, cx - kCellCols, cx, liveLo, liveHi);
+                if (cx % cols == 0 && cx >= cols) {
+                    cell_live_rows(live, cx - cols, cx, liveLo, liveHi);
                     rowLive = rowLive || (cy >= liveLo - pairing && cy <= liveHi + pairing);
                 }
                 if (!rowLive) continue;

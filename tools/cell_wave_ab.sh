@@ -1,0 +1,17 @@
+#!/bin/bash
+# the cell kernel's two wave shapes (AAI_CELL_WAVE=1: 64 x 1, 2: 32 x 2) x rows per wave over geometries, experiments build
+export AAI_LIB=$PWD/area_average_interpolation_amd/libaai_hip_exp.so
+OUT=gpurun_out/cell_wave_ab_${1:-r04}.txt; : > $OUT
+one() {   # workload-or-geometry batch wave rows(0 = the rule's)
+  if [[ "$1" == *,* ]]; then W="--custom $1"; else W="--workload $1"; fi
+  local R=""; [ "$4" != "0" ] && R="AAI_CELL_ROWS=$4"
+  env AAI_CELL_WAVE=$3 $R timeout -k 10 240 python bench.py $W --no-cpu-baseline --traffic off --configs off --steps 5 --warmup 1 --batch $2 --min-seconds 0.7 2>> gpurun_out/cell_wave_ab.err | python -c "
+import json,sys
+d=json.loads(sys.stdin.read()); r=d['roofline']
+print('%-22s x%-2s wave=%s rows=%-3s %9.1f us/launch %8.1f us/image' % ('$1', '$2', '$3', '$4', r['kernel_ms_per_launch']*1e3, r['kernel_ms_per_launch']*1e3/$2))" >> $OUT || echo "FAILED $1 $2 $3 $4" >> $OUT
+}
+for g in "8192,8192,3,1,30" "8192,8192,4,1,45" "8192,8192,5,1,17.5" "8192,8192,2,1,30" "8192,8192,1.6,1,61" "8192,8192,3,1,100"; do
+  one $g 2 1 0; for rows in 8 16 32; do one $g 2 2 $rows; done
+done
+one cfg3 1 1 0; one cfg3 1 2 0; one cfg3 8 1 0; one cfg3 8 2 0
+cat $OUT
