@@ -44,11 +44,13 @@ namespace aai {
 // The shape of the cell kernel's wave.  1: 64 consecutive cell columns of ONE cell row per step (63 dst columns a strip).  2: 32 cell columns
 // of TWO consecutive cell rows (31 dst columns a strip, the upper half-wave a row below the lower one): the two rows' windows share half
 // of their source lines, which one load instruction then fetches once -- L1 -> L2 requests -44 %, fabric reads -54 % at config 3 -- at the
-// price of row pieces of 124 bytes per store instead of 252.  Measured (profiles/r04_cell_kernel.txt, 6.): shape 2 wins where the source
-// is larger than the output (config 3 one image 158 -> 147 us, 8 images per launch 163 -> 130 us per image; 2:1 at 45 degrees level) and
-// loses where the stores weigh as much as the loads (1:1 at 30 degrees 824 -> 934 us, config 5's replicated source 2.65 -> 3.04 ms).
-// The kernel, its launcher and the CPU replay of its fetches (tests/emulation) all ask this function.
-AAI_HD int cell_wave_rows(double side, int scale) { return scale <= 1 && side >= 2.0 ? 2 : 1; }
+// price of row pieces of 124 bytes per store instead of 252 and ~8 % more instructions.  Measured (profiles/r04_cell_kernel.txt, 6.): shape 2
+// wins from about 2.4:1 up (config 3 one image 158 -> 147-150 us, 8 images per launch 163 -> 130 us per image; 3:1 at 30 degrees 330 -> 281,
+// 4:1 at 45 degrees 253 -> 184), is level or behind between 2:1 and 2.3:1 (2.2:1 at 75 degrees 213 -> 238), behind within a few degrees
+// of an axis (2.39:1 at 2 degrees 211 -> 247: a row of 64 cells already runs along the source rows there) and wherever the stores weigh as
+// much as the loads (1:1 at 30 degrees 824 -> 934 us, config 5's replicated source 2.65 -> 3.04 ms).
+// (c, s = cos, sin of the reduced angle.)  The kernel's launcher and the CPU replay of its fetches (tests/emulation) both ask this function.
+AAI_HD int cell_wave_rows(double side, int scale, double c, double s) { return scale <= 1 && side >= 2.35 && (c < s ? c : s) >= 0.1 ? 2 : 1; }
 constexpr int cell_wave_lanes(int waveRows) { return 64 / waveRows; }              // cell columns a wave evaluates per cell row
 constexpr int cell_wave_cols(int waveRows) { return 64 / waveRows - 1; }           // dst columns it completes (the last cell column only feeds its left neighbour)
 

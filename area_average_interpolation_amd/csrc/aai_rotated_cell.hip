@@ -455,7 +455,7 @@ hipError_t launch_cell_tile(const RotLaunch &r, const QuadConsts<float> &q, cons
 {
     const int rows = r.dyEnd - r.dyBase;
     // the wave's shape (cell_wave_rows; experiments build: AAI_CELL_WAVE=1 / 2)
-    int waveRows = cell_wave_rows(r.side, m.scale);
+    int waveRows = cell_wave_rows(r.side, m.scale, r.c, r.s);
     {
         const char *e = experiment_env("AAI_CELL_WAVE");
         if (e && m.scale <= 1 && (atoi(e) == 1 || atoi(e) == 2)) waveRows = atoi(e);

@@ -1010,7 +1010,7 @@ long aai_emu_band_cover(const aai_request *rq, int r0, int r1, int family, long 
                 // step -- cell_wave_rows -- a row is evaluated when it or its partner of the step is live: one row of margin covers either
                 // pairing)
                 int liveLo, liveHi;
-                const int waveRows = cell_wave_rows(r.side, r.scale), cols = cell_wave_cols(waveRows), pairing = waveRows - 1;
+                const int waveRows = cell_wave_rows(r.side, r.scale, r.c, r.s), cols = cell_wave_cols(waveRows), pairing = waveRows - 1;
                 const int x0 = std::min(cx, r.dW - 1) / cols * cols;
                 cell_live_rows(live, x0, x0 + cols, liveLo, liveHi);
                 bool rowLive = cy >= liveLo - pairing && cy <= liveHi + pairing;
