@@ -188,21 +188,24 @@ __device__ __forceinline__ void cell_walk(int dW, int x0, int y0, int y1, bool o
 // sums of THIS step, the lower half keeps the upper half's for the NEXT one) + the N + NW parts of its own cell.  Cell row y1 comes
 // from the wave below (its first row's parts, parked in LDS before the workgroup's one barrier) unless this wave owns the bottom row.
 // Per-cell arithmetic, the order of the additions and therefore every result are those of cell_walk.
-template <int NC, typename Look, typename Eval, typename Emit>
+// (WR = 2; the code is written for WR sub-rows of 64 / WR lanes: sub-row j takes the sums of sub-row j - 1 through a rotation by 64 / WR
+// lanes, sub-row 0 keeps what the last sub-row sends it for the next step.)
+template <int NC, int WR, typename Look, typename Eval, typename Emit>
 __device__ __forceinline__ void cell_walk2(int dW, int x0, int y0, int y1, bool ownsBottom, int wave, CellHandoffN<NC> &hand, int liveLo, int liveHi, int lane,
                                            Look look, Eval eval, Emit emit)
 {
-    static_assert(NC == 1, "the two-row wave serves plain images");
-    const int half = lane >> 5, hl = lane & 31;
+    static_assert(NC == 1, "the multi-row waves serve plain images");
+    constexpr int LANES = 64 / WR;
+    const int half = lane / LANES, hl = lane & (LANES - 1);     // (half: the lane's sub-row of the step)
     const int cx = x0 + hl;
-    const bool column = hl < 31 && cx < dW;                     // this lane's column is one the wave completes
+    const bool column = hl < LANES - 1 && cx < dW;              // this lane's column is one the wave completes
     const int last = ownsBottom ? y1 : y1 - 1;                  // last cell row this wave evaluates itself
     const bool active = y0 < y1;
-    const int other = (lane ^ 32) << 2;                          // ds_bpermute address of the same column in the other half-wave
+    const int other = ((lane - LANES) & 63) << 2;                // ds_bpermute address of the same column in the sub-row above (sub-row 0: the last one)
     float keptA = 0.f, keptVA = 0.f;                             // lower half: own + W of cell row c - 1, handed down by the upper half a step ago
     int keptU = 0;
     bool prevDead = false;                                       // wave-uniform: the previous step's two cell rows cannot touch the image (cell_live_rows)
-    for (int c = y0;; c += 2) {
+    for (int c = y0;; c += WR) {
         const bool first = c == y0;
         const int cy = c + half;
         const int py = cy - 1;                                   // the dst row this lane finishes in this step
@@ -212,7 +215,7 @@ __device__ __forceinline__ void cell_walk2(int dW, int x0, int y0, int y1, bool 
         float ownA = 0.f, ownVA = 0.f, belowA = 0.f, belowVA = 0.f;
         int rowU = 0;
         // (wave-uniform: neither cell row of this step is one the wave evaluates, or both miss the image -- cell_live_rows)
-        const bool dead = c > liveHi || c + 1 < liveLo;
+        const bool dead = c > liveHi || c + WR - 1 < liveLo;
         const bool live = active && c <= last && !dead;
         if (live) {
             float sA[4], sVA[4];
@@ -247,7 +250,7 @@ __device__ __forceinline__ void cell_walk2(int dW, int x0, int y0, int y1, bool 
             else emit(cx, py, aboveA + belowA, total, aboveU | rowU, seen);
         }
         keptA = swapA; keptVA = swapVA; keptU = swapU; prevDead = dead;
-        if (c + 2 > y1) break;
+        if (c + WR > y1) break;
     }
 }
 
@@ -339,7 +342,7 @@ __global__ __launch_bounds__(kQuadBlock, cell_min_waves(WIN)) __attribute__((amd
             // (written once, never read back: around the caches -- 1 % at configs 3 and 5)
             __builtin_nontemporal_store(A > 0.f ? VA[0] / A : 0.f, image + ((int64_t)(py - r.dyBase) * dv.rowStride + px));         // Source.cpp:577
         };
-    if constexpr (WR == 2) cell_walk2<1>(r.dW, x0, y0, y1, ownsBottom, wave, hand, liveLo, liveHi, lane, look, eval, emit);
+    if constexpr (WR >= 2) cell_walk2<1, WR>(r.dW, x0, y0, y1, ownsBottom, wave, hand, liveLo, liveHi, lane, look, eval, emit);
     else cell_walk<1>(r.dW, x0, y0, y1, ownsBottom, wave, hand, liveLo, liveHi, lane, look, eval, emit);
 }
 
@@ -458,7 +461,7 @@ hipError_t launch_cell_tile(const RotLaunch &r, const QuadConsts<float> &q, cons
     int waveRows = cell_wave_rows(r.side, m.scale, r.c, r.s);
     {
         const char *e = experiment_env("AAI_CELL_WAVE");
-        if (e && m.scale <= 1 && (atoi(e) == 1 || atoi(e) == 2)) waveRows = atoi(e);
+        if (e && m.scale <= 1 && (atoi(e) == 1 || atoi(e) == 2 || atoi(e) == 4)) waveRows = atoi(e);      // (4: 16 x 4, experiments build only)
     }
     const int rowsPerWave = cell_rows_per_wave(r.dW, rows, batch, r.side / (m.scale > 0 ? m.scale : 1), waveRows);
     const int strips = (r.dW + cell_wave_cols(waveRows) - 1) / cell_wave_cols(waveRows);
@@ -498,6 +501,11 @@ hipError_t launch_cell_tile(const RotLaunch &r, const QuadConsts<float> &q, cons
     } else if (waveRows == 2) {
         if (HPSEL != 0 && q.hiPrec) AAI_CELL_LAUNCH(false, true, 2);
         if (HPSEL != 1 && !q.hiPrec) AAI_CELL_LAUNCH(false, false, 2);
+#if defined(AAI_EXPERIMENTS)
+    } else if (waveRows == 4) {
+        if (HPSEL != 0 && q.hiPrec) AAI_CELL_LAUNCH(false, true, 4);
+        if (HPSEL != 1 && !q.hiPrec) AAI_CELL_LAUNCH(false, false, 4);
+#endif
     } else {
         if (HPSEL != 0 && q.hiPrec) AAI_CELL_LAUNCH(false, true, 1);
         if (HPSEL != 1 && !q.hiPrec) AAI_CELL_LAUNCH(false, false, 1);
