@@ -386,6 +386,32 @@ def config_block(aai, torch, policy, cfg2_cpu, cpu_procs, cpu_pool, with_cpu, cp
                  "ms": round(ms, 5), "launches": n, "mpix_s": round(B * dW * dH / (ms * 1e-3) / 1e6, 1),
                  "gbps": round(alg / (ms * 1e-3) / 1e9, 1), "frac": round(alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
                  "prepare_ms": round(prepare_ms, 2), "plan": compact_shape(aai.plan_shape(rq))}
+        if name == "cfg3":
+            # the same request as a batch of 8 distinct images in ONE launch (2.1 GB of sources: the 256 MB Infinity Cache, which holds a
+            # single image across the launches above, does not): ms per launch
+            try:
+                B8 = 8
+                src8 = torch.empty((B8, H, W), dtype=torch.float32, device="cuda")
+                dst8 = torch.empty((B8, dH, dW), dtype=torch.float32, device="cuda")
+                for b in range(B8):
+                    aai.synth_device(src8[b].data_ptr(), W, H, W, b + 1, stream)
+
+                def launch8():
+                    aai.resample_device(rq, src8.data_ptr(), W, dst8.data_ptr(), dW, stream, batch=B8, src_image_stride=W * H, dst_image_stride=dW * dH)
+
+                n8 = max(5, n // B8)
+                for _ in range(n8):
+                    launch8()
+                torch.cuda.synchronize()
+                e0.record()
+                for _ in range(n8):
+                    launch8()
+                e1.record()
+                torch.cuda.synchronize()
+                entry["x8_ms"] = round(e0.elapsed_time(e1) / n8, 5)
+                del src8, dst8
+            except Exception as exc:
+                entry["x8_ms"] = "failed: %s" % (str(exc)[:60],)
         if ms < 0.03:
             # a launch-bound configuration: the same launches captured ONCE into a HIP graph (the plan exists: a capture records
             # launches only) and replayed -- what a caller with a fixed pipeline pays per launch
@@ -755,7 +781,7 @@ def worker(args):
             torch.cuda.empty_cache()
             line["configs"] = config_block(aai, torch, policy, line.get("cpu_baseline"), cpu_procs, cpu_pool, not args.no_cpu_baseline, args.cpu_scale)
             line["configs_note"] = ("per BASELINE configuration, kernel-only: ms per launch, output Mpixels/s, algorithmic GB/s and fraction of the 8 TB/s HBM peak, "
-                                    "cold aai_prepare ms, graph_ms = the same launches replayed from a HIP graph (launch-bound configurations only); cpu = [Mpixels/s of the unmodified reference on 1 core of this host, output pixels of its sample, seconds]")
+                                    "cold aai_prepare ms, graph_ms = the same launches replayed from a HIP graph (launch-bound configurations only), x8_ms = 8 distinct images in one launch; cpu = [Mpixels/s of the unmodified reference on 1 core of this host, output pixels of its sample, seconds]")
         if cfg4_rank is not None:
             line["cfg4"] = cfg4_rank
         if saved_stdout is not None:
