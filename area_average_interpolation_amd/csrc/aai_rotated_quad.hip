@@ -305,11 +305,12 @@ __global__ __launch_bounds__(kQuadBlock) void aai_quad_fast_lds_kernel(RotLaunch
 template <typename T, int WIN, bool SCALED, int WORDS>
 __global__ __launch_bounds__(kQuadBlock, 160 / (WIN * WIN * WORDS) >= 6 ? 6 : (160 / (WIN * WIN * WORDS) >= 2 ? 160 / (WIN * WIN * WORDS) : 2))
 void aai_quad_multi_kernel(RotLaunch r, QuadConsts<float> q, QuadMap m, const T *__restrict__ src, ImageView sv, float *__restrict__ dst, ImageView dv,
-                           const unsigned long long *__restrict__ skipMasks)
+                           const unsigned long long *__restrict__ skipMasks, int xcdRows)
 {
     extern __shared__ unsigned windowWords[];
     const int tid = threadIdx.x;
-    const int tx = blockIdx.x, ty = blockIdx.y;
+    int tx = blockIdx.x, ty = blockIdx.y;
+    xcd_tile(xcdRows, tx, ty);                                 // XCD-aware tile order (aai_quad_src.hpp); rows beyond the image leave below
     const int dx = tx * 16 + (tid & 15);
     const int dy = r.dyBase + ty * 16 + (tid >> 4);
     if (!(dx < r.dW && dy < r.dyEnd)) return;
@@ -489,16 +490,21 @@ template <typename T, int WIN, int WORDS>
 hipError_t launch_quad_multi_words(const RotLaunch &r, const QuadConsts<float> &q, const QuadMap &m, const T *src, ImageView sv, float *dst, ImageView dv,
                                    int batch, const unsigned long long *skipMasks, hipStream_t stream)
 {
-    const dim3 grid((r.dW + 15) / 16, (r.dyEnd - r.dyBase + 15) / 16, batch);
+    const dim3 tiles((r.dW + 15) / 16, (r.dyEnd - r.dyBase + 15) / 16, batch);
+    // (the same XCD-aware tile order as the plain kernels of this file)
+    const int band = xcd_band(kFastXcdRowsDefault);
+    const int gy = xcd_grid_rows((int)tiles.y, band);
+    const dim3 grid(tiles.x, gy ? gy : tiles.y, tiles.z);
+    const int xcdRows = gy ? band : 0;
     const size_t lds = (size_t)WIN * WIN * WORDS * kQuadBlock * sizeof(unsigned);
     if (m.scale > 1) {
         static const hipError_t once = hipFuncSetAttribute(reinterpret_cast<const void *>(&aai_quad_multi_kernel<T, WIN, true, WORDS>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)once;
-        hipLaunchKernelGGL((aai_quad_multi_kernel<T, WIN, true, WORDS>), grid, dim3(kQuadBlock), lds, stream, r, q, m, src, sv, dst, dv, skipMasks);
+        hipLaunchKernelGGL((aai_quad_multi_kernel<T, WIN, true, WORDS>), grid, dim3(kQuadBlock), lds, stream, r, q, m, src, sv, dst, dv, skipMasks, xcdRows);
     } else {
         static const hipError_t once = hipFuncSetAttribute(reinterpret_cast<const void *>(&aai_quad_multi_kernel<T, WIN, false, WORDS>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)once;
-        hipLaunchKernelGGL((aai_quad_multi_kernel<T, WIN, false, WORDS>), grid, dim3(kQuadBlock), lds, stream, r, q, m, src, sv, dst, dv, skipMasks);
+        hipLaunchKernelGGL((aai_quad_multi_kernel<T, WIN, false, WORDS>), grid, dim3(kQuadBlock), lds, stream, r, q, m, src, sv, dst, dv, skipMasks, xcdRows);
     }
     return hipGetLastError();
 }
